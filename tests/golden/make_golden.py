@@ -1,0 +1,132 @@
+"""Generate the golden fixtures in tests/golden/ from the reference's importable Python.
+
+Runs ONLY in the build container (needs /root/reference); the fixtures it writes are
+plain data (inputs + expected outputs) and are committed.  Run as
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden.py
+
+What is pinned (these are the only parts of the path the reference can execute here —
+its rasterizer is CUDA and cannot be built in this image):
+  golden_sh.npz      tools/gs_utils/sh_utils.py:57-117   eval_sh  (SH basis constants/signs, deg 0..3)
+  golden_cov3d.npz   tools/gs_utils/general_utils.py:78-113 + volume_rendering/gaussian_model.py:30-33
+                     Sigma = (R S)(R S)^T from (scale, unit quaternion r,x,y,z), 6 upper-tri floats
+  golden_camera.npz  volume_rendering/camera_3dgs.py:22-72, tools/gs_utils/graphics_utils.py:51-84
+                     world_view_transform / projection / full_proj_transform / camera_center
+  golden_misc.npz    tools/gs_utils/general_utils.py:18-19 inverse_sigmoid
+  head_template_geom.npz  vertices + triangle indices of weights/head_template_mouth_close.obj
+                     (input geometry of BASELINE.json configs 2 and 5; data, not code)
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+# the reference hard-codes .cuda()/device="cuda"; run it on CPU
+torch.Tensor.cuda = lambda self, *a, **k: self
+_zeros = torch.zeros
+
+
+def _zeros_cpu(*a, **k):
+    k.pop("device", None)
+    return _zeros(*a, **k)
+
+
+torch.zeros = _zeros_cpu
+
+from tools.gs_utils import sh_utils, general_utils  # noqa: E402
+from volume_rendering.camera_3dgs import Camera  # noqa: E402
+from tools.gs_utils.graphics_utils import getProjectionMatrix  # noqa: E402
+
+
+def gen_sh():
+    g = torch.Generator().manual_seed(1234)
+    N = 257
+    dirs = torch.randn(N, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    sh = torch.rand(N, 16, 3, generator=g) * 2 - 1  # our layout [N, M, 3]
+    out = {}
+    for deg in range(4):
+        res = sh_utils.eval_sh(deg, sh.permute(0, 2, 1), dirs)  # [N,3]
+        out[f"deg{deg}"] = res.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "golden_sh.npz"), dirs=dirs.numpy(), sh=sh.numpy(), **out)
+
+
+def gen_cov3d():
+    g = torch.Generator().manual_seed(99)
+    N = 301
+    s = torch.exp(torch.randn(N, 3, generator=g) * 0.7 - 3.0)
+    q = torch.randn(N, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    for mod in (1.0, 0.37):
+        L = general_utils.build_scaling_rotation(mod * s, q)
+        cov = L @ L.transpose(1, 2)
+        sym = general_utils.strip_symmetric(cov)
+        if mod == 1.0:
+            c1 = sym.numpy().astype(np.float32)
+        else:
+            c2 = sym.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "golden_cov3d.npz"), scales=s.numpy(), quats=q.numpy(), cov_mod1=c1,
+                        cov_mod037=c2)
+
+
+def gen_camera():
+    cams = {}
+    fov = 2 * math.atan(0.2)
+    # config 2/5 camera
+    specs = [("cfg2", torch.diag(torch.tensor([1.0, -1.0, -1.0])), torch.tensor([0.0, 1.47, 0.98]), fov, fov, (512, 512))]
+    g = torch.Generator().manual_seed(7)
+    for k in range(4):
+        A = torch.randn(3, 3, generator=g)
+        Q, _ = torch.linalg.qr(A)
+        if torch.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = torch.randn(3, generator=g)
+        fx = 0.3 + 0.5 * torch.rand(1, generator=g).item()
+        fy = 0.3 + 0.5 * torch.rand(1, generator=g).item()
+        specs.append((f"rand{k}", Q, T, fx, fy, (240 + 16 * k, 320 - 8 * k)))
+    for name, R, T, fx, fy, res in specs:
+        cam = Camera(R.unsqueeze(0), T.unsqueeze(0), fx, fy, res, data_device="cpu")
+        cams[name + "_R"] = R.numpy()
+        cams[name + "_T"] = T.numpy()
+        cams[name + "_fov"] = np.asarray([fx, fy], np.float64)
+        cams[name + "_res"] = np.asarray(res, np.int32)
+        cams[name + "_wvt"] = cam.world_view_transform.numpy()
+        cams[name + "_proj"] = cam.projection_matrix.numpy()
+        cams[name + "_full"] = cam.full_proj_transform.numpy()
+        cams[name + "_center"] = cam.camera_center.numpy()
+    cams["names"] = np.asarray([s[0] for s in specs])
+    np.savez_compressed(os.path.join(OUT, "golden_camera.npz"), **cams)
+
+
+def gen_misc():
+    x = torch.linspace(0.01, 0.99, 50)
+    np.savez_compressed(os.path.join(OUT, "golden_misc.npz"), x=x.numpy(),
+                        inverse_sigmoid=general_utils.inverse_sigmoid(x).numpy())
+
+
+def gen_head():
+    verts, faces = [], []
+    with open(os.path.join(REF, "weights", "head_template_mouth_close.obj")) as f:
+        for line in f:
+            if line.startswith("v "):
+                verts.append([float(t) for t in line.split()[1:4]])
+            elif line.startswith("f "):
+                faces.append([int(t.split("/")[0]) - 1 for t in line.split()[1:4]])
+    np.savez_compressed(os.path.join(OUT, "head_template_geom.npz"), verts=np.asarray(verts, np.float32),
+                        faces=np.asarray(faces, np.int32))
+
+
+if __name__ == "__main__":
+    gen_sh()
+    gen_cov3d()
+    gen_camera()
+    gen_misc()
+    gen_head()
+    print("golden fixtures written to", OUT)
