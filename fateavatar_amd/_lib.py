@@ -1,0 +1,124 @@
+"""ctypes binding of libfr_hip.so (the C ABI of include/fr_rasterizer.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises —
+there is no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfr_hip.so")
+
+FR_OK = 0
+FR_ERR_INVALID_ARGUMENT = 1
+FR_ERR_BINNING_CAPACITY = 2
+FR_ERR_HIP = 3
+FR_ERR_UNSUPPORTED = 4
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class fr_params(C.Structure):
+    _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+
+
+class fr_inputs(C.Structure):
+    _fields_ = [(n, _fp) for n in ("background", "means3D", "shs", "colors_precomp", "opacities", "scales",
+                                   "rotations", "cov3D_precomp", "viewmatrix", "projmatrix", "campos")]
+
+
+class fr_grads(C.Structure):
+    _fields_ = [(n, _fp) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+                                   "dL_dscales", "dL_drotations")]
+
+
+class fr_counts(C.Structure):
+    _fields_ = [("num_rendered", C.c_uint32), ("num_instances", C.c_uint32), ("max_tile_list", C.c_uint32),
+                ("overflow", C.c_uint32)]
+
+
+EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_geometry_bytes", "fr_image_bytes",
+           "fr_binning_bytes", "fr_forward", "fr_backward", "fr_mark_visible", "fr_image_final_T",
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_knn_workspace_bytes", "fr_knn_mean_dist2"]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C fateavatar_amd/csrc`). There is no fallback path.")
+    L = C.CDLL(SO_PATH)
+    L.fr_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.fr_create.restype = C.c_int
+    L.fr_destroy.argtypes = [C.c_void_p]
+    L.fr_last_error.restype = C.c_char_p
+    L.fr_version.restype = C.c_char_p
+    L.fr_geometry_bytes.argtypes = [C.c_int32]
+    L.fr_geometry_bytes.restype = C.c_size_t
+    L.fr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.fr_image_bytes.restype = C.c_size_t
+    L.fr_binning_bytes.argtypes = [C.c_uint64]
+    L.fr_binning_bytes.restype = C.c_size_t
+    L.fr_forward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
+                             C.c_uint64, C.POINTER(fr_counts), C.c_void_p]
+    L.fr_forward.restype = C.c_int
+    L.fr_backward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
+                              C.POINTER(fr_grads), C.c_void_p]
+    L.fr_backward.restype = C.c_int
+    L.fr_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]
+    L.fr_mark_visible.restype = C.c_int
+    L.fr_image_final_T.argtypes = [_fp, C.c_int32, C.c_int32]
+    L.fr_image_final_T.restype = C.c_void_p
+    L.fr_image_n_contrib.argtypes = [_fp, C.c_int32, C.c_int32]
+    L.fr_image_n_contrib.restype = C.c_void_p
+    L.fr_debug_geometry_field.argtypes = [_fp, C.c_int32, C.c_int32]
+    L.fr_debug_geometry_field.restype = C.c_void_p
+    L.fr_knn_workspace_bytes.argtypes = [C.c_int32]
+    L.fr_knn_workspace_bytes.restype = C.c_size_t
+    L.fr_knn_mean_dist2.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
+    L.fr_knn_mean_dist2.restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().fr_last_error().decode("utf-8", "replace")
+
+
+_handles: dict = {}
+
+
+def handle(device_index: int):
+    """One fr_handle per device (created with that device current)."""
+    h = _handles.get(device_index)
+    if h is None:
+        import torch
+
+        with torch.cuda.device(device_index):
+            out = C.c_void_p()
+            rc = lib().fr_create(C.byref(out))
+            if rc != FR_OK:
+                raise RuntimeError(f"fr_create failed: {last_error()}")
+        h = out
+        _handles[device_index] = h
+    return h

@@ -1,0 +1,151 @@
+// extern "C" entry points declared in include/fr_rasterizer.h.  Argument checking, handle
+// lifetime, error strings; the work is in fr_preprocess.hip / fr_blend.hip /
+// fr_preprocess_bwd.hip / fr_knn.hip.
+#include "fr_common.hpp"
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace fr {
+
+thread_local char g_err[512] = "";
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line)
+{
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+    return FR_ERR_HIP;
+}
+int fail_msg(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+static int check_frame(const fr_params* prm, const fr_inputs* in, bool forward)
+{
+    if (!prm || !in) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null params/inputs");
+    if (prm->P < 0 || prm->W <= 0 || prm->H <= 0) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad P/W/H");
+    if (prm->W > 8 * 65535 || prm->H > 8 * 65535) return fail_msg(FR_ERR_UNSUPPORTED, "image larger than 65535 tiles per axis");
+    if (prm->D < 0 || prm->D > 3) return fail_msg(FR_ERR_INVALID_ARGUMENT, "SH degree must be 0..3");
+    if (prm->P == 0) return FR_OK;
+    // opacities are only read by the forward (the backward takes them from the geometry state)
+    if (!in->means3D || (forward && !in->opacities) || !in->viewmatrix || !in->projmatrix || !in->campos || !in->background)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "missing required input pointer");
+    // exactly one of shs / colors_precomp, exactly one of (scales+rotations) / cov3D_precomp
+    // (the reference enforces this in Python: diff_gaussian_rasterization/__init__.py:191-195)
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "provide exactly one of shs / colors_precomp");
+    const bool sr = in->scales && in->rotations;
+    if ((in->scales == nullptr) != (in->rotations == nullptr) || (sr == (in->cov3D_precomp != nullptr)))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations / cov3D_precomp");
+    if (in->shs && prm->M < (prm->D + 1) * (prm->D + 1))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "M smaller than (D+1)^2");
+    return FR_OK;
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+const char* fr_last_error(void) { return g_err; }
+const char* fr_version(void) { return "fateavatar_amd rasterizer 0.1 (gfx950, wave64, 8x8 tiles)"; }
+
+int fr_create(fr_handle** out)
+{
+    if (!out) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null out");
+    fr_handle_impl* h = new (std::nothrow) fr_handle_impl();
+    if (!h) return fail_msg(FR_ERR_HIP, "out of host memory");
+    FR_HIP(hipGetDevice(&h->device));
+    FR_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_counts), 64, hipHostMallocMapped));
+    memset(h->host_counts, 0, 64);
+    FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
+    FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
+    *out = reinterpret_cast<fr_handle*>(h);
+    return FR_OK;
+}
+
+int fr_destroy(fr_handle* hh)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h) return FR_OK;
+    (void)hipEventDestroy(h->counts_ready);
+    (void)hipHostFree(h->host_counts);
+    delete h;
+    return FR_OK;
+}
+
+size_t fr_geometry_bytes(int32_t P) { return GeomView::bytes((size_t)(P > 0 ? P : 0)); }
+size_t fr_image_bytes(int32_t W, int32_t H) { return ImageView::bytes(W, H); }
+size_t fr_binning_bytes(uint64_t capacity) { return BinningView::bytes((size_t)capacity); }
+
+int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
+               void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts, void* stream)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
+    int rc = check_frame(prm, in, true);
+    if (rc) return rc;
+    if (!out_color || !image || (prm->P > 0 && (!radii || !geometry)) || (binning_capacity > 0 && !binning))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "null output / scratch pointer");
+    if (binning_capacity >= (1ull << 32)) return fail_msg(FR_ERR_UNSUPPORTED, "binning capacity must be < 2^32 instances");
+    return launch_forward(h, *prm, *in, out_color, radii, geometry, image, binning, binning_capacity, counts,
+                          static_cast<hipStream_t>(stream));
+}
+
+int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,
+                const void* image, const void* binning, const float* dL_dpix, const fr_grads* grads, void* stream)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
+    int rc = check_frame(prm, in, false);
+    if (rc) return rc;
+    if (prm->P == 0) return FR_OK;
+    if (!radii || !geometry || !image || !binning || !dL_dpix || !grads)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "null pointer");
+    return launch_backward(h, *prm, *in, radii, geometry, image, binning, dL_dpix, *grads, static_cast<hipStream_t>(stream));
+}
+
+int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                    void* stream)
+{
+    (void)projmatrix;  // the reference computes but does not use the projected point (auxiliary.h:149-154)
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
+    return launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream));
+}
+
+const float* fr_image_final_T(const void* image, int32_t W, int32_t H)
+{
+    return ImageView::make(const_cast<void*>(image), W, H).final_T;
+}
+const uint32_t* fr_image_n_contrib(const void* image, int32_t W, int32_t H)
+{
+    return ImageView::make(const_cast<void*>(image), W, H).n_contrib;
+}
+
+const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t field)
+{
+    GeomView g = GeomView::make(const_cast<void*>(geometry), (size_t)(P > 0 ? P : 0));
+    switch (field) {
+        case 0: return g.means2D;
+        case 1: return g.depth;
+        case 2: return g.conic_opacity;
+        case 3: return g.rgba;
+        case 4: return g.cov3D;
+        case 5: return g.rect;
+        case 6: return g.clamped;
+        case 7: return g.accum;
+        default: return nullptr;
+    }
+}
+
+size_t fr_knn_workspace_bytes(int32_t P) { return knn_workspace_bytes(P); }
+
+int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (P < 0 || (P > 0 && (!points || !out || !workspace))) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
+    return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

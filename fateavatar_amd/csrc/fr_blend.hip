@@ -1,0 +1,374 @@
+// Per-tile stages for gfx950: depth sort of each 8x8 tile's list, front-to-back alpha blend
+// (forward) and back-to-front gradient pass (backward).
+//
+// Execution model: ONE 64-lane wavefront per 8x8-pixel tile, one pixel per lane, no
+// workgroup barriers anywhere.  The sort runs in registers (bitonic network across lanes and
+// registers).  It leaves, per tile, a contiguous array of 48-byte splat RECORDS in blend
+// order; both blend kernels walk that array with wave-uniform addresses, so the record
+// fetches are scalar loads (SMEM -> SGPRs) and the VALU only does per-pixel math.
+#include "fr_common.hpp"
+
+namespace fr {
+
+// 48-byte record = 3 x float4:
+//   q0 = (x, y, conic_a, conic_b)   q1 = (conic_c, opacity, r, g)   q2 = (b, id_bits, 0, 0)
+constexpr int kRecQuads = 3;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
+
+// ---- bitonic network, "flip" formulation (every compare-exchange puts the smaller key at the
+// lower index), element index i = r*64 + lane.
+template <int K>
+__device__ __forceinline__ void lane_xor_stage(u64 (&v)[K], int lane, int mask, int low_bit)
+{
+    // partner = lane ^ mask in the same register; this lane is the lower index iff (lane & low_bit) == 0
+    const bool lower = (lane & low_bit) == 0;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const u64 a = v[r];
+        const u64 b = shfl_xor_u64(a, mask);
+        v[r] = lower ? umin64(a, b) : umax64(a, b);
+    }
+}
+
+template <int K, int KK>
+__device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
+{
+    // merge step for blocks of KK > 64 elements
+    constexpr int m = (KK >> 6) - 1;
+    // flip: partner index = i ^ (KK-1)  ->  register r ^ m, lane ^ 63
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const int rp = r ^ m;
+        if (rp > r) {
+            const u64 a = v[r], b = v[rp];
+            const u64 sa = shfl_xor_u64(a, 63), sb = shfl_xor_u64(b, 63);
+            v[r] = umin64(a, sb);
+            v[rp] = umax64(b, sa);
+        }
+    }
+    // half-cleaners with distance >= 64: pure register exchanges
+#pragma unroll
+    for (int j = KK >> 2; j >= 64; j >>= 1) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            const int rp = r ^ jr;
+            if (rp > r) {
+                const u64 a = v[r], b = v[rp];
+                v[r] = umin64(a, b);
+                v[rp] = umax64(a, b);
+            }
+        }
+    }
+    // half-cleaners with distance < 64
+    for (int j = (KK >> 2) < 32 ? (KK >> 2) : 32; j > 0; j >>= 1) lane_xor_stage<K>(v, lane, j, j);
+}
+
+template <int K>
+__device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
+{
+    for (int k = 2; k <= 64; k <<= 1) {
+        lane_xor_stage<K>(v, lane, k - 1, k >> 1);  // flip inside blocks of k lanes
+        for (int j = k >> 2; j > 0; j >>= 1) lane_xor_stage<K>(v, lane, j, j);
+    }
+    if constexpr (K >= 2) big_stage<K, 128>(v, lane);
+    if constexpr (K >= 4) big_stage<K, 256>(v, lane);
+    if constexpr (K >= 8) big_stage<K, 512>(v, lane);
+    if constexpr (K >= 16) big_stage<K, 1024>(v, lane);
+}
+
+__device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g)
+{
+    const float2 xy = g.means2D[id];
+    const float4 co = g.conic_opacity[id];
+    const float4 c = g.rgba[id];
+    float4* r = recs + (size_t)pos * kRecQuads;
+    r[0] = make_float4(xy.x, xy.y, co.x, co.y);
+    r[1] = make_float4(co.z, co.w, c.x, c.y);
+    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);
+}
+
+template <int K>
+__device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, uint32_t start, uint32_t n, int lane,
+                                               const GeomView& g)
+{
+    u64 v[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const uint32_t i = (uint32_t)(r * 64 + lane);
+        v[r] = i < n ? keys[start + i] : ~0ull;
+    }
+    wave_sort<K>(v, lane);
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const uint32_t i = (uint32_t)(r * 64 + lane);
+        if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
+    }
+}
+
+// Slow path for a tile list longer than kSortRegMax: bitonic network over the tile's key segment
+// in global memory by one 256-thread workgroup (virtual +inf padding: a compare-exchange whose
+// upper index is >= n is a no-op in the flip formulation).  Agent-scope accesses keep the data
+// out of the per-CU L1 so that waves of the workgroup see each other's stores.
+__device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g)
+{
+    u64* seg = keys + start;
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    auto stage = [&](uint32_t mask) {
+        for (uint32_t i = tid; i < N; i += nt) {
+            const uint32_t p = i ^ mask;
+            if (p > i && p < n) {
+                const u64 a = __hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 b = __hip_atomic_load(seg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b < a) {
+                    __hip_atomic_store(seg + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(seg + p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        stage(k - 1);                                    // flip
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) stage(j);  // half-cleaners
+    }
+    for (uint32_t i = tid; i < n; i += nt) {
+        const u64 kv = __hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        write_record(recs, start + i, (uint32_t)kv, g);
+    }
+}
+
+// Grid: ceil(T/4) "small" workgroups (4 waves = 4 tiles each) followed by kLargeSorters
+// workgroups that drain the queue of over-long tiles.
+constexpr int kLargeSorters = 8;
+
+__global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t small_blocks, u64* keys,
+                                                   float4* recs, GeomView g)
+{
+    if (v.counts->overflow) return;
+    if (blockIdx.x >= small_blocks) {
+        __shared__ uint32_t s_item;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_item = atomicAdd(&v.counts->large_cursor, 1u);
+            __syncthreads();
+            const uint32_t item = s_item;
+            if (item >= v.counts->large_tiles) return;
+            const uint32_t tile = v.large_list[item];
+            sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_count[tile], g);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (tile >= T) return;
+    const uint32_t n = v.tile_count[tile];
+    if (n == 0 || n > (uint32_t)kSortRegMax) return;
+    const uint32_t start = v.tile_offset[tile];
+    if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
+    else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
+    else if (n <= 256) sort_tile_regs<4>(keys, recs, start, n, lane, g);
+    else if (n <= 512) sort_tile_regs<8>(keys, recs, start, n, lane, g);
+    else sort_tile_regs<16>(keys, recs, start, n, lane, g);
+}
+
+// ------------------------------------------------------------------ blend forward
+// reference: renderCUDA, forward.cu:261-374.  Per pixel the sequence of operations (and the
+// tests power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) is the reference's; only the order of
+// evaluation across pixels differs.
+__global__ void __launch_bounds__(64) k_blend_fwd(const uint32_t* __restrict__ tile_offset,
+                                                  const float4* __restrict__ recs, int W, int H, int tiles_x,
+                                                  const float* __restrict__ bg, float* __restrict__ out_color,
+                                                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                  const DeviceCounts* __restrict__ counts)
+{
+    if (counts->overflow) return;
+    const uint32_t tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
+    const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
+
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    for (uint32_t pos = start; pos < end; ++pos) {
+        if (((pos - start) & 7u) == 0 && __all(done)) break;
+        const float4 q0 = recs[(size_t)pos * kRecQuads + 0];
+        const float4 q1 = recs[(size_t)pos * kRecQuads + 1];
+        const float q2x = recs[(size_t)pos * kRecQuads + 2].x;
+        const float dx = q0.x - fx, dy = q0.y - fy;
+        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+        const float alpha = fminf(0.99f, q1.y * __expf(power));
+        bool c = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        const float test_T = T * (1.f - alpha);
+        const bool fin = c && (test_T < 0.0001f);
+        done = done || fin;
+        c = c && !fin;
+        const float w = c ? alpha * T : 0.f;
+        Cr += q1.z * w;
+        Cg += q1.w * w;
+        Cb += q2x * w;
+        T = c ? test_T : T;
+        last = c ? (pos - start + 1u) : last;
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = Cr + T * bg[0];
+        out_color[HW + pix] = Cg + T * bg[1];
+        out_color[2 * HW + pix] = Cb + T * bg[2];
+    }
+}
+
+// ------------------------------------------------------------------ blend backward
+// reference: renderCUDA, backward.cu:399-557.  Per (pixel, Gaussian) pair the arithmetic is the
+// reference's; instead of 9 global atomics per contributing pair, the 64 pixels of the tile are
+// reduced inside the wavefront and ONE lane issues 9 atomics per (tile, Gaussian) instance.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    // xor butterfly inside rows of 16 lanes with DPP, then across the four rows
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_blend_bwd(const uint32_t* __restrict__ tile_offset,
+                                                  const float4* __restrict__ recs, int W, int H, int tiles_x,
+                                                  const float* __restrict__ bg, const float* __restrict__ final_T,
+                                                  const uint32_t* __restrict__ n_contrib,
+                                                  const float* __restrict__ dL_dpix, float* __restrict__ accum)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
+    if (end == start) return;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
+    const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const size_t pix = inside ? (size_t)py * W + px : 0, HW = (size_t)H * W;
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float T = T_final;
+    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
+    if (inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
+    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;  // accum_rec
+    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // nothing behind the deepest contributor of any pixel of the tile can matter
+    uint32_t max_last = last;
+    for (int off = 32; off > 0; off >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor(max_last, off));
+    max_last = __builtin_amdgcn_readfirstlane(max_last);
+
+    for (uint32_t k = max_last; k-- > 0;) {
+        const uint32_t pos = start + k;
+        const float4 q0 = recs[(size_t)pos * kRecQuads + 0];
+        const float4 q1 = recs[(size_t)pos * kRecQuads + 1];
+        const float4 q2 = recs[(size_t)pos * kRecQuads + 2];
+        const float dx = q0.x - fx, dy = q0.y - fy;
+        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, q1.y * G);
+        const bool c = (k < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        if (!__any(c)) continue;
+
+        const float Tn = T / (1.f - alpha);
+        T = c ? Tn : T;
+        const float dchannel_dcolor = c ? alpha * T : 0.f;
+        // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
+        const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
+        const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
+        const float nb = last_alpha * last_b + (1.f - last_alpha) * acc_b;
+        acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nb : acc_b;
+        last_r = c ? q1.z : last_r, last_g = c ? q1.w : last_g, last_b = c ? q2.x : last_b;
+        float dL_dalpha = ((q1.z - acc_r) * dpr + (q1.w - acc_g) * dpg) + (q2.x - acc_b) * dpb;
+        dL_dalpha *= T;
+        last_alpha = c ? alpha : last_alpha;
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        dL_dalpha = c ? dL_dalpha : 0.f;
+
+        const float Gc = c ? G : 0.f;  // G may be inf/NaN on lanes that failed the tests
+        const float dL_dG = q1.y * dL_dalpha;
+        const float gdx = Gc * dx, gdy = Gc * dy;
+        const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+        const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+
+        float s[9];
+        s[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
+        s[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
+        s[ACC_CA] = -0.5f * gdx * dx * dL_dG;
+        s[ACC_CB] = -0.5f * gdx * dy * dL_dG;
+        s[ACC_CC] = -0.5f * gdy * dy * dL_dG;
+        s[ACC_OP] = Gc * dL_dalpha;
+        s[ACC_R] = dchannel_dcolor * dpr;
+        s[ACC_G] = dchannel_dcolor * dpg;
+        s[ACC_B] = dchannel_dcolor * dpb;
+#pragma unroll
+        for (int i = 0; i < 9; i++) s[i] = wave_sum(s[i]);
+        if (lane == 0) {
+            float* a = accum + (size_t)__float_as_uint(q2.y) * kAccumStride;
+#pragma unroll
+            for (int i = 0; i < 9; i++) atomic_add_f32(a + i, s[i]);
+        }
+    }
+}
+
+static int debug_sync(bool debug, hipStream_t s, const char* stage)
+{
+    if (!debug) return FR_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail_hip(e, stage, __FILE__, __LINE__);
+    return FR_OK;
+}
+
+int launch_sort_and_blend(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
+                          float* out_color, hipStream_t s, bool debug)
+{
+    const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+    const uint32_t small_blocks = (T + 3) / 4;
+    int rc;
+    hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters), dim3(256), 0, s, v, T, small_blocks,
+                       (u64*)b.keys, b.recs, g);
+    FR_HIP(hipGetLastError());
+    if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
+    hipLaunchKernelGGL(k_blend_fwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
+                       v.tiles_x, in.background, out_color, v.final_T, v.n_contrib, v.counts);
+    FR_HIP(hipGetLastError());
+    if ((rc = debug_sync(debug, s, "blend_fwd"))) return rc;
+    return FR_OK;
+}
+
+int launch_blend_backward(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
+                          const float* dL_dpix, hipStream_t s, bool debug)
+{
+    const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+    hipLaunchKernelGGL(k_blend_bwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
+                       v.tiles_x, in.background, v.final_T, v.n_contrib, dL_dpix, g.accum);
+    FR_HIP(hipGetLastError());
+    return debug_sync(debug, s, "blend_bwd");
+}
+
+}  // namespace fr

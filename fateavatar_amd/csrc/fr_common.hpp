@@ -1,0 +1,175 @@
+// Shared declarations for the gfx950 rasterizer kernels: scratch-buffer layouts, error
+// plumbing, wave-level helpers.  CDNA4 only: wavefront = 64 lanes, tile = 8x8 pixels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/fr_rasterizer.h"
+
+namespace fr {
+
+constexpr int kWave = 64;
+constexpr int kTile = 8;    // 8x8 pixels = one wavefront
+constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): radii / num_rendered semantics
+constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
+constexpr int kSortRegMax = 1024; // longest tile list the in-register wave sort handles
+
+// accumulator slots (blend backward -> preprocess backward)
+enum { ACC_MX = 0, ACC_MY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8 };
+
+extern thread_local char g_err[512];
+int fail_hip(hipError_t e, const char* what, const char* file, int line);
+int fail_msg(int code, const char* msg);
+
+#define FR_HIP(expr)                                                          \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return ::fr::fail_hip(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static inline T* carve(char*& p, size_t count)
+{
+    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
+    T* r = reinterpret_cast<T*>(a);
+    p = reinterpret_cast<char*>(r + count);
+    return r;
+}
+
+// Per-Gaussian state written by the forward preprocess and read by every later stage.
+struct GeomView {
+    float2* means2D;        // [P] pixel-space centre
+    float* depth;           // [P] view-space z
+    float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
+    float4* rgba;           // [P] colour fed to the blend (SH result or colors_precomp), w unused
+    float* cov3D;           // [P*6]
+    uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive
+    uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
+    float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
+    static GeomView make(void* buf, size_t P)
+    {
+        char* p = static_cast<char*>(buf);
+        GeomView g;
+        g.means2D = carve<float2>(p, P);
+        g.depth = carve<float>(p, P);
+        g.conic_opacity = carve<float4>(p, P);
+        g.rgba = carve<float4>(p, P);
+        g.cov3D = carve<float>(p, P * 6);
+        g.rect = carve<uint2>(p, P);
+        g.clamped = carve<uint8_t>(p, P);
+        g.accum = carve<float>(p, P * kAccumStride);
+        return g;
+    }
+    static size_t bytes(size_t P)
+    {
+        char* p = nullptr;
+        GeomView g = make(p, P);
+        return reinterpret_cast<size_t>(g.accum + P * kAccumStride) + 256;
+    }
+};
+
+struct DeviceCounts {  // lives at the head of the image buffer
+    uint32_t num_rendered;   // reference semantics
+    uint32_t num_instances;
+    uint32_t max_tile_list;
+    uint32_t overflow;
+    uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
+    uint32_t large_cursor;   // work-queue head for the large-tile sorter
+    uint32_t pad[2];
+};
+
+struct ImageView {
+    DeviceCounts* counts;
+    uint32_t* tile_count;    // [T]   instances per 8x8 tile
+    uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
+    uint32_t* tile_cursor;   // [T]   emit cursors (start at tile_offset)
+    uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
+    float* final_T;          // [W*H]
+    uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
+    int tiles_x, tiles_y;
+    static ImageView make(void* buf, int W, int H)
+    {
+        char* p = static_cast<char*>(buf);
+        ImageView v;
+        v.tiles_x = (W + kTile - 1) / kTile;
+        v.tiles_y = (H + kTile - 1) / kTile;
+        size_t T = (size_t)v.tiles_x * v.tiles_y;
+        v.counts = carve<DeviceCounts>(p, 1);
+        v.tile_count = carve<uint32_t>(p, T);
+        v.tile_offset = carve<uint32_t>(p, T + 1);
+        v.tile_cursor = carve<uint32_t>(p, T);
+        v.large_list = carve<uint32_t>(p, T);
+        v.final_T = carve<float>(p, (size_t)W * H);
+        v.n_contrib = carve<uint32_t>(p, (size_t)W * H);
+        return v;
+    }
+    static size_t bytes(int W, int H)
+    {
+        ImageView v = make(nullptr, W, H);
+        return reinterpret_cast<size_t>(v.n_contrib + (size_t)W * H) + 256;
+    }
+    // bytes from the start of the buffer that must be zero before a forward (counts + tile_count)
+    size_t zero_bytes(const void* base) const
+    {
+        size_t T = (size_t)tiles_x * tiles_y;
+        return reinterpret_cast<const char*>(tile_count + T) - static_cast<const char*>(base);
+    }
+};
+
+struct BinningView {
+    uint64_t* keys;  // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
+    float4* recs;    // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
+    static BinningView make(void* buf, size_t cap)
+    {
+        char* p = static_cast<char*>(buf);
+        BinningView b;
+        b.keys = carve<uint64_t>(p, cap);
+        b.recs = carve<float4>(p, cap * 3);
+        return b;
+    }
+    static size_t bytes(size_t cap)
+    {
+        BinningView b = make(nullptr, cap);
+        return reinterpret_cast<size_t>(b.recs + cap * 3) + 256;
+    }
+};
+
+struct fr_handle_impl {
+    int device;
+    fr_counts* host_counts;      // pinned, mapped
+    fr_counts* host_counts_dev;  // device view of the same memory
+    hipEvent_t counts_ready;
+};
+
+// ---- stage launchers (defined in the .hip files) ----
+int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, float* out_color, int32_t* radii,
+                   void* geometry, void* image, void* binning, uint64_t cap, fr_counts* counts, hipStream_t s);
+int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
+                    const void* image, const void* binning, const float* dL_dpix, const fr_grads& g, hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+size_t knn_workspace_bytes(int P);
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// HW fp32 atomic add (global_atomic_add_f32), no return value needed.
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// reference auxiliary.h:58-77 — matrices are indexed column-major
+__device__ __forceinline__ float3 xform4x3(const float3 p, const float* m)
+{
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(const float3 p, const float* m)
+{
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+#endif
+
+}  // namespace fr

@@ -1,0 +1,370 @@
+// Per-Gaussian forward stages for gfx950: preprocess (cull, project, covariance, SH colour,
+// tile rectangle, tile histogram), tile scan, instance emission.
+//
+// Compiled with -ffp-contract=off: the per-Gaussian arithmetic below is written in the same
+// operation order as the reference (forward.cu:74-152,155-256; auxiliary.h:41-77), so radii,
+// pixel centres, conics, depths and colours are bit-comparable with the CPU oracle.  These
+// kernels are bandwidth-trivial; the missing FMAs cost nothing measurable.
+#include "fr_common.hpp"
+
+namespace fr {
+
+__constant__ float kSH_C0 = 0.28209479177387814f;
+__constant__ float kSH_C1 = 0.4886025119029199f;
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+struct PreArgs {
+    int P, D, M, W, H;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    int* radii;
+    GeomView g;
+    uint32_t* tile_count;
+    DeviceCounts* counts;
+    int tiles_x, tiles_y;   // 8x8 tiles
+    int ref_gx, ref_gy;     // 16x16 tiles (reference grid)
+};
+
+// SH -> RGB for one channel; same expression tree as forward.cu:30-63.
+__device__ __forceinline__ float sh_channel(const float* sh, int c, int deg, float x, float y, float z)
+{
+#define SH(k) sh[(k) * 3 + c]
+    float result = kSH_C0 * SH(0);
+    if (deg > 0) {
+        result = result - kSH_C1 * y * SH(1) + kSH_C1 * z * SH(2) - kSH_C1 * x * SH(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            result = result + kSH_C2[0] * xy * SH(4) + kSH_C2[1] * yz * SH(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                     kSH_C2[3] * xz * SH(7) + kSH_C2[4] * (xx - yy) * SH(8);
+            if (deg > 2) {
+                result = result + kSH_C3[0] * y * (3.0f * xx - yy) * SH(9) + kSH_C3[1] * xy * z * SH(10) +
+                         kSH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                         kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                         kSH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + kSH_C3[5] * z * (xx - yy) * SH(14) +
+                         kSH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+            }
+        }
+    }
+#undef SH
+    return result + 0.5f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One thread per Gaussian.  reference: preprocessCUDA, forward.cu:155-256.
+__global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ref_tiles = 0;  // tiles_touched in reference semantics (16x16)
+    if (idx < a.P) {
+        int radius_out = 0;
+        uint2 rect = make_uint2(0u, 0u);
+        do {
+            const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+            // near cull only (auxiliary.h:154)
+            const float3 p_view = xform4x3(p_orig, a.view);
+            if (p_view.z <= 0.2f) break;
+
+            const float4 p_hom = xform4x4(p_orig, a.proj);
+            const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+            const float p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
+
+            // ---- Sigma3D = R S^2 R^T, 6 upper-triangular floats (forward.cu:118-152)
+            float c3[6];
+            if (a.cov3D_precomp) {
+                for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+            } else {
+                const float s0 = a.scale_modifier * a.scales[3 * idx], s1 = a.scale_modifier * a.scales[3 * idx + 1],
+                            s2 = a.scale_modifier * a.scales[3 * idx + 2];
+                const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
+                            z = a.rotations[4 * idx + 3];
+                // rows of the rotation matrix, each entry scaled by the scale of its COLUMN index
+                const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)),
+                            m02 = s2 * (2.f * (x * z + r * y));
+                const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)),
+                            m12 = s2 * (2.f * (y * z - r * x));
+                const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)),
+                            m22 = s2 * (1.f - 2.f * (x * x + y * y));
+                c3[0] = m00 * m00 + m01 * m01 + m02 * m02;
+                c3[1] = m10 * m00 + m11 * m01 + m12 * m02;
+                c3[2] = m20 * m00 + m21 * m01 + m22 * m02;
+                c3[3] = m10 * m10 + m11 * m11 + m12 * m12;
+                c3[4] = m20 * m10 + m21 * m11 + m22 * m12;
+                c3[5] = m20 * m20 + m21 * m21 + m22 * m22;
+                for (int k = 0; k < 6; k++) a.g.cov3D[6 * (size_t)idx + k] = c3[k];
+            }
+
+            // ---- EWA projection to a 2D covariance (forward.cu:74-113)
+            float3 t = p_view;  // transformPoint4x3(mean, viewmatrix) again in the reference; same value
+            const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+            const float txtz = t.x / t.z, tytz = t.y / t.z;
+            t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+            t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+            const float j00 = a.focal_x / t.z, j02 = -(a.focal_x * t.x) / (t.z * t.z);
+            const float j11 = a.focal_y / t.z, j12 = -(a.focal_y * t.y) / (t.z * t.z);
+            const float* vm = a.view;
+            // T = J * W (2x3): row 0 and row 1; the zero products are kept so the sums round identically
+            float T0[3], T1[3];
+            for (int w = 0; w < 3; w++) {
+                const float W0 = vm[4 * w], W1 = vm[4 * w + 1], W2 = vm[4 * w + 2];
+                T0[w] = W0 * j00 + W1 * 0.0f + W2 * j02;
+                T1[w] = W0 * 0.0f + W1 * j11 + W2 * j12;
+            }
+            const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+            float A0[3], A1[3];  // (T * Sigma) rows
+            for (int c = 0; c < 3; c++) {
+                A0[c] = T0[0] * V[0][c] + T0[1] * V[1][c] + T0[2] * V[2][c];
+                A1[c] = T1[0] * V[0][c] + T1[1] * V[1][c] + T1[2] * V[2][c];
+            }
+            float cov_a = A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2];
+            const float cov_b = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2];
+            float cov_c = A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2];
+            cov_a += 0.3f;
+            cov_c += 0.3f;
+
+            const float det = (cov_a * cov_c - cov_b * cov_b);
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float conic_a = cov_c * det_inv, conic_b = -cov_b * det_inv, conic_c = cov_a * det_inv;
+
+            const float mid = 0.5f * (cov_a + cov_c);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix in double (auxiliary.h:41-44)
+            const float pix_x = (float)((((double)p_proj_x + 1.0) * a.W - 1.0) * 0.5);
+            const float pix_y = (float)((((double)p_proj_y + 1.0) * a.H - 1.0) * 0.5);
+            // reference 16x16 rectangle (auxiliary.h:46-56)
+            const int mr = (int)my_radius;
+            const int rx0 = min(a.ref_gx, max(0, (int)((pix_x - mr) / kRefTile)));
+            const int ry0 = min(a.ref_gy, max(0, (int)((pix_y - mr) / kRefTile)));
+            const int rx1 = min(a.ref_gx, max(0, (int)((pix_x + mr + kRefTile - 1) / kRefTile)));
+            const int ry1 = min(a.ref_gy, max(0, (int)((pix_y + mr + kRefTile - 1) / kRefTile)));
+            if ((rx1 - rx0) * (ry1 - ry0) == 0) break;
+            ref_tiles = (uint32_t)((rx1 - rx0) * (ry1 - ry0));
+
+            // ---- colour (forward.cu:20-71)
+            float col[3];
+            uint8_t clamp_bits = 0;
+            if (a.colors_precomp) {
+                col[0] = a.colors_precomp[3 * idx], col[1] = a.colors_precomp[3 * idx + 1], col[2] = a.colors_precomp[3 * idx + 2];
+            } else {
+                float dx = p_orig.x - a.campos[0], dy = p_orig.y - a.campos[1], dz = p_orig.z - a.campos[2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len, dy = dy / len, dz = dz / len;
+                const float* sh = a.shs + (size_t)idx * a.M * 3;
+                for (int c = 0; c < 3; c++) {
+                    const float v = sh_channel(sh, c, a.D, dx, dy, dz);
+                    if (v < 0) clamp_bits |= (uint8_t)(1u << c);
+                    col[c] = fmaxf(v, 0.0f);
+                }
+            }
+
+            const float opacity = a.opacities[idx];
+            radius_out = mr;
+            a.g.depth[idx] = p_view.z;
+            a.g.means2D[idx] = make_float2(pix_x, pix_y);
+            a.g.conic_opacity[idx] = make_float4(conic_a, conic_b, conic_c, opacity);
+            a.g.rgba[idx] = make_float4(col[0], col[1], col[2], 0.f);
+            a.g.clamped[idx] = clamp_bits;
+
+            // ---- 8x8-tile rectangle of the alpha >= 1/255 footprint, clipped to the pixels the
+            // reference rectangle covers.  A pixel outside it can never pass the blend kernels'
+            // alpha test, so dropping those (tile, Gaussian) instances changes no pixel.
+            int px0 = rx0 * kRefTile, px1 = min(rx1 * kRefTile, a.W) - 1;
+            int py0 = ry0 * kRefTile, py1 = min(ry1 * kRefTile, a.H) - 1;
+            if (!(opacity >= 1.0f / 255.0f)) break;  // alpha = opacity * G <= opacity < 1/255 everywhere
+            {
+                const double A = conic_a, B = conic_b, C = conic_c;
+                const double dq = A * C - B * B;
+                if (dq > 0.0 && A > 0.0 && C > 0.0 && dq < 1e300) {
+                    const double cond = A * C / dq;                       // 1 / (1 - rho^2)
+                    double tau = log(255.0 * (double)opacity);            // alpha >= 1/255  <=>  power >= -tau
+                    tau = tau * (1.0 + 1.6e-5 * cond + 1e-5) + 1e-4;      // fp32 evaluation slack of `power`
+                    const double ex = sqrt(2.0 * tau * C / dq) * (1.0 + 1e-6) + 1e-3;
+                    const double ey = sqrt(2.0 * tau * A / dq) * (1.0 + 1e-6) + 1e-3;
+                    const double x_lo = floor((double)pix_x - ex), x_hi = ceil((double)pix_x + ex);
+                    const double y_lo = floor((double)pix_y - ey), y_hi = ceil((double)pix_y + ey);
+                    if (x_lo > (double)px0) px0 = (int)fmin(x_lo, (double)px1 + 1.0);
+                    if (x_hi < (double)px1) px1 = (int)fmax(x_hi, (double)px0 - 1.0);
+                    if (y_lo > (double)py0) py0 = (int)fmin(y_lo, (double)py1 + 1.0);
+                    if (y_hi < (double)py1) py1 = (int)fmax(y_hi, (double)py0 - 1.0);
+                }
+            }
+            if (px1 < px0 || py1 < py0) break;
+            const int tx0 = px0 / kTile, tx1 = px1 / kTile + 1, ty0 = py0 / kTile, ty1 = py1 / kTile + 1;
+            rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+            for (int ty = ty0; ty < ty1; ty++)
+                for (int tx = tx0; tx < tx1; tx++) atomicAdd(&a.tile_count[ty * a.tiles_x + tx], 1u);
+        } while (false);
+        a.radii[idx] = radius_out;
+        a.g.rect[idx] = rect;
+    }
+    // num_rendered in reference semantics: one atomic per wave
+    uint32_t s = ref_tiles;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&a.counts->num_rendered, s);
+}
+
+// Exclusive scan of the per-tile counts by ONE workgroup; also publishes the frame counts to
+// pinned host memory and builds the list of tiles too long for the in-register sort.
+__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, fr_counts* host_counts)
+{
+    __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_max[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (T + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = min(T, b + per);
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t c = v.tile_count[i];
+        sum += c;
+        mx = max(mx, c);
+        if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&v.counts->large_tiles, 1u)] = i;
+    }
+    s_sum[tid] = sum;
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
+    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partial sums
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t t = (tid >= off) ? s_sum[tid - off] : 0u;
+        __syncthreads();
+        s_sum[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
+    for (uint32_t i = b; i < e; i++) {
+        v.tile_offset[i] = run;
+        v.tile_cursor[i] = run;
+        run += v.tile_count[i];
+    }
+    if (tid == 1023) {
+        const uint32_t total = s_sum[1023];
+        uint32_t m = 0;
+        for (int i = 0; i < 16; i++) m = max(m, s_max[i]);
+        v.tile_offset[T] = total;
+        DeviceCounts* c = v.counts;
+        c->num_instances = total;
+        c->max_tile_list = m;
+        c->overflow = (uint64_t)total > capacity ? 1u : 0u;
+        host_counts->num_rendered = c->num_rendered;
+        host_counts->num_instances = total;
+        host_counts->max_tile_list = m;
+        host_counts->overflow = c->overflow;
+        __threadfence_system();
+    }
+}
+
+// One thread per Gaussian: write (depth | id) keys into the per-tile segments.
+// reference counterpart: duplicateWithKeys, rasterizer_impl.cu:70-111 (the tile id is implicit
+// in the segment here, and the order inside a segment is fixed later by the per-tile sort).
+__global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, ImageView v, uint64_t* keys)
+{
+    if (v.counts->overflow) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const uint2 r = g.rect[idx];
+    const int tx0 = r.x & 0xffff, ty0 = r.x >> 16, tx1 = r.y & 0xffff, ty1 = r.y >> 16;
+    if (tx1 <= tx0 || ty1 <= ty0) return;
+    const uint64_t key = ((uint64_t)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
+    for (int ty = ty0; ty < ty1; ty++)
+        for (int tx = tx0; tx < tx1; tx++) {
+            const uint32_t slot = atomicAdd(&v.tile_cursor[ty * v.tiles_x + tx], 1u);
+            keys[slot] = key;
+        }
+}
+
+// reference: checkFrustum, rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(256) k_mark_visible(int P, const float* means3D, const float* view, uint8_t* present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 pv = xform4x3(p, view);
+    present[idx] = (pv.z <= 0.2f) ? 0 : 1;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s)
+{
+    if (P <= 0) return FR_OK;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
+// implemented in fr_blend.hip
+int launch_sort_and_blend(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
+                          float* out_color, hipStream_t s, bool debug);
+
+static int debug_sync(bool debug, hipStream_t s, const char* stage)
+{
+    if (!debug) return FR_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail_hip(e, stage, __FILE__, __LINE__);
+    return FR_OK;
+}
+
+int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, float* out_color, int32_t* radii,
+                   void* geometry, void* image, void* binning, uint64_t cap, fr_counts* counts, hipStream_t s)
+{
+    const int P = prm.P, W = prm.W, H = prm.H;
+    GeomView g = GeomView::make(geometry, (size_t)P);
+    ImageView v = ImageView::make(image, W, H);
+    BinningView b = BinningView::make(binning, (size_t)cap);
+    const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+    const bool debug = prm.debug != 0;
+    int rc;
+
+    FR_HIP(hipMemsetAsync(image, 0, v.zero_bytes(image), s));
+
+    PreArgs a;
+    a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
+    a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
+    a.focal_y = H / (2.0f * prm.tan_fovy);  // rasterizer_impl.cu:222-223
+    a.focal_x = W / (2.0f * prm.tan_fovx);
+    a.scale_modifier = prm.scale_modifier;
+    a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.opacities = in.opacities;
+    a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
+    a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
+    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.counts = v.counts;
+    a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
+    a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
+    if (P > 0) {
+        hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+        FR_HIP(hipGetLastError());
+        if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, h->host_counts_dev);
+    FR_HIP(hipGetLastError());
+    FR_HIP(hipEventRecord(h->counts_ready, s));
+    if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
+    if (P > 0) {
+        hipLaunchKernelGGL(k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, s, P, g, v, b.keys);
+        FR_HIP(hipGetLastError());
+        if ((rc = debug_sync(debug, s, "emit_instances"))) return rc;
+    }
+    if ((rc = launch_sort_and_blend(prm, in, g, v, b, out_color, s, debug))) return rc;
+
+    // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).
+    FR_HIP(hipEventSynchronize(h->counts_ready));
+    fr_counts c = *h->host_counts;
+    if (counts) *counts = c;
+    if (c.overflow) return FR_ERR_BINNING_CAPACITY;
+    return FR_OK;
+}
+
+}  // namespace fr

@@ -1,0 +1,311 @@
+// Per-Gaussian backward for gfx950: one kernel that turns the blend-backward accumulators
+// (dL/dmean2D, dL/dconic, dL/dopacity, dL/dcolour) into every gradient the API returns.
+// reference: computeCov2DCUDA (backward.cu:144-274) + preprocessCUDA (backward.cu:346-396) +
+// SH backward (backward.cu:20-139) + Sigma3D backward (backward.cu:278-341), fused.
+//
+// Compiled with -ffp-contract=off and written in the reference's operation order (see
+// fr_preprocess.hip).  Every output row is written (zeros for culled Gaussians), so callers
+// need not pre-zero anything.
+#include "fr_common.hpp"
+
+namespace fr {
+
+__constant__ float bSH_C0 = 0.28209479177387814f;
+__constant__ float bSH_C1 = 0.4886025119029199f;
+__constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+struct PreBwdArgs {
+    int P, D, M;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const int* radii;
+    GeomView g;
+    fr_grads out;
+};
+
+__device__ __forceinline__ void store3(float* p, size_t i, float a, float b, float c)
+{
+    if (p) p[3 * i] = a, p[3 * i + 1] = b, p[3 * i + 2] = c;
+}
+
+__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    const size_t i = (size_t)idx;
+    const int Mc = a.M;
+    if (!(a.radii[idx] > 0)) {
+        store3(a.out.dL_dmeans2D, i, 0.f, 0.f, 0.f);
+        store3(a.out.dL_dcolors, i, 0.f, 0.f, 0.f);
+        if (a.out.dL_dopacity) a.out.dL_dopacity[i] = 0.f;
+        store3(a.out.dL_dmeans3D, i, 0.f, 0.f, 0.f);
+        if (a.out.dL_dcov3D)
+            for (int k = 0; k < 6; k++) a.out.dL_dcov3D[6 * i + k] = 0.f;
+        if (a.out.dL_dsh)
+            for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
+        store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f);
+        if (a.out.dL_drotations)
+            for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
+        return;
+    }
+    const float* acc = a.g.accum + i * kAccumStride;
+    const float g2x = acc[ACC_MX], g2y = acc[ACC_MY];
+    const float dcx = acc[ACC_CA], dcy = acc[ACC_CB], dcz = acc[ACC_CC];
+    const float dop = acc[ACC_OP];
+    float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
+    store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f);
+    store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2]);
+    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = dop;
+
+    const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const float* vm = a.view;
+    const float* c3 = a.cov3D_precomp ? a.cov3D_precomp + 6 * i : a.g.cov3D + 6 * i;
+
+    // ---------------- conic -> Sigma2D -> Sigma3D and mean (backward.cu:144-274)
+    float3 t = xform4x3(mean, vm);
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float x_grad_mul = txtz < -limx || txtz > limx ? 0 : 1;
+    const float y_grad_mul = tytz < -limy || tytz > limy ? 0 : 1;
+    const float h_x = a.focal_x, h_y = a.focal_y;
+    const float j00 = h_x / t.z, j02 = -(h_x * t.x) / (t.z * t.z);
+    const float j11 = h_y / t.z, j12 = -(h_y * t.y) / (t.z * t.z);
+    float T0[3], T1[3];  // T0[w] = T[0][w], T1[w] = T[1][w] of the reference's column-major T
+    for (int w = 0; w < 3; w++) {
+        const float W0 = vm[4 * w], W1 = vm[4 * w + 1], W2 = vm[4 * w + 2];
+        T0[w] = W0 * j00 + W1 * 0.0f + W2 * j02;
+        T1[w] = W0 * 0.0f + W1 * j11 + W2 * j12;
+    }
+    const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+    float A0[3], A1[3];
+    for (int c = 0; c < 3; c++) {
+        A0[c] = T0[0] * V[0][c] + T0[1] * V[1][c] + T0[2] * V[2][c];
+        A1[c] = T1[0] * V[0][c] + T1[1] * V[1][c] + T1[2] * V[2][c];
+    }
+    float ca = A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2];
+    const float cb = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2];
+    float cc = A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2];
+    ca += 0.3f;
+    cc += 0.3f;
+    const float denom = ca * cc - cb * cb;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dcov[6] = {0, 0, 0, 0, 0, 0};
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+        dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+        dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+        dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+        dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+        dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+        dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+        dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+        dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+    }
+    if (a.out.dL_dcov3D)
+        for (int k = 0; k < 6; k++) a.out.dL_dcov3D[6 * i + k] = dcov[k];
+
+    // dL/dT (upper 2x3), backward.cu:237-248.  Vrk[c][r] is symmetric.
+    float dT0[3], dT1[3];
+    for (int c = 0; c < 3; c++) {
+        const float tv0 = T0[0] * V[c][0] + T0[1] * V[c][1] + T0[2] * V[c][2];
+        const float tv1 = T1[0] * V[c][0] + T1[1] * V[c][1] + T1[2] * V[c][2];
+        dT0[c] = 2 * tv0 * dL_da + tv1 * dL_db;
+        dT1[c] = 2 * tv1 * dL_dc + tv0 * dL_db;
+    }
+    // dL/dJ, backward.cu:252-255 (W[c][r] = vm[c + 4r])
+    const float dL_dJ00 = vm[0] * dT0[0] + vm[4] * dT0[1] + vm[8] * dT0[2];
+    const float dL_dJ02 = vm[2] * dT0[0] + vm[6] * dT0[1] + vm[10] * dT0[2];
+    const float dL_dJ11 = vm[1] * dT1[0] + vm[5] * dT1[1] + vm[9] * dT1[2];
+    const float dL_dJ12 = vm[2] * dT1[0] + vm[6] * dT1[1] + vm[10] * dT1[2];
+    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    // NB the clamped t.x / t.y are treated as constants here (stop-gradient quirk of the reference)
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+    float dmx = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+    float dmy = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+    float dmz = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+    // ---------------- projection part of dL/dmean3D (backward.cu:370-387)
+    {
+        const float* proj = a.proj;
+        const float4 m_hom = xform4x4(mean, proj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        const float px = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        const float py = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        const float pz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        dmx += px, dmy += py, dmz += pz;
+    }
+
+    // ---------------- SH backward (backward.cu:20-139)
+    if (a.shs) {
+        const float dox = mean.x - a.campos[0], doy = mean.y - a.campos[1], doz = mean.z - a.campos[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float* sh = a.shs + i * Mc * 3;
+        float* dsh = a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr;
+        const uint8_t cl = a.g.clamped[idx];
+        float dRGB[3];
+        for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1) ? 0 : 1);
+        float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+        const int deg = a.D;
+        const int used = (deg + 1) * (deg + 1);
+#define SH(k, c) sh[(k) * 3 + (c)]
+#define DSH(k, c, v_)                    \
+    do {                                 \
+        if (dsh) dsh[(k) * 3 + (c)] = (v_); \
+    } while (0)
+        for (int c = 0; c < 3; c++) {
+            DSH(0, c, bSH_C0 * dRGB[c]);
+            if (deg > 0) {
+                DSH(1, c, (-bSH_C1 * y) * dRGB[c]);
+                DSH(2, c, (bSH_C1 * z) * dRGB[c]);
+                DSH(3, c, (-bSH_C1 * x) * dRGB[c]);
+                dRGBdx[c] = -bSH_C1 * SH(3, c);
+                dRGBdy[c] = -bSH_C1 * SH(1, c);
+                dRGBdz[c] = bSH_C1 * SH(2, c);
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    const float xy = x * y, yz = y * z, xz = x * z;
+                    DSH(4, c, (bSH_C2[0] * xy) * dRGB[c]);
+                    DSH(5, c, (bSH_C2[1] * yz) * dRGB[c]);
+                    DSH(6, c, (bSH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c]);
+                    DSH(7, c, (bSH_C2[3] * xz) * dRGB[c]);
+                    DSH(8, c, (bSH_C2[4] * (xx - yy)) * dRGB[c]);
+                    dRGBdx[c] += bSH_C2[0] * y * SH(4, c) + bSH_C2[2] * 2.f * -x * SH(6, c) + bSH_C2[3] * z * SH(7, c) + bSH_C2[4] * 2.f * x * SH(8, c);
+                    dRGBdy[c] += bSH_C2[0] * x * SH(4, c) + bSH_C2[1] * z * SH(5, c) + bSH_C2[2] * 2.f * -y * SH(6, c) + bSH_C2[4] * 2.f * -y * SH(8, c);
+                    dRGBdz[c] += bSH_C2[1] * y * SH(5, c) + bSH_C2[2] * 2.f * 2.f * z * SH(6, c) + bSH_C2[3] * x * SH(7, c);
+                    if (deg > 2) {
+                        DSH(9, c, (bSH_C3[0] * y * (3.f * xx - yy)) * dRGB[c]);
+                        DSH(10, c, (bSH_C3[1] * xy * z) * dRGB[c]);
+                        DSH(11, c, (bSH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c]);
+                        DSH(12, c, (bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c]);
+                        DSH(13, c, (bSH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c]);
+                        DSH(14, c, (bSH_C3[5] * z * (xx - yy)) * dRGB[c]);
+                        DSH(15, c, (bSH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c]);
+                        dRGBdx[c] += (bSH_C3[0] * SH(9, c) * 3.f * 2.f * xy + bSH_C3[1] * SH(10, c) * yz +
+                                      bSH_C3[2] * SH(11, c) * -2.f * xy + bSH_C3[3] * SH(12, c) * -3.f * 2.f * xz +
+                                      bSH_C3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy) +
+                                      bSH_C3[5] * SH(14, c) * 2.f * xz + bSH_C3[6] * SH(15, c) * 3.f * (xx - yy));
+                        dRGBdy[c] += (bSH_C3[0] * SH(9, c) * 3.f * (xx - yy) + bSH_C3[1] * SH(10, c) * xz +
+                                      bSH_C3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) +
+                                      bSH_C3[3] * SH(12, c) * -3.f * 2.f * yz + bSH_C3[4] * SH(13, c) * -2.f * xy +
+                                      bSH_C3[5] * SH(14, c) * -2.f * yz + bSH_C3[6] * SH(15, c) * -3.f * 2.f * xy);
+                        dRGBdz[c] += (bSH_C3[1] * SH(10, c) * xy + bSH_C3[2] * SH(11, c) * 4.f * 2.f * yz +
+                                      bSH_C3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) +
+                                      bSH_C3[4] * SH(13, c) * 4.f * 2.f * xz + bSH_C3[5] * SH(14, c) * (xx - yy));
+                    }
+                }
+            }
+        }
+        // coefficients above the active degree receive no gradient (the reference leaves its
+        // zero-initialised rows untouched)
+        if (dsh)
+            for (int k = used; k < Mc; k++) dsh[k * 3] = 0.f, dsh[k * 3 + 1] = 0.f, dsh[k * 3 + 2] = 0.f;
+#undef SH
+#undef DSH
+        const float ddx = dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2];
+        const float ddy = dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2];
+        const float ddz = dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2];
+        // dnormvdv (auxiliary.h:107-117)
+        const float sum2 = dox * dox + doy * doy + doz * doz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmx += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
+        dmy += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
+        dmz += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
+    } else if (a.out.dL_dsh) {
+        for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
+    }
+    store3(a.out.dL_dmeans3D, i, dmx, dmy, dmz);
+
+    // ---------------- Sigma3D -> scale, quaternion (backward.cu:278-341)
+    if (a.scales) {
+        const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
+                    z = a.rotations[4 * idx + 3];
+        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                            a.scale_modifier * a.scales[3 * idx + 2]};
+        // Rc[c][w]: the reference's column-major R (its column c is row c of the usual rotation matrix)
+        const float Rc[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                                {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                                {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+        // M = S * R : M[c][w] = s_w * Rc[c][w];  dL_dSigma symmetric with halved off-diagonals
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        // dL_dM = (2M) * dL_dSigma : dM[c][w] = sum_k (2 M[k][w]) * dS[c][k]
+        float dM[3][3];
+        for (int c = 0; c < 3; c++)
+            for (int w = 0; w < 3; w++)
+                dM[c][w] = (s[w] * Rc[0][w] * 2.0f) * dS[c][0] + (s[w] * Rc[1][w] * 2.0f) * dS[c][1] + (s[w] * Rc[2][w] * 2.0f) * dS[c][2];
+        // Rt[c][w] = Rc[w][c], dMt[c][w] = dM[w][c];  dL_dscale_c = dot(Rt[c], dMt[c])
+        float dMt[3][3];
+        for (int c = 0; c < 3; c++)
+            for (int w = 0; w < 3; w++) dMt[c][w] = dM[w][c];
+        const float dsx = Rc[0][0] * dMt[0][0] + Rc[1][0] * dMt[0][1] + Rc[2][0] * dMt[0][2];
+        const float dsy = Rc[0][1] * dMt[1][0] + Rc[1][1] * dMt[1][1] + Rc[2][1] * dMt[1][2];
+        const float dsz = Rc[0][2] * dMt[2][0] + Rc[1][2] * dMt[2][1] + Rc[2][2] * dMt[2][2];
+        store3(a.out.dL_dscales, i, dsx, dsy, dsz);
+        for (int w = 0; w < 3; w++) dMt[0][w] *= s[0], dMt[1][w] *= s[1], dMt[2][w] *= s[2];
+#define Dm(c_, r_) dMt[c_][r_]
+        if (a.out.dL_drotations) {
+            float* dq = a.out.dL_drotations + 4 * i;
+            dq[0] = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
+            dq[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
+            dq[2] = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
+            dq[3] = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
+        }
+#undef Dm
+    } else {
+        store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f);
+        if (a.out.dL_drotations)
+            for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
+    }
+}
+
+int launch_blend_backward(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
+                          const float* dL_dpix, hipStream_t s, bool debug);
+
+int launch_backward(fr_handle_impl*, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
+                    const void* image, const void* binning, const float* dL_dpix, const fr_grads& gr, hipStream_t s)
+{
+    const int P = prm.P;
+    if (P <= 0) return FR_OK;
+    GeomView g = GeomView::make(geometry, (size_t)P);
+    ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
+    BinningView b = BinningView::make(const_cast<void*>(binning), 0);
+    const bool debug = prm.debug != 0;
+    FR_HIP(hipMemsetAsync(g.accum, 0, sizeof(float) * (size_t)P * kAccumStride, s));
+    int rc = launch_blend_backward(prm, in, g, v, b, dL_dpix, s, debug);
+    if (rc) return rc;
+
+    PreBwdArgs a;
+    a.P = P, a.D = prm.D, a.M = prm.M;
+    a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
+    a.focal_y = prm.H / (2.0f * prm.tan_fovy);
+    a.focal_x = prm.W / (2.0f * prm.tan_fovx);
+    a.scale_modifier = prm.scale_modifier;
+    a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.shs = in.shs;
+    a.cov3D_precomp = in.cov3D_precomp, a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
+    a.radii = radii, a.g = g, a.out = gr;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    FR_HIP(hipGetLastError());
+    if (debug) FR_HIP(hipStreamSynchronize(s));
+    return FR_OK;
+}
+
+}  // namespace fr

@@ -1,0 +1,286 @@
+"""Python host of the MI355X rasterizer: the reference's operator interface, same names,
+argument meaning and error behaviour, over the C ABI in include/fr_rasterizer.h.
+
+Mirrors (paths relative to /root/reference/submodules/diff-gaussian-rasterization/):
+  GaussianRasterizationSettings   diff_gaussian_rasterization/__init__.py:157-169
+  GaussianRasterizer              diff_gaussian_rasterization/__init__.py:171-220
+  _RasterizeGaussians             diff_gaussian_rasterization/__init__.py:44-155
+  rasterize_gaussians / rasterize_gaussians_backward / mark_visible  (the `_C` module)
+                                  ext.cpp:15-19, rasterize_points.cu:35-217
+
+All tensors must live on a HIP device ("cuda" in PyTorch-ROCm).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
+
+# per-device guess of the binning capacity (instances); grows when a frame overflows it
+_capacity_hint: dict = {}
+last_counts: dict = {}  # device index -> fr_counts of the most recent forward (diagnostics)
+
+
+def _dev_index(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise RuntimeError("fateavatar_amd rasterizer: tensors must be on a HIP device (torch device 'cuda'); "
+                           "there is no CPU path")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: torch.Tensor | None) -> int:
+    return 0 if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _check(rc: int, what: str):
+    if rc != _lib.FR_OK:
+        raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+
+
+def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug) -> _lib.fr_params:
+    return _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
+                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)))
+
+
+def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
+    return _lib.fr_inputs(_ptr(bg), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                          _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos))
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """`_C.rasterize_gaussians` (rasterize_points.cu:35-115).
+
+    Returns (num_rendered, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer); the three
+    byte buffers are opaque and must be handed back to `rasterize_gaussians_backward`."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = _dev_index(means3D)
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    opts = dict(device=means3D.device)
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, **opts)
+    radii = torch.empty((P,), dtype=torch.int32, **opts)
+    if P == 0:  # rasterize_points.cu:81 skips the rasterizer entirely
+        empty = torch.empty((0,), dtype=torch.uint8, **opts)
+        return 0, out_color.zero_(), radii, empty, empty.clone(), empty.clone()
+
+    background, means3D, opacity = _f32c(background), _f32c(means3D), _f32c(opacity)
+    colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
+    viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
+    M = sh.size(1) if sh.numel() != 0 else 0
+
+    L = _lib.lib()
+    h = _lib.handle(dev)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug)
+    inp = _inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                  campos)
+    geom = torch.empty((L.fr_geometry_bytes(P),), dtype=torch.uint8, **opts)
+    img = torch.empty((L.fr_image_bytes(W, H),), dtype=torch.uint8, **opts)
+    cap = max(_capacity_hint.get(dev, 0), 4 * P + 65536)
+    counts = _lib.fr_counts()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        while True:
+            binning = torch.empty((L.fr_binning_bytes(cap),), dtype=torch.uint8, **opts)
+            rc = L.fr_forward(h, C.byref(prm), C.byref(inp), out_color.data_ptr(), radii.data_ptr(), geom.data_ptr(),
+                              img.data_ptr(), binning.data_ptr(), cap, C.byref(counts), stream)
+            if rc == _lib.FR_ERR_BINNING_CAPACITY:
+                cap = int(counts.num_instances * 1.25) + 1024
+                continue
+            _check(rc, "fr_forward")
+            break
+    _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(counts.num_instances * 1.25) + 1024)
+    last_counts[dev] = counts
+    return int(counts.num_rendered), out_color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None):
+    """`_C.rasterize_gaussians_backward` (rasterize_points.cu:117-196).
+
+    Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+    dL_dscales[P,3], dL_drotations[P,4])."""
+    dev = _dev_index(means3D)
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    opts = dict(device=means3D.device, dtype=torch.float32)
+    shapes = dict(dL_dmeans2D=(P, 3), dL_dcolors=(P, NUM_CHANNELS), dL_dopacity=(P, 1), dL_dmeans3D=(P, 3),
+                  dL_dcov3D=(P, 6), dL_dsh=(P, M, 3), dL_dscales=(P, 3), dL_drotations=(P, 4))
+    if P == 0:
+        return tuple(torch.zeros(s, **opts) for s in shapes.values())
+    # the kernel writes every row of every array it is given, so uninitialised memory is fine
+    g = {k: (torch.empty(s, **opts) if (_want is None or k in _want) else None) for k, s in shapes.items()}
+
+    background, means3D = _f32c(background), _f32c(means3D)
+    colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
+    viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
+    dL_dout_color = _f32c(dL_dout_color)
+    radii = radii.contiguous()
+
+    L = _lib.lib()
+    h = _lib.handle(dev)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug)
+    inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                  campos)
+    grads = _lib.fr_grads(*[_ptr(g[k]) for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D",
+                                                  "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.fr_backward(h, C.byref(prm), C.byref(inp), radii.data_ptr(), geomBuffer.data_ptr(),
+                           imageBuffer.data_ptr(), binningBuffer.data_ptr(), dL_dout_color.data_ptr(),
+                           C.byref(grads), stream)
+    _check(rc, "fr_backward")
+    return tuple(g.values())
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """`_C.mark_visible` (rasterize_points.cu:198-217)."""
+    dev = _dev_index(means3D)
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        means3D, viewmatrix, projmatrix = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().fr_mark_visible(P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(),
+                                            present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _check(rc, "fr_mark_visible")
+    return present
+
+
+def image_aux(imgBuffer: torch.Tensor, H: int, W: int):
+    """(final_T[H,W] float32, n_contrib[H,W] int32) views into an image buffer: the per-pixel alpha channel
+    (alpha = 1 - final_T; reference accum_alpha, forward.cu:369) and contributor count."""
+    L = _lib.lib()
+    base = imgBuffer.data_ptr()
+    oT = L.fr_image_final_T(base, W, H) - base
+    oN = L.fr_image_n_contrib(base, W, H) - base
+    T = imgBuffer[oT:oT + 4 * H * W].view(torch.float32).view(H, W)
+    N = imgBuffer[oN:oN + 4 * H * W].view(torch.int32).view(H, W)
+    return T, N
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """diff_gaussian_rasterization/__init__.py:44-155."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+            ctx.saved_tensors
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                grads = rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            grads = rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = grads
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                 raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    """diff_gaussian_rasterization/__init__.py:171-220."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                            cov3D_precomp, rs)

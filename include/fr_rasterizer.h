@@ -1,0 +1,154 @@
+/*
+ * fr_rasterizer.h — C ABI of the MI355X (gfx950) Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for FateAvatar's render path.  Every entry point takes plain
+ * DEVICE pointers, sizes and a HIP stream; no torch types, no exceptions across
+ * the ABI, integer return codes.  The entry points are what the reference's own
+ * torch glue binds (reference paths are relative to
+ * submodules/diff-gaussian-rasterization/ and submodules/simple-knn/):
+ *
+ *   fr_forward        replaces CudaRasterizer::Rasterizer::forward
+ *                     (cuda_rasterizer/rasterizer.h:36-60, rasterizer_impl.cu:198-336),
+ *                     called from RasterizeGaussiansCUDA (rasterize_points.cu:35-115)
+ *   fr_backward       replaces CudaRasterizer::Rasterizer::backward
+ *                     (cuda_rasterizer/rasterizer.h:62-85, rasterizer_impl.cu:340-434),
+ *                     called from RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196)
+ *   fr_mark_visible   replaces CudaRasterizer::Rasterizer::markVisible
+ *                     (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153),
+ *                     called from markVisible (rasterize_points.cu:198-217)
+ *   fr_knn_mean_dist2 replaces SimpleKNN::knn (simple_knn.h, simple_knn.cu:186-222),
+ *                     called from distCUDA2 (spatial.cu:14-25)
+ *
+ * Differences from the reference interface, all deliberate:
+ *   - Scratch is three caller-owned byte buffers sized by fr_*_bytes() instead of
+ *     std::function<char*(size_t)> resize callbacks: the caller's allocator stays in
+ *     charge (torch caching allocator in the Python host) and nothing is allocated
+ *     inside a call.
+ *   - The binning buffer has a CAPACITY.  fr_forward never blocks the GPU on the
+ *     instance count (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:281):
+ *     it enqueues the whole frame, then reads the counts the scan kernel wrote to pinned
+ *     host memory.  If the capacity was too small it returns FR_ERR_BINNING_CAPACITY and
+ *     the required size; the caller regrows and calls again.
+ *   - Work is enqueued on the stream passed in, not on the legacy default stream.
+ *   - Tiles are 8x8 pixels = one 64-lane wavefront (the reference uses 16x16 = 256
+ *     threads) and per-tile lists only hold Gaussians whose alpha >= 1/255 footprint
+ *     touches the tile, clipped to the reference's own 16x16 tile rectangle, so every
+ *     pixel blends exactly the sequence the reference blends.  `num_rendered` is still
+ *     reported in reference semantics (sum of 16x16 tiles touched).
+ */
+#ifndef FR_RASTERIZER_H_INCLUDED
+#define FR_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_OK 0
+#define FR_ERR_INVALID_ARGUMENT 1
+#define FR_ERR_BINNING_CAPACITY 2 /* binning buffer too small; *instances_needed tells how big */
+#define FR_ERR_HIP 3              /* a HIP runtime call failed; see fr_last_error() */
+#define FR_ERR_UNSUPPORTED 4
+
+typedef struct fr_handle fr_handle; /* per-device context: pinned count slots, events */
+
+/* Frame parameters: the scalar arguments of Rasterizer::forward/backward. */
+typedef struct fr_params {
+    int32_t P;            /* number of Gaussians */
+    int32_t D;            /* active SH degree (0..3) */
+    int32_t M;            /* SH coefficients stored per Gaussian (shs is [P,M,3]); 0 if no shs */
+    int32_t W, H;         /* image size in pixels */
+    float tan_fovx, tan_fovy;
+    float scale_modifier;
+    int32_t prefiltered;  /* accepted for interface parity; the near-plane cull is always applied */
+    int32_t debug;        /* !=0: synchronise and check after every stage (auxiliary.h:166-173) */
+} fr_params;
+
+/* Device pointers.  NULL = the "empty tensor" of the reference glue
+ * (rasterize_points.cu:94-103 passes data_ptr() of empty tensors; kernels branch on nullptr). */
+typedef struct fr_inputs {
+    const float* background;     /* [3] */
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3]   or NULL (exactly one of shs / colors_precomp) */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3]   or NULL */
+    const float* rotations;      /* [P,4]   or NULL (r,x,y,z; not normalised in-kernel) */
+    const float* cov3D_precomp;  /* [P,6]   or NULL (exactly one of scales+rotations / cov3D_precomp) */
+    const float* viewmatrix;     /* [16] row-major "transposed" world->view (camera_3dgs.py:53) */
+    const float* projmatrix;     /* [16] full projection, same convention (camera_3dgs.py:71) */
+    const float* campos;         /* [3] */
+} fr_inputs;
+
+/* Gradient outputs of fr_backward (device pointers).  Every non-NULL array is fully written
+ * (rows of culled Gaussians are zero), so the caller may pass uninitialised memory; the
+ * reference instead requires nine zero-filled tensors (rasterize_points.cu:151-159).
+ * NULL = not wanted. */
+typedef struct fr_grads {
+    float* dL_dmeans2D;   /* [P,3] screen-space mean gradient, NDC-scaled, z = 0 (backward.cu:545-546) */
+    float* dL_dcolors;    /* [P,3] */
+    float* dL_dopacity;   /* [P]   */
+    float* dL_dmeans3D;   /* [P,3] */
+    float* dL_dcov3D;     /* [P,6] */
+    float* dL_dsh;        /* [P,M,3] */
+    float* dL_dscales;    /* [P,3] */
+    float* dL_drotations; /* [P,4] */
+} fr_grads;
+
+/* What the scan stage reports for a frame. */
+typedef struct fr_counts {
+    uint32_t num_rendered;   /* reference semantics: sum over Gaussians of 16x16 tiles touched */
+    uint32_t num_instances;  /* (8x8 tile, Gaussian) instances this implementation bins and sorts */
+    uint32_t max_tile_list;  /* longest per-tile list */
+    uint32_t overflow;       /* 1 if num_instances exceeded the binning capacity */
+} fr_counts;
+
+int fr_create(fr_handle** out);
+int fr_destroy(fr_handle* h);
+const char* fr_last_error(void);
+const char* fr_version(void);
+
+/* Scratch sizes in bytes.  geometry: per-Gaussian state + gradient accumulators; image: per-pixel
+ * final transmittance / contributor count and per-tile ranges; binning: `capacity` instances. */
+size_t fr_geometry_bytes(int32_t P);
+size_t fr_image_bytes(int32_t W, int32_t H);
+size_t fr_binning_bytes(uint64_t capacity);
+
+/* out_color [3,H,W], radii [P] (reference semantics: ceil(3*sigma_max), 0 if culled).
+ * Returns FR_OK, or FR_ERR_BINNING_CAPACITY with counts->num_instances = capacity required
+ * (outputs are then undefined and the call must be repeated with a larger binning buffer). */
+int fr_forward(fr_handle* h, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
+               void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts,
+               void* hip_stream);
+
+/* geometry/image/binning: the buffers a successful fr_forward of the same frame filled.
+ * dL_dpix [3,H,W]. */
+int fr_backward(fr_handle* h, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,
+                const void* image, const void* binning, const float* dL_dpix, const fr_grads* grads,
+                void* hip_stream);
+
+/* present[i] = view-space z of means3D[i] > 0.2 (auxiliary.h:154). */
+int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, void* hip_stream);
+
+/* Per-pixel auxiliaries of the last forward held in `image` (device pointers into it). */
+const float* fr_image_final_T(const void* image, int32_t W, int32_t H);
+const uint32_t* fr_image_n_contrib(const void* image, int32_t W, int32_t H);
+
+/* Test/diagnostic accessor: device pointer of one per-Gaussian array inside a geometry buffer filled by
+ * fr_forward.  field: 0 means2D (float2), 1 depth (float), 2 conic_opacity (float4), 3 rgba (float4),
+ * 4 cov3D (6 floats), 5 tile rect (2 x uint32: x0|y0<<16, x1|y1<<16 in 8x8 tiles), 6 clamped (uint8 bitmask),
+ * 7 gradient accumulators (16 floats).  Returns NULL for an unknown field. */
+const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t field);
+
+/* simple-knn: out[i] = mean of the 3 smallest squared distances from points[i] to the other points. */
+size_t fr_knn_workspace_bytes(int32_t P);
+int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
+                      void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
