@@ -125,14 +125,16 @@ struct BinningView {
     {
         char* p = static_cast<char*>(buf);
         BinningView b;
-        b.keys = carve<uint64_t>(p, cap);
+        // recs first: its address does not depend on the capacity, so the backward (which only
+        // needs the records) can find it without knowing the capacity of the forward call
         b.recs = carve<float4>(p, cap * 3);
+        b.keys = carve<uint64_t>(p, cap);
         return b;
     }
     static size_t bytes(size_t cap)
     {
         BinningView b = make(nullptr, cap);
-        return reinterpret_cast<size_t>(b.recs + cap * 3) + 256;
+        return reinterpret_cast<size_t>(b.keys + cap) + 256;
     }
 };
 
