@@ -44,7 +44,7 @@ class fr_counts(C.Structure):
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_backward", "fr_mark_visible", "fr_image_final_T",
-           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_knn_workspace_bytes", "fr_knn_mean_dist2"]
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2"]
 
 
 def build(force: bool = False) -> str:
@@ -93,6 +93,8 @@ def lib():
     L.fr_image_n_contrib.restype = C.c_void_p
     L.fr_debug_geometry_field.argtypes = [_fp, C.c_int32, C.c_int32]
     L.fr_debug_geometry_field.restype = C.c_void_p
+    L.fr_debug_selftest_reduce.argtypes = [_fp, _fp, C.c_void_p]
+    L.fr_debug_selftest_reduce.restype = C.c_int
     L.fr_knn_workspace_bytes.argtypes = [C.c_int32]
     L.fr_knn_workspace_bytes.restype = C.c_size_t
     L.fr_knn_mean_dist2.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]

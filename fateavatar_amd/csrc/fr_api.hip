@@ -140,6 +140,11 @@ const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t fie
     }
 }
 
+int fr_debug_selftest_reduce(const float* in, float* out, void* stream)
+{
+    return launch_selftest_reduce(in, out, static_cast<hipStream_t>(stream));
+}
+
 size_t fr_knn_workspace_bytes(int32_t P) { return knn_workspace_bytes(P); }
 
 int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, void* stream)

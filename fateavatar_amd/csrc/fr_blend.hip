@@ -184,6 +184,34 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     else sort_tile_regs<16>(keys, recs, start, n, lane, g);
 }
 
+// ------------------------------------------------------------------ LDS staging of a tile's list
+// A wavefront walks its tile's record array in batches of 64: lane i fetches record i of the
+// batch with three coalesced 16-byte loads (the NEXT batch is fetched into registers while the
+// current one is blended), parks it in LDS, and the blend loop reads records back with
+// wave-uniform addresses (LDS broadcast), four at a time so that the four exp/alpha evaluations
+// are independent instruction streams and only the short T / colour recurrence is serial.
+constexpr int kBatch = 64;
+constexpr int kGroup = 4;
+
+struct RecRegs {
+    float4 q0, q1, q2;
+};
+
+__device__ __forceinline__ RecRegs fetch_record(const float4* __restrict__ src, uint32_t i, uint32_t n)
+{
+    RecRegs r;
+    if (i < n) {
+        r.q0 = src[(size_t)i * kRecQuads + 0];
+        r.q1 = src[(size_t)i * kRecQuads + 1];
+        r.q2 = src[(size_t)i * kRecQuads + 2];
+    } else {  // padding: opacity 0 -> alpha 0 -> never blended
+        r.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.q1 = r.q0;
+        r.q2 = r.q0;
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------ blend forward
 // reference: renderCUDA, forward.cu:261-374.  Per pixel the sequence of operations (and the
 // tests power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) is the reference's; only the order of
@@ -194,6 +222,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd(const uint32_t* __restrict__ t
                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                   const DeviceCounts* __restrict__ counts)
 {
+    __shared__ float4 s_rec[kBatch * kRecQuads];
     if (counts->overflow) return;
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x;
@@ -202,29 +231,54 @@ __global__ void __launch_bounds__(64) k_blend_fwd(const uint32_t* __restrict__ t
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
+    const uint32_t n = end - start;
+    const float4* __restrict__ src = recs + (size_t)start * kRecQuads;
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    for (uint32_t pos = start; pos < end; ++pos) {
-        if (((pos - start) & 7u) == 0 && __all(done)) break;
-        const float4 q0 = recs[(size_t)pos * kRecQuads + 0];
-        const float4 q1 = recs[(size_t)pos * kRecQuads + 1];
-        const float q2x = recs[(size_t)pos * kRecQuads + 2].x;
-        const float dx = q0.x - fx, dy = q0.y - fy;
-        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-        const float alpha = fminf(0.99f, q1.y * __expf(power));
-        bool c = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        const float test_T = T * (1.f - alpha);
-        const bool fin = c && (test_T < 0.0001f);
-        done = done || fin;
-        c = c && !fin;
-        const float w = c ? alpha * T : 0.f;
-        Cr += q1.z * w;
-        Cg += q1.w * w;
-        Cb += q2x * w;
-        T = c ? test_T : T;
-        last = c ? (pos - start + 1u) : last;
+    RecRegs nxt = fetch_record(src, (uint32_t)lane, n);
+    for (uint32_t base = 0; base < n; base += kBatch) {
+        s_rec[lane * kRecQuads + 0] = nxt.q0;
+        s_rec[lane * kRecQuads + 1] = nxt.q1;
+        s_rec[lane * kRecQuads + 2] = nxt.q2;
+        if (base + kBatch < n) nxt = fetch_record(src, base + kBatch + lane, n);
+        const uint32_t m = min((uint32_t)kBatch, n - base);
+        bool all_done = false;
+        for (uint32_t j = 0; j < m; j += kGroup) {
+            if (__all(done)) {
+                all_done = true;
+                break;
+            }
+            float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
+            bool ok[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) {
+                const float4 q0 = s_rec[(j + u) * kRecQuads + 0];
+                const float4 q1 = s_rec[(j + u) * kRecQuads + 1];
+                const float q2x = s_rec[(j + u) * kRecQuads + 2].x;
+                const float dx = q0.x - fx, dy = q0.y - fy;
+                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+                alpha[u] = fminf(0.99f, q1.y * __expf(power));
+                ok[u] = !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+                cr[u] = q1.z, cg[u] = q1.w, cb[u] = q2x;
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) {
+                bool c = !done && ok[u];
+                const float test_T = T * (1.f - alpha[u]);
+                const bool fin = c && (test_T < 0.0001f);
+                done = done || fin;
+                c = c && !fin;
+                const float w = c ? alpha[u] * T : 0.f;
+                Cr += cr[u] * w;
+                Cg += cg[u] * w;
+                Cb += cb[u] * w;
+                T = c ? test_T : T;
+                last = c ? (base + j + u + 1u) : last;
+            }
+        }
+        if (all_done) break;
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -238,18 +292,61 @@ __global__ void __launch_bounds__(64) k_blend_fwd(const uint32_t* __restrict__ t
 
 // ------------------------------------------------------------------ blend backward
 // reference: renderCUDA, backward.cu:399-557.  Per (pixel, Gaussian) pair the arithmetic is the
-// reference's; instead of 9 global atomics per contributing pair, the 64 pixels of the tile are
-// reduced inside the wavefront and ONE lane issues 9 atomics per (tile, Gaussian) instance.
-__device__ __forceinline__ float wave_sum(float v)
+// reference's.  Instead of 9 global atomics per contributing PAIR, the 64 pixels of the tile are
+// reduced inside the wavefront: four Gaussians are processed per step, their 4 x 9 per-lane
+// partial gradients go through a reduce-scatter butterfly (v_permlane32_swap / v_permlane16_swap
+// across the four 16-lane rows, DPP inside a row) that leaves each of the 36 totals in a
+// different lane, and ONE global_atomic_add_f32 instruction with 36 active lanes adds them to the
+// per-Gaussian accumulators.
+#define FR_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+
+__device__ __forceinline__ float swap32_add(float a, float b)
 {
-    // xor butterfly inside rows of 16 lanes with DPP, then across the four rows
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    // low half: a.lo + a.hi ; high half: b.lo + b.hi
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    // even rows: a.r(2i) + a.r(2i+1) ; odd rows: b.r(2i) + b.r(2i+1)
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// Reduce 36 per-lane values across the 64 lanes; on return lane l holds the wave total of value
+// bitrev6(l) (for bitrev6(l) < 36; other lanes hold junk).
+__device__ __forceinline__ float reduce_scatter_36(const float (&r)[36], int lane)
+{
+    float a[18], b[9], c[5], d[3], e[2];
+#pragma unroll
+    for (int i = 0; i < 18; i++) a[i] = swap32_add(r[2 * i], r[2 * i + 1]);  // lane bit 5 <- value bit 0
+#pragma unroll
+    for (int i = 0; i < 9; i++) b[i] = swap16_add(a[2 * i], a[2 * i + 1]);   // lane bit 4 <- value bit 1
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                                            // lane bit 3 <- value bit 2
+        const float lo = FR_DPP_ADD(b[2 * i], 0x128), hi = FR_DPP_ADD(b[2 * i + 1], 0x128);  // row_ror:8
+        c[i] = b3 ? hi : lo;
+    }
+    c[4] = FR_DPP_ADD(b[8], 0x128);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                                            // lane bit 2 <- value bit 3
+        const float lo = FR_DPP_ADD(c[2 * i], 0x141), hi = FR_DPP_ADD(c[2 * i + 1], 0x141);  // row_half_mirror
+        d[i] = b2 ? hi : lo;
+    }
+    d[2] = FR_DPP_ADD(c[4], 0x141);
+    {                                                                        // lane bit 1 <- value bit 4
+        const float lo = FR_DPP_ADD(d[0], 0x4E), hi = FR_DPP_ADD(d[1], 0x4E);  // quad_perm [2,3,0,1]
+        e[0] = b1 ? hi : lo;
+        e[1] = FR_DPP_ADD(d[2], 0x4E);
+    }
+    const float lo = FR_DPP_ADD(e[0], 0xB1), hi = FR_DPP_ADD(e[1], 0xB1);      // quad_perm [1,0,3,2]; lane bit 0 <- value bit 5
+    return b0 ? hi : lo;
+}
+
+__device__ __forceinline__ int bitrev6(int l)
+{
+    return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
 }
 
 __global__ void __launch_bounds__(64) k_blend_bwd(const uint32_t* __restrict__ tile_offset,
@@ -258,6 +355,7 @@ __global__ void __launch_bounds__(64) k_blend_bwd(const uint32_t* __restrict__ t
                                                   const uint32_t* __restrict__ n_contrib,
                                                   const float* __restrict__ dL_dpix, float* __restrict__ accum)
 {
+    __shared__ float4 s_rec[kBatch * kRecQuads];
     const uint32_t tile = blockIdx.x;
     const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
     if (end == start) return;
@@ -281,59 +379,100 @@ __global__ void __launch_bounds__(64) k_blend_bwd(const uint32_t* __restrict__ t
     // nothing behind the deepest contributor of any pixel of the tile can matter
     uint32_t max_last = last;
     for (int off = 32; off > 0; off >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor(max_last, off));
-    max_last = __builtin_amdgcn_readfirstlane(max_last);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(max_last);
+    if (n == 0) return;
+    const float4* __restrict__ src = recs + (size_t)start * kRecQuads;
 
-    for (uint32_t k = max_last; k-- > 0;) {
-        const uint32_t pos = start + k;
-        const float4 q0 = recs[(size_t)pos * kRecQuads + 0];
-        const float4 q1 = recs[(size_t)pos * kRecQuads + 1];
-        const float4 q2 = recs[(size_t)pos * kRecQuads + 2];
-        const float dx = q0.x - fx, dy = q0.y - fy;
-        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, q1.y * G);
-        const bool c = (k < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        if (!__any(c)) continue;
+    // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
+    const int v = bitrev6(lane);
+    const int own_u = v / 9, own_c = v - own_u * 9;
 
-        const float Tn = T / (1.f - alpha);
-        T = c ? Tn : T;
-        const float dchannel_dcolor = c ? alpha * T : 0.f;
-        // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
-        const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-        const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-        const float nb = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-        acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nb : acc_b;
-        last_r = c ? q1.z : last_r, last_g = c ? q1.w : last_g, last_b = c ? q2.x : last_b;
-        float dL_dalpha = ((q1.z - acc_r) * dpr + (q1.w - acc_g) * dpg) + (q2.x - acc_b) * dpb;
-        dL_dalpha *= T;
-        last_alpha = c ? alpha : last_alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-        dL_dalpha = c ? dL_dalpha : 0.f;
-
-        const float Gc = c ? G : 0.f;  // G may be inf/NaN on lanes that failed the tests
-        const float dL_dG = q1.y * dL_dalpha;
-        const float gdx = Gc * dx, gdy = Gc * dy;
-        const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-        const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-
-        float s[9];
-        s[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
-        s[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
-        s[ACC_CA] = -0.5f * gdx * dx * dL_dG;
-        s[ACC_CB] = -0.5f * gdx * dy * dL_dG;
-        s[ACC_CC] = -0.5f * gdy * dy * dL_dG;
-        s[ACC_OP] = Gc * dL_dalpha;
-        s[ACC_R] = dchannel_dcolor * dpr;
-        s[ACC_G] = dchannel_dcolor * dpg;
-        s[ACC_B] = dchannel_dcolor * dpb;
+    const int nb = (int)((n + kBatch - 1) / kBatch);
+    RecRegs nxt = fetch_record(src, (uint32_t)(nb - 1) * kBatch + lane, n);
+    for (int b = nb - 1; b >= 0; --b) {
+        s_rec[lane * kRecQuads + 0] = nxt.q0;
+        s_rec[lane * kRecQuads + 1] = nxt.q1;
+        s_rec[lane * kRecQuads + 2] = nxt.q2;
+        if (b > 0) nxt = fetch_record(src, (uint32_t)(b - 1) * kBatch + lane, n);
+        const uint32_t base = (uint32_t)b * kBatch;
+        const int m = (int)min((uint32_t)kBatch, n - base);
+        for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
+            float G[kGroup], alpha[kGroup], dx[kGroup], dy[kGroup];
+            float4 q0[kGroup], q1[kGroup];
+            float q2x[kGroup];
+            bool ok[kGroup];
+            bool any_ok = false;
 #pragma unroll
-        for (int i = 0; i < 9; i++) s[i] = wave_sum(s[i]);
-        if (lane == 0) {
-            float* a = accum + (size_t)__float_as_uint(q2.y) * kAccumStride;
+            for (int u = 0; u < kGroup; u++) {
+                q0[u] = s_rec[(j + u) * kRecQuads + 0];
+                q1[u] = s_rec[(j + u) * kRecQuads + 1];
+                q2x[u] = s_rec[(j + u) * kRecQuads + 2].x;
+                dx[u] = q0[u].x - fx, dy[u] = q0[u].y - fy;
+                const float power = -0.5f * (q0[u].z * dx[u] * dx[u] + q1[u].x * dy[u] * dy[u]) - q0[u].w * dx[u] * dy[u];
+                G[u] = __expf(power);
+                alpha[u] = fminf(0.99f, q1[u].y * G[u]);
+                ok[u] = (base + (uint32_t)(j + u) < last) && !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+                any_ok = any_ok || ok[u];
+            }
+            if (!__any(any_ok)) continue;
+
+            float s[kGroup * 9];
 #pragma unroll
-            for (int i = 0; i < 9; i++) atomic_add_f32(a + i, s[i]);
+            for (int u = kGroup - 1; u >= 0; u--) {  // back to front
+                const bool c = ok[u];
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha[u]);
+                T = c ? T * inv : T;
+                const float dchannel_dcolor = c ? alpha[u] * T : 0.f;
+                // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
+                const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
+                const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
+                const float nbl = last_alpha * last_b + (1.f - last_alpha) * acc_b;
+                acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nbl : acc_b;
+                last_r = c ? q1[u].z : last_r, last_g = c ? q1[u].w : last_g, last_b = c ? q2x[u] : last_b;
+                float dL_dalpha = ((q1[u].z - acc_r) * dpr + (q1[u].w - acc_g) * dpg) + (q2x[u] - acc_b) * dpb;
+                dL_dalpha *= T;
+                last_alpha = c ? alpha[u] : last_alpha;
+                dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
+                dL_dalpha = c ? dL_dalpha : 0.f;
+
+                const float Gc = c ? G[u] : 0.f;  // G may be inf/NaN on lanes that failed the tests
+                const float dL_dG = q1[u].y * dL_dalpha;
+                const float gdx = Gc * dx[u], gdy = Gc * dy[u];
+                const float dG_ddelx = -gdx * q0[u].z - gdy * q0[u].w;
+                const float dG_ddely = -gdy * q1[u].x - gdx * q0[u].w;
+                float* su = s + u * 9;
+                su[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
+                su[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
+                su[ACC_CA] = -0.5f * gdx * dx[u] * dL_dG;
+                su[ACC_CB] = -0.5f * gdx * dy[u] * dL_dG;
+                su[ACC_CC] = -0.5f * gdy * dy[u] * dL_dG;
+                su[ACC_OP] = Gc * dL_dalpha;
+                su[ACC_R] = dchannel_dcolor * dpr;
+                su[ACC_G] = dchannel_dcolor * dpg;
+                su[ACC_B] = dchannel_dcolor * dpb;
+            }
+            const float total = reduce_scatter_36(reinterpret_cast<const float(&)[36]>(s), lane);
+            if (v < kGroup * 9 && (j + own_u) < m) {
+                const uint32_t id = __float_as_uint(s_rec[(j + own_u) * kRecQuads + 2].y);
+                atomic_add_f32(accum + (size_t)id * kAccumStride + own_c, total);
+            }
         }
     }
+}
+
+// test hook: run the 36-value reduce-scatter on in[lane*36 + k] and return each lane's result
+__global__ void __launch_bounds__(64) k_selftest_reduce(const float* in, float* out)
+{
+    float r[36];
+    for (int k = 0; k < 36; k++) r[k] = in[threadIdx.x * 36 + k];
+    out[threadIdx.x] = reduce_scatter_36(r, threadIdx.x);
+}
+
+int launch_selftest_reduce(const float* in, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_reduce, dim3(1), dim3(64), 0, s, in, out);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
 }
 
 static int debug_sync(bool debug, hipStream_t s, const char* stage)

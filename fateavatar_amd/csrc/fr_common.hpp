@@ -153,6 +153,7 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
+int launch_selftest_reduce(const float* in, float* out, hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- device helpers

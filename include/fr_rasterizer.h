@@ -143,6 +143,10 @@ const uint32_t* fr_image_n_contrib(const void* image, int32_t W, int32_t H);
  * 7 gradient accumulators (16 floats).  Returns NULL for an unknown field. */
 const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t field);
 
+/* Test hook for the wave reduce-scatter used by the blend backward: in[64*36] (lane-major), out[64]:
+ * out[l] = sum over lanes of in[lane*36 + bitrev6(l)] for bitrev6(l) < 36. */
+int fr_debug_selftest_reduce(const float* in, float* out, void* hip_stream);
+
 /* simple-knn: out[i] = mean of the 3 smallest squared distances from points[i] to the other points. */
 size_t fr_knn_workspace_bytes(int32_t P);
 int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,

@@ -169,3 +169,21 @@ def test_mark_visible(gpu_device):
     ref = oracle.mark_visible(s.means3D, c.world_view_transform, c.full_proj_transform)
     np.testing.assert_array_equal(got, ref)
     assert 0 < ref.sum() < s.P
+
+
+def test_reduce_scatter_selftest(gpu_device):
+    """The 36-value wave reduce-scatter of the blend backward, in isolation."""
+    import torch
+    from fateavatar_amd import _lib
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(64, 36)).astype(np.float32)
+    tin = torch.from_numpy(x).to(gpu_device)
+    tout = torch.zeros(64, dtype=torch.float32, device=gpu_device)
+    rc = _lib.lib().fr_debug_selftest_reduce(tin.data_ptr(), tout.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = tout.cpu().numpy()
+    ref = x.astype(np.float64).sum(0)
+    for l in range(64):
+        v = int(format(l, "06b")[::-1], 2)
+        if v < 36:
+            assert abs(got[l] - ref[v]) <= 1e-4 * max(1.0, abs(ref[v])), (l, v, got[l], ref[v])
