@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py — render+backward frames/s of the MI355X rasterizer on BASELINE.json's metric config.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` (activations in stock
+PyTorch + the HIP rasterizer through the reference's Python API) followed by `loss.backward()` down
+to the raw Gaussian parameters; at N > 1 each rank renders its own view of the replicated Gaussians
+and the step ends with ONE RCCL all-reduce(AVG) of the flat gradient buffer.
+Workload (config.workload): BASELINE.json configs[1] — 100 000 Gaussians sampled on the head
+template, 512x512, SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident
+in HBM before the timed region.
+
+The JSON line carries
+  roofline     — the blend backward (the graded kernel): algorithmic bytes 76*R + 20*H*W + 8*T
+                 (R = num_rendered and T = 16x16 tiles in reference semantics) divided by
+                 that kernel's mean launch duration, measured with HIP events on the launch stream
+                 during the timed steps, against the 8 TB/s HBM peak.
+  cpu_baseline — the CPU oracle (oracle/fr_oracle.c, OpenMP, kind "port": the reference has no CPU
+                 rasterizer) timed on the host cores on a bounded sample of the same frames.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fateavatar_amd import _lib, dp, scenes  # noqa: E402
+from fateavatar_amd.model import FlatGaussians, TorchCamera  # noqa: E402
+from fateavatar_amd.render import render  # noqa: E402
+from fateavatar_amd import rasterizer  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
+
+
+def cpu_baseline(scene, n_frames: int):
+    """Oracle forward+backward on the host, all cores.  Returns (frames/s, threads, sample text)."""
+    from oracle import oracle
+    c = scene.camera
+    H, W = c.image_height, c.image_width
+    dpix = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
+    kw = dict(bg=scene.bg, means3D=scene.means3D, opacities=scene.opacities, viewmatrix=c.world_view_transform,
+              projmatrix=c.full_proj_transform, campos=c.camera_center, tanfovx=c.tanfovx, tanfovy=c.tanfovy, H=H,
+              W=W, shs=scene.shs, sh_degree=scene.sh_degree, scales=scene.scales, rotations=scene.rotations)
+    f = oracle.forward(**kw)  # warm-up (page-in, thread pool)
+    oracle.backward(f, dpix)
+    t0 = time.perf_counter()
+    for _ in range(n_frames):
+        f = oracle.forward(**kw)
+        oracle.backward(f, dpix)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, oracle.num_threads(), f"{n_frames} frames fwd+bwd of the same workload ({dt:.1f} s)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--P", type=int, default=100_000)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # replicated Gaussians (same seed on every rank), one view per rank
+    scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1))
+    pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree, dev)
+    cam = TorchCamera(scene.camera, dev)
+    bg = torch.from_numpy(scene.bg).to(dev)
+    H = W = args.res
+    target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+
+    def step():
+        pc.flat.grad.zero_()
+        out = render(cam, pc, bg)
+        loss = (out["render"] - target).abs().mean()  # L1 (train/loss.py), the synthetic loop's loss
+        loss.backward()
+        if world > 1:
+            dp.allreduce_mean_(pc.flat.grad)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(local, True)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_read(local)
+    _lib.profile_enable(local, False)
+    counts = rasterizer.last_counts[local]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        R = int(counts.num_rendered)
+        T16 = ((W + 15) // 16) * ((H + 15) // 16)
+        bytes_bwd = 76 * R + 20 * H * W + 8 * T16
+        ms, n = prof["blend_bwd"]
+        roof = None
+        if n:
+            avg_s = ms / n * 1e-3
+            ach = bytes_bwd / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_blend_bwd_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("P") == args.P and tj.get("res") == args.res:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_blend_bwd", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "algorithmic_bytes": bytes_bwd, "avg_launch_us": round(avg_s * 1e6, 2), "launches": n}
+        stages = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}
+        cpu = None
+        if args.cpu_frames > 0 and world == 1:
+            v, cores, sample = cpu_baseline(scene, args.cpu_frames)
+            cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+        line = {
+            "metric": "render+backward frames/sec at 512^2, 100k Gaussians", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {args.P} Gaussians on the head template, "
+                                   f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
+                                   "forward+backward through render() + L1 loss",
+                       "frames_per_step_per_gpu": 1, "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
+                       "num_rendered": R, "tile_instances_8x8": int(counts.num_instances),
+                       "max_tile_list": int(counts.max_tile_list)},
+            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages,
+        }
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

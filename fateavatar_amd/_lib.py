@@ -42,7 +42,7 @@ class fr_counts(C.Structure):
                 ("overflow", C.c_uint32)]
 
 
-EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_geometry_bytes", "fr_image_bytes",
+EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_backward", "fr_mark_visible", "fr_image_final_T",
            "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2"]
 
@@ -73,6 +73,10 @@ def lib():
     L.fr_destroy.argtypes = [C.c_void_p]
     L.fr_last_error.restype = C.c_char_p
     L.fr_version.restype = C.c_char_p
+    L.fr_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    L.fr_profile_enable.restype = C.c_int
+    L.fr_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.fr_profile_read.restype = C.c_int
     L.fr_geometry_bytes.argtypes = [C.c_int32]
     L.fr_geometry_bytes.restype = C.c_size_t
     L.fr_image_bytes.argtypes = [C.c_int32, C.c_int32]
@@ -101,6 +105,27 @@ def lib():
     L.fr_knn_mean_dist2.restype = C.c_int
     _lib = L
     return L
+
+
+STAGES = ("preprocess_fwd", "scan", "emit", "tile_sort", "blend_fwd", "blend_bwd", "preprocess_bwd")
+
+
+def profile_enable(device_index: int, on: bool) -> None:
+    rc = lib().fr_profile_enable(handle(device_index), int(on))
+    if rc != FR_OK:
+        raise RuntimeError(last_error())
+
+
+def profile_read(device_index: int) -> dict:
+    """{stage: (total_ms, launches)} since profile_enable(True); synchronise the device first."""
+    out = {}
+    for i, name in enumerate(STAGES):
+        ms, n = C.c_double(), C.c_uint32()
+        rc = lib().fr_profile_read(handle(device_index), i, C.byref(ms), C.byref(n))
+        if rc != FR_OK:
+            raise RuntimeError(last_error())
+        out[name] = (ms.value, n.value)
+    return out
 
 
 def last_error() -> str:

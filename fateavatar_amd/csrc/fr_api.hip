@@ -71,8 +71,38 @@ int fr_destroy(fr_handle* hh)
     fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
     if (!h) return FR_OK;
     (void)hipEventDestroy(h->counts_ready);
+    for (int st = 0; st < ST_COUNT; st++)
+        for (size_t i = 0; i < h->ev[st].start.size(); i++) {
+            (void)hipEventDestroy(h->ev[st].start[i]);
+            (void)hipEventDestroy(h->ev[st].stop[i]);
+        }
     (void)hipHostFree(h->host_counts);
     delete h;
+    return FR_OK;
+}
+
+int fr_profile_enable(fr_handle* hh, int32_t on)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
+    h->profiling = on != 0;
+    for (int st = 0; st < ST_COUNT; st++) h->ev[st].used = 0;
+    return FR_OK;
+}
+
+int fr_profile_read(fr_handle* hh, int32_t stage, double* total_ms, uint32_t* launches)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h || stage < 0 || stage >= ST_COUNT || !total_ms || !launches) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
+    StageEvents& e = h->ev[stage];
+    double tot = 0;
+    for (size_t i = 0; i < e.used; i++) {
+        float ms = 0;
+        FR_HIP(hipEventElapsedTime(&ms, e.start[i], e.stop[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (uint32_t)e.used;
     return FR_OK;
 }
 

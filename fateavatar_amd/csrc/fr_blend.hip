@@ -483,29 +483,38 @@ static int debug_sync(bool debug, hipStream_t s, const char* stage)
     return FR_OK;
 }
 
-int launch_sort_and_blend(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
-                          float* out_color, hipStream_t s, bool debug)
+int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
+                          BinningView b, float* out_color, hipStream_t s, bool debug)
 {
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
     const uint32_t small_blocks = (T + 3) / 4;
     int rc;
-    hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters), dim3(256), 0, s, v, T, small_blocks,
-                       (u64*)b.keys, b.recs, g);
+    {
+        StageScope sc(h, ST_SORT, s);
+        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters), dim3(256), 0, s, v, T, small_blocks,
+                           (u64*)b.keys, b.recs, g);
+    }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
-    hipLaunchKernelGGL(k_blend_fwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
-                       v.tiles_x, in.background, out_color, v.final_T, v.n_contrib, v.counts);
+    {
+        StageScope sc(h, ST_BLEND_FWD, s);
+        hipLaunchKernelGGL(k_blend_fwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
+                           v.tiles_x, in.background, out_color, v.final_T, v.n_contrib, v.counts);
+    }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "blend_fwd"))) return rc;
     return FR_OK;
 }
 
-int launch_blend_backward(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
-                          const float* dL_dpix, hipStream_t s, bool debug)
+int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
+                          BinningView b, const float* dL_dpix, hipStream_t s, bool debug)
 {
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
-    hipLaunchKernelGGL(k_blend_bwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
-                       v.tiles_x, in.background, v.final_T, v.n_contrib, dL_dpix, g.accum);
+    {
+        StageScope sc(h, ST_BLEND_BWD, s);
+        hipLaunchKernelGGL(k_blend_bwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
+                           v.tiles_x, in.background, v.final_T, v.n_contrib, dL_dpix, g.accum);
+    }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");
 }

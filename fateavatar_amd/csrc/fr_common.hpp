@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/fr_rasterizer.h"
 
 namespace fr {
@@ -138,11 +139,45 @@ struct BinningView {
     }
 };
 
+enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+
+struct StageEvents {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+
 struct fr_handle_impl {
     int device;
     fr_counts* host_counts;      // pinned, mapped
     fr_counts* host_counts_dev;  // device view of the same memory
     hipEvent_t counts_ready;
+    bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
+    StageEvents ev[ST_COUNT];
+};
+
+// Brackets one kernel launch with HIP events on its stream when profiling is on.
+struct StageScope {
+    fr_handle_impl* h;
+    int st;
+    hipStream_t s;
+    StageScope(fr_handle_impl* h_, int st_, hipStream_t s_) : h(h_), st(st_), s(s_)
+    {
+        if (!h || !h->profiling) { h = nullptr; return; }
+        StageEvents& e = h->ev[st];
+        if (e.used == e.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { h = nullptr; return; }
+            e.start.push_back(a), e.stop.push_back(b);
+        }
+        (void)hipEventRecord(e.start[e.used], s);
+    }
+    ~StageScope()
+    {
+        if (!h) return;
+        StageEvents& e = h->ev[st];
+        (void)hipEventRecord(e.stop[e.used], s);
+        e.used++;
+    }
 };
 
 // ---- stage launchers (defined in the .hip files) ----

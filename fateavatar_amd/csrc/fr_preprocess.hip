@@ -307,8 +307,8 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 }
 
 // implemented in fr_blend.hip
-int launch_sort_and_blend(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
-                          float* out_color, hipStream_t s, bool debug);
+int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
+                          BinningView b, float* out_color, hipStream_t s, bool debug);
 
 static int debug_sync(bool debug, hipStream_t s, const char* stage)
 {
@@ -344,20 +344,29 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
     if (P > 0) {
-        hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+        {
+            StageScope sc(h, ST_PREPROCESS_FWD, s);
+            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+        }
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, h->host_counts_dev);
+    {
+        StageScope sc(h, ST_SCAN, s);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, h->host_counts_dev);
+    }
     FR_HIP(hipGetLastError());
     FR_HIP(hipEventRecord(h->counts_ready, s));
     if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
     if (P > 0) {
-        hipLaunchKernelGGL(k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, s, P, g, v, b.keys);
+        {
+            StageScope sc(h, ST_EMIT, s);
+            hipLaunchKernelGGL(k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, s, P, g, v, b.keys);
+        }
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "emit_instances"))) return rc;
     }
-    if ((rc = launch_sort_and_blend(prm, in, g, v, b, out_color, s, debug))) return rc;
+    if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
 
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).
     FR_HIP(hipEventSynchronize(h->counts_ready));

@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
     }
 }
 
-int launch_blend_backward(const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v, BinningView b,
-                          const float* dL_dpix, hipStream_t s, bool debug);
+int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
+                          BinningView b, const float* dL_dpix, hipStream_t s, bool debug);
 
-int launch_backward(fr_handle_impl*, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
+int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
                     const void* image, const void* binning, const float* dL_dpix, const fr_grads& gr, hipStream_t s)
 {
     const int P = prm.P;
@@ -290,7 +290,7 @@ int launch_backward(fr_handle_impl*, const fr_params& prm, const fr_inputs& in, 
     BinningView b = BinningView::make(const_cast<void*>(binning), 0);
     const bool debug = prm.debug != 0;
     FR_HIP(hipMemsetAsync(g.accum, 0, sizeof(float) * (size_t)P * kAccumStride, s));
-    int rc = launch_blend_backward(prm, in, g, v, b, dL_dpix, s, debug);
+    int rc = launch_blend_backward(h, prm, in, g, v, b, dL_dpix, s, debug);
     if (rc) return rc;
 
     PreBwdArgs a;
@@ -302,7 +302,10 @@ int launch_backward(fr_handle_impl*, const fr_params& prm, const fr_inputs& in, 
     a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.shs = in.shs;
     a.cov3D_precomp = in.cov3D_precomp, a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.radii = radii, a.g = g, a.out = gr;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    {
+        StageScope sc(h, ST_PREPROCESS_BWD, s);
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    }
     FR_HIP(hipGetLastError());
     if (debug) FR_HIP(hipStreamSynchronize(s));
     return FR_OK;

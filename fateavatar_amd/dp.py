@@ -1,0 +1,73 @@
+"""Data-parallel frame sharding (BASELINE.json config 4).
+
+The reference is single-process; it loops `for bs_ in range(bs): render(...)` over the frames of a
+batch with shared Gaussian parameters and averages the loss (model/fateavatar.py:251-276,
+train/loss.py:92-105).  Here: one process per GPU, parameters replicated, rank r renders frame r,
+and ONE all-reduce(AVG) of the flat gradient buffer over RCCL/xGMI makes every rank's gradient the
+batch mean; the per-view densification statistics (‖means2D.grad‖ sums and visibility counts,
+model/fateavatar.py:734-737) are summed with a second small all-reduce.  No collective runs
+inside the rasterizer: a frame never leaves its GPU.
+
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
+    """In-place batch-mean of a flat gradient buffer across ranks (one collective)."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(w)
+    return flat_grad
+
+
+def allreduce_sum_(stats: torch.Tensor) -> torch.Tensor:
+    """In-place sum of per-view statistics (densification accumulators) across ranks."""
+    if world_size() > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    return stats
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> list[int]:
+    """Frames of a batch handled by `rank` (round-robin, like a DistributedSampler without shuffling)."""
+    return list(range(rank, n_frames, world))
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Make a tensor identical on every rank (initial parameters, densification draws)."""
+    if world_size() > 1:
+        dist.broadcast(t, src)
+    return t
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

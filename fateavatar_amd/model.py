@@ -1,0 +1,78 @@
+"""Minimal Gaussian parameter holder with the reference GaussianModel's getters
+(volume_rendering/gaussian_model.py:39-50,105-128): raw parameters + exp / sigmoid / normalize
+activations in stock PyTorch.  It exists so that `render()` can be driven exactly like the
+reference drives it; densification, PLY I/O and optimizer surgery are out of scope.
+
+All parameters live in ONE flat fp32 buffer (and their gradients in one flat buffer), so the
+data-parallel exchange is a single all-reduce (fateavatar_amd/dp.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class FlatGaussians(torch.nn.Module):
+    FIELDS = (("_xyz", 3), ("_features", None), ("_opacity", 1), ("_scaling", 3), ("_rotation", 4))
+
+    def __init__(self, means3D, shs, opacities, scales, rotations, sh_degree: int, device):
+        """Arguments are ACTIVATED values (numpy): they are inverted into raw parameters like
+        create_from_pcd does (gaussian_model.py:137-160)."""
+        super().__init__()
+        P, M = means3D.shape[0], shs.shape[1]
+        self.max_sh_degree = sh_degree
+        self.P, self.M = P, M
+        sizes = [P * 3, P * M * 3, P, P * 3, P * 4]
+        self.flat = torch.nn.Parameter(torch.empty(sum(sizes), dtype=torch.float32, device=device))
+        self.flat.grad = torch.zeros_like(self.flat)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+        op = t(opacities).reshape(-1).clamp(1e-6, 1 - 1e-6)
+        raw = [t(means3D), t(shs), torch.log(op / (1 - op)), torch.log(t(scales)), t(rotations)]
+        self._views, self._gviews = {}, {}
+        off = 0
+        shapes = [(P, 3), (P, M, 3), (P, 1), (P, 3), (P, 4)]
+        with torch.no_grad():
+            for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
+                self.flat.data[off:off + n].copy_(r.reshape(-1))
+                self._views[name] = (off, n, shp)
+                off += n
+
+    def _p(self, name):
+        off, n, shp = self._views[name]
+        return self.flat[off:off + n].view(shp)
+
+    # ---- the reference getters
+    @property
+    def get_xyz(self):
+        return self._p("_xyz")
+
+    @property
+    def get_features(self):
+        return self._p("_features")
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._p("_opacity"))
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._p("_scaling"))
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._p("_rotation"))
+
+    def grad_of(self, name):
+        off, n, shp = self._views[name]
+        return self.flat.grad[off:off + n].view(shp)
+
+
+class TorchCamera:
+    """Device-side camera with the attribute names render() reads (camera_3dgs.py:22-72)."""
+
+    def __init__(self, cam, device):
+        self.image_height, self.image_width = cam.image_height, cam.image_width
+        self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
+        self.world_view_transform = torch.from_numpy(cam.world_view_transform).to(device)
+        self.full_proj_transform = torch.from_numpy(cam.full_proj_transform).to(device)
+        self.camera_center = torch.from_numpy(cam.camera_center).to(device)

@@ -200,7 +200,9 @@ def head_scene(P: int = 100_000, res: int = 512, sh_degree: int = 3, seed: int =
     T = np.asarray([0.0, 1.47, 0.98], np.float32)
     if n_views > 1 and view > 0:
         # rotate the camera about the head's vertical axis through (0, 1.47, 0): world' = Ry * (world - c) + c
-        ang = (view / n_views) * (math.pi / 3) - math.pi / 6
+        # view 0 frontal, then alternating +/- steps out to +-30 degrees
+        step = (math.pi / 6) / max(1, (n_views) // 2)
+        ang = ((view + 1) // 2) * step * (1.0 if view % 2 else -1.0)
         c, s = math.cos(ang), math.sin(ang)
         Ry = np.asarray([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
         ctr = np.asarray([0.0, 1.47, 0.0], np.float32)

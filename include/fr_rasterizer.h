@@ -110,6 +110,13 @@ int fr_destroy(fr_handle* h);
 const char* fr_last_error(void);
 const char* fr_version(void);
 
+/* Stage timing.  While enabled, every kernel launch of fr_forward / fr_backward is bracketed by HIP
+ * events on the stream it is launched on; fr_profile_read sums the elapsed time of one stage over all
+ * launches since fr_profile_enable(h, 1) (the stream must have been synchronised by the caller).
+ * stage: 0 preprocess_fwd, 1 scan, 2 emit, 3 tile_sort, 4 blend_fwd, 5 blend_bwd, 6 preprocess_bwd. */
+int fr_profile_enable(fr_handle* h, int32_t on);
+int fr_profile_read(fr_handle* h, int32_t stage, double* total_ms, uint32_t* launches);
+
 /* Scratch sizes in bytes.  geometry: per-Gaussian state + gradient accumulators; image: per-pixel
  * final transmittance / contributor count and per-tile ranges; binning: `capacity` instances. */
 size_t fr_geometry_bytes(int32_t P);

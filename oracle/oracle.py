@@ -43,6 +43,8 @@ def lib():
         L.fro_knn_mean_dist2.argtypes = [C.c_int, fp, fp]
         L.fro_num_rendered.argtypes = [C.c_void_p]
         L.fro_num_rendered.restype = C.c_int
+        L.fro_eval_sh.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
+        L.fro_cov3d.argtypes = [fp, C.c_float, fp, fp]
         L.fro_num_threads.restype = C.c_int
         L.fro_set_num_threads.argtypes = [C.c_int]
         for name, ty in [("depths", C.c_float), ("clamped", C.c_uint8), ("means2D", C.c_float), ("cov3D", C.c_float),
@@ -204,3 +206,19 @@ def num_threads() -> int:
 
 def set_num_threads(n: int) -> None:
     lib().fro_set_num_threads(int(n))
+
+
+def eval_sh(deg: int, sh, mean, campos):
+    """Clamped RGB of one Gaussian (forward.cu:20-71). sh [M,3]."""
+    sh, mean, campos = _f32(sh), _f32(mean), _f32(campos)
+    out = np.zeros(3, np.float32)
+    cl = np.zeros(3, np.uint8)
+    lib().fro_eval_sh(int(deg), sh.shape[0], _p(mean), _p(campos), _p(sh), _p(out), cl.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out, cl.astype(bool)
+
+
+def cov3d(scale, mod: float, rot):
+    """6 upper-triangular floats of Sigma = R S^2 R^T (forward.cu:118-152)."""
+    out = np.zeros(6, np.float32)
+    lib().fro_cov3d(_p(_f32(scale)), float(mod), _p(_f32(rot)), _p(out))
+    return out

@@ -187,3 +187,49 @@ def test_reduce_scatter_selftest(gpu_device):
         v = int(format(l, "06b")[::-1], 2)
         if v < 36:
             assert abs(got[l] - ref[v]) <= 1e-4 * max(1.0, abs(ref[v])), (l, v, got[l], ref[v])
+
+
+def test_knn_bit_exact_vs_oracle(gpu_device):
+    import torch
+    from oracle import oracle
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(2)
+    verts, faces, _ = scenes.head_geometry()
+    for pts in (scenes.sample_mesh(verts, faces, 20000, seed=3), rng.normal(size=(5000, 3)).astype(np.float32),
+                rng.uniform(-1, 1, (37, 3)).astype(np.float32),
+                np.repeat(rng.normal(size=(50, 3)).astype(np.float32), 5, axis=0)):  # exact duplicates
+        got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+        ref = oracle.knn_mean_dist2(pts)
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_render_api_autograd_path(gpu_device):
+    """render() + autograd down to the raw parameters == oracle grads chained through the activations."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from oracle import oracle
+    s = scenes.head_scene(P=6000, res=96, sh_degree=3, seed=1)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 3, gpu_device)
+    cam = TorchCamera(s.camera, gpu_device)
+    out = render(cam, pc, torch.from_numpy(s.bg).to(gpu_device))
+    img = out["render"]
+    rng = np.random.default_rng(0)
+    w = (rng.uniform(-1, 1, img.shape) / img.numel()).astype(np.float32)
+    (img * torch.from_numpy(w).to(gpu_device)).sum().backward()
+    c = s.camera
+    f = oracle.forward(bg=s.bg, means3D=s.means3D, opacities=pc.get_opacity.detach().cpu().numpy(),
+                       viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, campos=c.camera_center,
+                       tanfovx=c.tanfovx, tanfovy=c.tanfovy, H=96, W=96, shs=s.shs, sh_degree=3,
+                       scales=pc.get_scaling.detach().cpu().numpy(), rotations=pc.get_rotation.detach().cpu().numpy())
+    b = oracle.backward(f, w)
+    assert util.frac_close(img.detach().cpu().numpy(), f.color, 1e-4, 1e-5) >= 0.9999
+    assert np.array_equal(out["visibility_filter"].cpu().numpy(), f.radii > 0)
+    assert util.rel_l2(out["viewspace_points"].grad.cpu().numpy(), b.dL_dmeans2D) < 2e-4
+    assert util.rel_l2(pc.grad_of("_xyz").cpu().numpy(), b.dL_dmeans3D) < 2e-4
+    assert util.rel_l2(pc.grad_of("_features").cpu().numpy(), b.dL_dsh) < 2e-4
+    # chain rule through sigmoid / exp in stock PyTorch
+    op = pc.get_opacity.detach().cpu().numpy()
+    assert util.rel_l2(pc.grad_of("_opacity").cpu().numpy(), b.dL_dopacity * op * (1 - op)) < 2e-4
+    sc = pc.get_scaling.detach().cpu().numpy()
+    assert util.rel_l2(pc.grad_of("_scaling").cpu().numpy(), b.dL_dscales * sc) < 2e-4

@@ -1,0 +1,92 @@
+"""CPU: the Python host mirrors the reference operator interface (names, argument order, errors)."""
+import numpy as np
+import pytest
+import torch
+
+import diff_gaussian_rasterization as dgr
+from fateavatar_amd import rasterizer, scenes
+from fateavatar_amd.model import FlatGaussians
+
+
+def _settings(**kw):
+    base = dict(image_height=32, image_width=32, tanfovx=0.2, tanfovy=0.2, bg=torch.ones(3), scale_modifier=1.0,
+                viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3),
+                prefiltered=False, debug=False)
+    base.update(kw)
+    return dgr.GaussianRasterizationSettings(**base)
+
+
+def test_settings_fields_match_reference_order():
+    # reference diff_gaussian_rasterization/__init__.py:157-169
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+
+
+def test_alias_packages_expose_reference_names():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C  # noqa: F401
+    from simple_knn._C import distCUDA2  # noqa: F401
+    assert callable(_C.rasterize_gaussians) and callable(_C.rasterize_gaussians_backward) and callable(_C.mark_visible)
+
+
+def test_argument_validation_messages_match_reference():
+    r = dgr.GaussianRasterizer(_settings())
+    P = 4
+    m3, m2, op = torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1)
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(m3, m2, op, scales=torch.ones(P, 3), rotations=torch.ones(P, 4))
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(m3, m2, op, shs=torch.zeros(P, 1, 3), colors_precomp=torch.zeros(P, 3), scales=torch.ones(P, 3),
+          rotations=torch.ones(P, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m3, m2, op, shs=torch.zeros(P, 1, 3))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m3, m2, op, shs=torch.zeros(P, 1, 3), scales=torch.ones(P, 3), rotations=torch.ones(P, 4),
+          cov3D_precomp=torch.zeros(P, 6))
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    """No silent CPU fallback: the product path needs the HIP device."""
+    r = dgr.GaussianRasterizer(_settings())
+    P = 4
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1), shs=torch.zeros(P, 1, 3), scales=torch.ones(P, 3),
+          rotations=torch.ones(P, 4))
+    from simple_knn._C import distCUDA2
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        distCUDA2(torch.zeros(8, 3))
+
+
+def test_means3d_shape_check_matches_reference_glue():
+    # rasterize_points.cu:57-59
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        rasterizer.rasterize_gaussians(torch.ones(3), torch.zeros(5, 2), torch.empty(0), torch.ones(5, 1),
+                                       torch.ones(5, 3), torch.ones(5, 4), 1.0, torch.empty(0), torch.eye(4),
+                                       torch.eye(4), 0.2, 0.2, 8, 8, torch.zeros(5, 1, 3), 0, torch.zeros(3), False,
+                                       False)
+
+
+def test_flat_gaussians_getters_reproduce_activated_values():
+    s = scenes.random_scene(50, 16, 16, sh_degree=1, seed=0)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 1, "cpu")
+    np.testing.assert_allclose(pc.get_xyz.detach().numpy(), s.means3D, rtol=0, atol=0)
+    np.testing.assert_allclose(pc.get_opacity.detach().numpy(), s.opacities, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pc.get_scaling.detach().numpy(), s.scales, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pc.get_rotation.detach().numpy(), s.rotations, rtol=1e-5, atol=1e-6)
+    assert pc.get_features.shape == (50, 4, 3)
+    # gradients of every field land in ONE flat buffer
+    (pc.get_opacity.sum() + pc.get_scaling.sum() + pc.get_xyz.sum()).backward()
+    assert pc.flat.grad.shape == pc.flat.shape and pc.flat.grad.abs().sum() > 0
+    assert torch.equal(pc.grad_of("_xyz"), torch.ones(50, 3))
+
+
+def test_head_scene_and_view_orbit():
+    s0 = scenes.head_scene(P=2000, res=64, view=0, n_views=4)
+    s1 = scenes.head_scene(P=2000, res=64, view=2, n_views=4)
+    assert s0.means3D.shape == (2000, 3) and s0.shs.shape == (2000, 16, 3)
+    np.testing.assert_array_equal(s0.means3D, s1.means3D)  # replicated Gaussians, different cameras
+    assert not np.allclose(s0.camera.world_view_transform, s1.camera.world_view_transform)
+    # both cameras look at the head: the head centre projects near the image centre
+    for s in (s0, s1):
+        c = np.array([0.0, 1.47, 0.0, 1.0], np.float32) @ s.camera.full_proj_transform
+        assert abs(c[0] / c[3]) < 0.3 and abs(c[1] / c[3]) < 0.3 and c[3] > 0.2

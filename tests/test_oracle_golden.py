@@ -1,0 +1,80 @@
+"""CPU: pin the oracle (and the host-side camera helpers) against golden vectors produced by the
+reference's own importable Python (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+
+from fateavatar_amd import scenes
+from oracle import oracle
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sh_colour_matches_reference_eval_sh():
+    z = np.load(os.path.join(G, "golden_sh.npz"))
+    dirs, sh = z["dirs"], z["sh"]
+    campos = np.zeros(3, np.float32)
+    worst = 0.0
+    for deg in range(4):
+        ref = np.maximum(z[f"deg{deg}"] + 0.5, 0.0)  # forward.cu:63-70 adds 0.5 and clamps
+        for i in range(dirs.shape[0]):
+            got, cl = oracle.eval_sh(deg, sh[i], dirs[i] * 2.5, campos)  # any point along the direction
+            worst = max(worst, float(np.abs(got - ref[i]).max()))
+            assert np.array_equal(cl, (z[f"deg{deg}"][i] + 0.5) < 0) or np.abs(z[f"deg{deg}"][i] + 0.5).min() < 1e-6
+    assert worst < 2e-6, worst
+
+
+def test_cov3d_matches_reference_build_scaling_rotation():
+    z = np.load(os.path.join(G, "golden_cov3d.npz"))
+    for key, mod in (("cov_mod1", 1.0), ("cov_mod037", 0.37)):
+        ref = z[key]
+        got = np.stack([oracle.cov3d(z["scales"][i], mod, z["quats"][i]) for i in range(ref.shape[0])])
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        assert (np.abs(got - ref) <= 2e-6 * scale + 1e-12).all()
+
+
+def test_camera_matches_reference_camera():
+    z = np.load(os.path.join(G, "golden_camera.npz"))
+    for name in z["names"]:
+        fx, fy = z[f"{name}_fov"]
+        h, w = z[f"{name}_res"]
+        cam = scenes.make_camera(z[f"{name}_R"], z[f"{name}_T"], float(fx), float(fy), int(h), int(w))
+        np.testing.assert_allclose(cam.world_view_transform, z[f"{name}_wvt"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(cam.full_proj_transform, z[f"{name}_full"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(cam.camera_center, z[f"{name}_center"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(scenes.projection_matrix(0.01, 100.0, float(fx), float(fy)).T, z[f"{name}_proj"],
+                                   rtol=1e-6, atol=1e-7)
+
+
+def test_inverse_sigmoid_round_trip():
+    z = np.load(os.path.join(G, "golden_misc.npz"))
+    x = z["x"].astype(np.float64)
+    np.testing.assert_allclose(np.log(x / (1 - x)), z["inverse_sigmoid"], rtol=2e-6, atol=1e-6)
+
+
+def test_workload_shape_matches_survey():
+    """SURVEY.md Appendix B measured the reference (run through a host shim) on config 2:
+    351 non-empty 16x16 tiles, mean/max list 594/1570, all radii 4, 28.5 % covered pixels."""
+    s = scenes.head_scene()
+    f = oracle.forward(bg=s.bg, means3D=s.means3D, opacities=s.opacities, viewmatrix=s.camera.world_view_transform,
+                       projmatrix=s.camera.full_proj_transform, campos=s.camera.camera_center,
+                       tanfovx=s.camera.tanfovx, tanfovy=s.camera.tanfovy, H=512, W=512, shs=s.shs, sh_degree=3,
+                       scales=s.scales, rotations=s.rotations)
+    ln = f.ranges[:, 1] - f.ranges[:, 0]
+    assert int((ln > 0).sum()) == 351
+    assert int(ln.max()) == 1570
+    assert abs(f.num_rendered - 208596) < 200
+    assert set(np.unique(f.radii)) == {4}
+    assert abs(float((f.final_T < 1).mean()) - 0.285) < 0.003
+
+
+def test_knn_oracle_is_exact():
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(3000, 3)).astype(np.float32)
+    got = oracle.knn_mean_dist2(pts)
+    d = ((pts[:, None, :] - pts[None, :, :]) ** 2)
+    d2 = (d[..., 0] + d[..., 1]) + d[..., 2]
+    np.fill_diagonal(d2, np.inf)
+    d2.sort(axis=1)
+    ref = ((d2[:, 0] + d2[:, 1]) + d2[:, 2]) / np.float32(3.0)
+    np.testing.assert_array_equal(got, ref.astype(np.float32))
