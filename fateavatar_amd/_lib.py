@@ -67,6 +67,10 @@ def lib():
         raise RuntimeError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C fateavatar_amd/csrc`). There is no fallback path.")
+    # PyTorch-ROCm ships its own libamdhip64: import it FIRST so that this library binds to the same
+    # HIP runtime instance (two runtimes in one process cannot share streams or device pointers).
+    import torch  # noqa: F401
+
     L = C.CDLL(SO_PATH)
     L.fr_create.argtypes = [C.POINTER(C.c_void_p)]
     L.fr_create.restype = C.c_int
