@@ -85,7 +85,7 @@ def lib():
     L.fr_geometry_bytes.restype = C.c_size_t
     L.fr_image_bytes.argtypes = [C.c_int32, C.c_int32]
     L.fr_image_bytes.restype = C.c_size_t
-    L.fr_binning_bytes.argtypes = [C.c_uint64]
+    L.fr_binning_bytes.argtypes = [C.c_uint64, C.c_int32, C.c_int32]
     L.fr_binning_bytes.restype = C.c_size_t
     L.fr_forward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
                              C.c_uint64, C.POINTER(fr_counts), C.c_void_p]

@@ -108,7 +108,11 @@ int fr_profile_read(fr_handle* hh, int32_t stage, double* total_ms, uint32_t* la
 
 size_t fr_geometry_bytes(int32_t P) { return GeomView::bytes((size_t)(P > 0 ? P : 0)); }
 size_t fr_image_bytes(int32_t W, int32_t H) { return ImageView::bytes(W, H); }
-size_t fr_binning_bytes(uint64_t capacity) { return BinningView::bytes((size_t)capacity); }
+size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H)
+{
+    ImageView v = ImageView::make(nullptr, W, H);
+    return BinningView::bytes((size_t)capacity, (size_t)v.tiles_x * v.tiles_y);
+}
 
 int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
                void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts, void* stream)

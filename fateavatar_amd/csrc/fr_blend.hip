@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
 // wave-uniform addresses (LDS broadcast), four at a time so that the four exp/alpha evaluations
 // are independent instruction streams and only the short T / colour recurrence is serial.
 constexpr int kBatch = 64;
+constexpr uint32_t kUnitGrid = 8192;  // workgroups of the unit kernels (grid-stride over the device-side unit count)
 constexpr int kGroup = 4;
 
 struct RecRegs {
@@ -212,81 +213,196 @@ __device__ __forceinline__ RecRegs fetch_record(const float4* __restrict__ src, 
     return r;
 }
 
-// ------------------------------------------------------------------ blend forward
-// reference: renderCUDA, forward.cu:261-374.  Per pixel the sequence of operations (and the
-// tests power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) is the reference's; only the order of
-// evaluation across pixels differs.
-__global__ void __launch_bounds__(64) k_blend_fwd(const uint32_t* __restrict__ tile_offset,
+// ================================================================== unit-parallel blending
+// A tile's sorted list is cut into UNITS of 64 records.  Every unit is an independent wavefront-sized
+// work item, so the serial instruction stream of a wave is bounded by 64 records no matter how long a
+// tile's list is (a wave issues roughly one instruction per 4 cycles: with one wave per TILE the longest
+// list set the kernel time).  Front-to-back compositing is a scan, so three light passes restore the
+// exact sequential semantics of the reference:
+//   A  k_unit_tseg     per unit and pixel: product of (1 - alpha) over the unit's blendable records
+//   B  k_unit_blend    per unit: T_in = product of the previous units' products; blend the unit's records
+//                      with the reference's tests (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) starting
+//                      from T_in; leave partial colour, running T, last contributor, termination flag
+//   C  k_tile_combine  per tile: sum the partial colours, pick final T / contributor count at the first
+//                      terminated unit, write the image, and leave for each unit the backward's entry state
+// The backward then runs every unit independently from that state.
+
+__device__ __forceinline__ void stage_unit(float4* s_rec, const float4* __restrict__ src, uint32_t base, uint32_t n,
+                                           int lane)
+{
+    const RecRegs r = fetch_record(src, base + (uint32_t)lane, n);
+    s_rec[lane * kRecQuads + 0] = r.q0;
+    s_rec[lane * kRecQuads + 1] = r.q1;
+    s_rec[lane * kRecQuads + 2] = r.q2;
+}
+
+struct UnitInfo {
+    uint32_t tile, seg, start, n, base, m;  // tile id, segment index, list start, list length, first record, records in unit
+    int px, py;
+    bool inside;
+};
+
+__device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint32_t* __restrict__ unit_tile,
+                                              const uint32_t* __restrict__ unit_offset,
+                                              const uint32_t* __restrict__ tile_offset, int W, int H, int tiles_x, int lane)
+{
+    UnitInfo i;
+    i.tile = unit_tile[u];
+    i.seg = u - unit_offset[i.tile];
+    i.start = tile_offset[i.tile];
+    i.n = tile_offset[i.tile + 1] - i.start;
+    i.base = i.seg * kUnit;
+    i.m = min((uint32_t)kUnit, i.n - i.base);
+    i.px = (int)(i.tile % (uint32_t)tiles_x) * kTile + (lane & 7);
+    i.py = (int)(i.tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
+    i.inside = i.px < W && i.py < H;
+    return i;
+}
+
+// ---- pass A
+__global__ void __launch_bounds__(64) k_unit_tseg(const DeviceCounts* __restrict__ counts,
+                                                  const uint32_t* __restrict__ unit_tile,
+                                                  const uint32_t* __restrict__ unit_offset,
+                                                  const uint32_t* __restrict__ tile_offset,
                                                   const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                  const float* __restrict__ bg, float* __restrict__ out_color,
-                                                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                  const DeviceCounts* __restrict__ counts)
+                                                  float* __restrict__ unit_tseg)
 {
     __shared__ float4 s_rec[kBatch * kRecQuads];
+    const int lane = threadIdx.x;
+    const uint32_t nu = counts->num_units;
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
+    if (ui.base + kUnit >= ui.n) continue;  // the last unit's product is never needed
+    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+    float t = 1.0f;
+    for (uint32_t j = 0; j < (uint32_t)kUnit; j += kGroup) {
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
+            const float2 q1 = *reinterpret_cast<const float2*>(&s_rec[(j + k) * kRecQuads + 1]);
+            const float dx = q0.x - fx, dy = q0.y - fy;
+            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            const bool ok = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            t = ok ? t * (1.f - alpha) : t;
+        }
+    }
+    unit_tseg[(size_t)u * kUnit + lane] = t;
+    }
+}
+
+// ---- pass B (reference: renderCUDA, forward.cu:261-374, restricted to one unit)
+__global__ void __launch_bounds__(64) k_unit_blend(const DeviceCounts* __restrict__ counts,
+                                                   const uint32_t* __restrict__ unit_tile,
+                                                   const uint32_t* __restrict__ unit_offset,
+                                                   const uint32_t* __restrict__ tile_offset,
+                                                   const float4* __restrict__ recs, int W, int H, int tiles_x,
+                                                   const float* __restrict__ unit_tseg, float* __restrict__ unit_out)
+{
+    __shared__ float4 s_rec[kBatch * kRecQuads];
+    const int lane = threadIdx.x;
+    const uint32_t nu = counts->num_units;
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
+    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+
+    float T = 1.0f;
+    for (uint32_t p = u - ui.seg; p < u; p++) T *= unit_tseg[(size_t)p * kUnit + lane];
+    // T_in < 1e-4 means an earlier unit already terminated this pixel: nothing here can be blended
+    bool dead = !ui.inside || (T < 0.0001f);
+    bool term = false;  // terminated inside THIS unit
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f;
+    uint32_t last = 0;
+    for (uint32_t j = 0; j < ui.m; j += kGroup) {
+        if (__all(dead)) break;
+        float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
+        bool ok[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
+            const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
+            const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
+            const float dx = q0.x - fx, dy = q0.y - fy;
+            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+            alpha[k] = fminf(0.99f, q1.y * __expf(power));
+            ok[k] = !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+            cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            bool c = !dead && ok[k];
+            const float test_T = T * (1.f - alpha[k]);
+            const bool fin = c && (test_T < 0.0001f);
+            term = term || fin;
+            dead = dead || fin;
+            c = c && !fin;
+            const float w = c ? alpha[k] * T : 0.f;
+            Cr += cr[k] * w;
+            Cg += cg[k] * w;
+            Cb += cb[k] * w;
+            T = c ? test_T : T;
+            last = c ? (ui.base + j + k + 1u) : last;
+        }
+    }
+    float* o = unit_out + (size_t)u * 5 * kUnit + lane;
+    o[0] = Cr;
+    o[kUnit] = Cg;
+    o[2 * kUnit] = Cb;
+    o[3 * kUnit] = T;
+    o[4 * kUnit] = __uint_as_float(last | (term ? 0x80000000u : 0u));
+    }
+}
+
+// ---- pass C: one wave per tile
+__global__ void __launch_bounds__(64) k_tile_combine(const DeviceCounts* __restrict__ counts,
+                                                     const uint32_t* __restrict__ unit_offset, int W, int H, int tiles_x,
+                                                     const float* __restrict__ bg, const float* __restrict__ unit_out,
+                                                     float4* __restrict__ unit_state, float* __restrict__ out_color,
+                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+{
     if (counts->overflow) return;
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
     const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
-    const uint32_t n = end - start;
-    const float4* __restrict__ src = recs + (size_t)start * kRecQuads;
-
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-    RecRegs nxt = fetch_record(src, (uint32_t)lane, n);
-    for (uint32_t base = 0; base < n; base += kBatch) {
-        s_rec[lane * kRecQuads + 0] = nxt.q0;
-        s_rec[lane * kRecQuads + 1] = nxt.q1;
-        s_rec[lane * kRecQuads + 2] = nxt.q2;
-        if (base + kBatch < n) nxt = fetch_record(src, base + kBatch + lane, n);
-        const uint32_t m = min((uint32_t)kBatch, n - base);
-        bool all_done = false;
-        for (uint32_t j = 0; j < m; j += kGroup) {
-            if (__all(done)) {
-                all_done = true;
-                break;
-            }
-            float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
-            bool ok[kGroup];
-#pragma unroll
-            for (int u = 0; u < kGroup; u++) {
-                const float4 q0 = s_rec[(j + u) * kRecQuads + 0];
-                const float4 q1 = s_rec[(j + u) * kRecQuads + 1];
-                const float q2x = s_rec[(j + u) * kRecQuads + 2].x;
-                const float dx = q0.x - fx, dy = q0.y - fy;
-                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-                alpha[u] = fminf(0.99f, q1.y * __expf(power));
-                ok[u] = !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
-                cr[u] = q1.z, cg[u] = q1.w, cb[u] = q2x;
-            }
-#pragma unroll
-            for (int u = 0; u < kGroup; u++) {
-                bool c = !done && ok[u];
-                const float test_T = T * (1.f - alpha[u]);
-                const bool fin = c && (test_T < 0.0001f);
-                done = done || fin;
-                c = c && !fin;
-                const float w = c ? alpha[u] * T : 0.f;
-                Cr += cr[u] * w;
-                Cg += cg[u] * w;
-                Cb += cb[u] * w;
-                T = c ? test_T : T;
-                last = c ? (base + j + u + 1u) : last;
-            }
+    const uint32_t u0 = unit_offset[tile], u1 = unit_offset[tile + 1];
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
+    uint32_t ncon = 0;
+    bool finished = false;
+    for (uint32_t u = u0; u < u1; u++) {
+        const float* o = unit_out + (size_t)u * 5 * kUnit + lane;
+        Cr += o[0];
+        Cg += o[kUnit];
+        Cb += o[2 * kUnit];
+        const uint32_t lf = __float_as_uint(o[4 * kUnit]);
+        if (!finished) {
+            Tf = o[3 * kUnit];
+            if (lf & 0x7fffffffu) ncon = lf & 0x7fffffffu;
+            finished = (lf & 0x80000000u) != 0;
         }
-        if (all_done) break;
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = Cr + T * bg[0];
-        out_color[HW + pix] = Cg + T * bg[1];
-        out_color[2 * HW + pix] = Cb + T * bg[2];
+        final_T[pix] = Tf;
+        n_contrib[pix] = ncon;
+        out_color[pix] = Cr + Tf * bg[0];
+        out_color[HW + pix] = Cg + Tf * bg[1];
+        out_color[2 * HW + pix] = Cb + Tf * bg[2];
+    }
+    // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the
+    // transmittance at the unit's far boundary (= what the reference's accum_rec recurrence yields there)
+    float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+    for (uint32_t u = u1; u-- > u0;) {
+        const float* o = unit_out + (size_t)u * 5 * kUnit + lane;
+        const float To = o[3 * kUnit];
+        const float inv = __builtin_amdgcn_rcpf(To);
+        unit_state[(size_t)u * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
+        Sr += o[0];
+        Sg += o[kUnit];
+        Sb += o[2 * kUnit];
     }
 }
 
@@ -349,114 +465,98 @@ __device__ __forceinline__ int bitrev6(int l)
     return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
 }
 
-__global__ void __launch_bounds__(64) k_blend_bwd(const uint32_t* __restrict__ tile_offset,
-                                                  const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                  const float* __restrict__ bg, const float* __restrict__ final_T,
-                                                  const uint32_t* __restrict__ n_contrib,
-                                                  const float* __restrict__ dL_dpix, float* __restrict__ accum)
+__global__ void __launch_bounds__(64) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                       void* binning, int W, int H, const float* __restrict__ bg,
+                                                       const float* __restrict__ dL_dpix, float* __restrict__ accum)
 {
     __shared__ float4 s_rec[kBatch * kRecQuads];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t start = tile_offset[tile], end = tile_offset[tile + 1];
-    if (end == start) return;
     const int lane = threadIdx.x;
-    const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
-    const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const size_t pix = inside ? (size_t)py * W + px : 0, HW = (size_t)H * W;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float T = T_final;
-    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
-    if (inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
-    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;  // accum_rec
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
-    // nothing behind the deepest contributor of any pixel of the tile can matter
-    uint32_t max_last = last;
-    for (int off = 32; off > 0; off >>= 1) max_last = max(max_last, (uint32_t)__shfl_xor(max_last, off));
-    const uint32_t n = __builtin_amdgcn_readfirstlane(max_last);
-    if (n == 0) return;
-    const float4* __restrict__ src = recs + (size_t)start * kRecQuads;
-
+    const uint32_t nu = counts->num_units;
+    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
     // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
-    const int v = bitrev6(lane);
-    const int own_u = v / 9, own_c = v - own_u * 9;
+    const int vv = bitrev6(lane);
+    const int own_u = vv / 9, own_c = vv - own_u * 9;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
+    const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
+    const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
+    // nothing at or behind the deepest contributor of any pixel of the tile can matter
+    if (!__any(last > ui.base)) continue;
 
-    const int nb = (int)((n + kBatch - 1) / kBatch);
-    RecRegs nxt = fetch_record(src, (uint32_t)(nb - 1) * kBatch + lane, n);
-    for (int b = nb - 1; b >= 0; --b) {
-        s_rec[lane * kRecQuads + 0] = nxt.q0;
-        s_rec[lane * kRecQuads + 1] = nxt.q1;
-        s_rec[lane * kRecQuads + 2] = nxt.q2;
-        if (b > 0) nxt = fetch_record(src, (uint32_t)(b - 1) * kBatch + lane, n);
-        const uint32_t base = (uint32_t)b * kBatch;
-        const int m = (int)min((uint32_t)kBatch, n - base);
-        for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
-            float G[kGroup], alpha[kGroup], dx[kGroup], dy[kGroup];
-            float4 q0[kGroup], q1[kGroup];
-            float q2x[kGroup];
-            bool ok[kGroup];
-            bool any_ok = false;
+    stage_unit(s_rec, b.recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+    const float T_final = ui.inside ? v.final_T[pix] : 0.f;
+    const float4 st = b.unit_state[(size_t)u * kUnit + lane];
+    float T = st.w;
+    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
+    if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
+    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
+    float acc_r = st.x, acc_g = st.y, acc_b = st.z;  // accum_rec entering the unit from behind
+    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+    const int m = (int)ui.m;
+
+    for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
+        float G[kGroup], alpha[kGroup], dx[kGroup], dy[kGroup];
+        float4 q0[kGroup], q1[kGroup];
+        float q2x[kGroup];
+        bool ok[kGroup];
+        bool any_ok = false;
 #pragma unroll
-            for (int u = 0; u < kGroup; u++) {
-                q0[u] = s_rec[(j + u) * kRecQuads + 0];
-                q1[u] = s_rec[(j + u) * kRecQuads + 1];
-                q2x[u] = s_rec[(j + u) * kRecQuads + 2].x;
-                dx[u] = q0[u].x - fx, dy[u] = q0[u].y - fy;
-                const float power = -0.5f * (q0[u].z * dx[u] * dx[u] + q1[u].x * dy[u] * dy[u]) - q0[u].w * dx[u] * dy[u];
-                G[u] = __expf(power);
-                alpha[u] = fminf(0.99f, q1[u].y * G[u]);
-                ok[u] = (base + (uint32_t)(j + u) < last) && !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
-                any_ok = any_ok || ok[u];
-            }
-            if (!__any(any_ok)) continue;
-
-            float s[kGroup * 9];
-#pragma unroll
-            for (int u = kGroup - 1; u >= 0; u--) {  // back to front
-                const bool c = ok[u];
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha[u]);
-                T = c ? T * inv : T;
-                const float dchannel_dcolor = c ? alpha[u] * T : 0.f;
-                // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
-                const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-                const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-                const float nbl = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-                acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nbl : acc_b;
-                last_r = c ? q1[u].z : last_r, last_g = c ? q1[u].w : last_g, last_b = c ? q2x[u] : last_b;
-                float dL_dalpha = ((q1[u].z - acc_r) * dpr + (q1[u].w - acc_g) * dpg) + (q2x[u] - acc_b) * dpb;
-                dL_dalpha *= T;
-                last_alpha = c ? alpha[u] : last_alpha;
-                dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-                dL_dalpha = c ? dL_dalpha : 0.f;
-
-                const float Gc = c ? G[u] : 0.f;  // G may be inf/NaN on lanes that failed the tests
-                const float dL_dG = q1[u].y * dL_dalpha;
-                const float gdx = Gc * dx[u], gdy = Gc * dy[u];
-                const float dG_ddelx = -gdx * q0[u].z - gdy * q0[u].w;
-                const float dG_ddely = -gdy * q1[u].x - gdx * q0[u].w;
-                float* su = s + u * 9;
-                su[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
-                su[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
-                su[ACC_CA] = -0.5f * gdx * dx[u] * dL_dG;
-                su[ACC_CB] = -0.5f * gdx * dy[u] * dL_dG;
-                su[ACC_CC] = -0.5f * gdy * dy[u] * dL_dG;
-                su[ACC_OP] = Gc * dL_dalpha;
-                su[ACC_R] = dchannel_dcolor * dpr;
-                su[ACC_G] = dchannel_dcolor * dpg;
-                su[ACC_B] = dchannel_dcolor * dpb;
-            }
-            const float total = reduce_scatter_36(reinterpret_cast<const float(&)[36]>(s), lane);
-            if (v < kGroup * 9 && (j + own_u) < m) {
-                const uint32_t id = __float_as_uint(s_rec[(j + own_u) * kRecQuads + 2].y);
-                atomic_add_f32(accum + (size_t)id * kAccumStride + own_c, total);
-            }
+        for (int k = 0; k < kGroup; k++) {
+            q0[k] = s_rec[(j + k) * kRecQuads + 0];
+            q1[k] = s_rec[(j + k) * kRecQuads + 1];
+            q2x[k] = s_rec[(j + k) * kRecQuads + 2].x;
+            dx[k] = q0[k].x - fx, dy[k] = q0[k].y - fy;
+            const float power = -0.5f * (q0[k].z * dx[k] * dx[k] + q1[k].x * dy[k] * dy[k]) - q0[k].w * dx[k] * dy[k];
+            G[k] = __expf(power);
+            alpha[k] = fminf(0.99f, q1[k].y * G[k]);
+            ok[k] = (ui.base + (uint32_t)(j + k) < last) && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+            any_ok = any_ok || ok[k];
         }
+        if (!__any(any_ok)) continue;
+
+        float s[kGroup * 9];
+#pragma unroll
+        for (int k = kGroup - 1; k >= 0; k--) {  // back to front
+            const bool c = ok[k];
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha[k]);
+            T = c ? T * inv : T;
+            const float dchannel_dcolor = c ? alpha[k] * T : 0.f;
+            // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
+            const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
+            const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
+            const float nbl = last_alpha * last_b + (1.f - last_alpha) * acc_b;
+            acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nbl : acc_b;
+            last_r = c ? q1[k].z : last_r, last_g = c ? q1[k].w : last_g, last_b = c ? q2x[k] : last_b;
+            float dL_dalpha = ((q1[k].z - acc_r) * dpr + (q1[k].w - acc_g) * dpg) + (q2x[k] - acc_b) * dpb;
+            dL_dalpha *= T;
+            last_alpha = c ? alpha[k] : last_alpha;
+            dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
+            dL_dalpha = c ? dL_dalpha : 0.f;
+
+            const float Gc = c ? G[k] : 0.f;  // G may be inf/NaN on lanes that failed the tests
+            const float dL_dG = q1[k].y * dL_dalpha;
+            const float gdx = Gc * dx[k], gdy = Gc * dy[k];
+            const float dG_ddelx = -gdx * q0[k].z - gdy * q0[k].w;
+            const float dG_ddely = -gdy * q1[k].x - gdx * q0[k].w;
+            float* su = s + k * 9;
+            su[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
+            su[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
+            su[ACC_CA] = -0.5f * gdx * dx[k] * dL_dG;
+            su[ACC_CB] = -0.5f * gdx * dy[k] * dL_dG;
+            su[ACC_CC] = -0.5f * gdy * dy[k] * dL_dG;
+            su[ACC_OP] = Gc * dL_dalpha;
+            su[ACC_R] = dchannel_dcolor * dpr;
+            su[ACC_G] = dchannel_dcolor * dpg;
+            su[ACC_B] = dchannel_dcolor * dpb;
+        }
+        const float total = reduce_scatter_36(reinterpret_cast<const float(&)[36]>(s), lane);
+        if (vv < kGroup * 9 && (j + own_u) < m) {
+            const uint32_t id = __float_as_uint(s_rec[(j + own_u) * kRecQuads + 2].y);
+            atomic_add_f32(accum + (size_t)id * kAccumStride + own_c, total);
+        }
+    }
     }
 }
 
@@ -488,6 +588,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
 {
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
     const uint32_t small_blocks = (T + 3) / 4;
+    const uint32_t unit_grid = (uint32_t)(b.unit_cap < kUnitGrid ? b.unit_cap : kUnitGrid);
     int rc;
     {
         StageScope sc(h, ST_SORT, s);
@@ -498,8 +599,12 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
     {
         StageScope sc(h, ST_BLEND_FWD, s);
-        hipLaunchKernelGGL(k_blend_fwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
-                           v.tiles_x, in.background, out_color, v.final_T, v.n_contrib, v.counts);
+        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64), 0, s, v.counts, b.unit_tile, v.unit_offset,
+                           v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
+        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64), 0, s, v.counts, b.unit_tile, v.unit_offset,
+                           v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        hipLaunchKernelGGL(k_tile_combine, dim3(T), dim3(64), 0, s, v.counts, v.unit_offset, prm.W, prm.H, v.tiles_x,
+                           in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "blend_fwd"))) return rc;
@@ -507,13 +612,14 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
 }
 
 int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          BinningView b, const float* dL_dpix, hipStream_t s, bool debug)
+                          void* binning, const float* dL_dpix, hipStream_t s, bool debug)
 {
-    const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+    // the unit count lives on the device: fixed grid, grid-stride loop over the units
+    const uint32_t unit_grid = kUnitGrid;
     {
         StageScope sc(h, ST_BLEND_BWD, s);
-        hipLaunchKernelGGL(k_blend_bwd, dim3(T), dim3(64), 0, s, v.tile_offset, (const float4*)b.recs, prm.W, prm.H,
-                           v.tiles_x, in.background, v.final_T, v.n_contrib, dL_dpix, g.accum);
+        hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64), 0, s, v.counts, v, binning, prm.W, prm.H,
+                           in.background, dL_dpix, g.accum);
     }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");

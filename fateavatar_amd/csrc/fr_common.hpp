@@ -31,7 +31,7 @@ int fail_msg(int code, const char* msg);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
-static inline T* carve(char*& p, size_t count)
+__host__ __device__ static inline T* carve(char*& p, size_t count)
 {
     uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
     T* r = reinterpret_cast<T*>(a);
@@ -78,7 +78,8 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
     uint32_t large_cursor;   // work-queue head for the large-tile sorter
-    uint32_t pad[2];
+    uint32_t num_units;      // total number of blend units (64-record segments of tile lists)
+    uint32_t capacity;       // binning capacity of this frame (the backward re-derives the binning layout from it)
 };
 
 struct ImageView {
@@ -87,6 +88,7 @@ struct ImageView {
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
     uint32_t* tile_cursor;   // [T]   emit cursors (start at tile_offset)
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
+    uint32_t* unit_offset;   // [T+1] exclusive scan of ceil(tile_count / 64): first blend unit of each tile
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
     int tiles_x, tiles_y;
@@ -102,6 +104,7 @@ struct ImageView {
         v.tile_offset = carve<uint32_t>(p, T + 1);
         v.tile_cursor = carve<uint32_t>(p, T);
         v.large_list = carve<uint32_t>(p, T);
+        v.unit_offset = carve<uint32_t>(p, T + 1);
         v.final_T = carve<float>(p, (size_t)W * H);
         v.n_contrib = carve<uint32_t>(p, (size_t)W * H);
         return v;
@@ -119,23 +122,37 @@ struct ImageView {
     }
 };
 
+constexpr int kUnit = 64;  // records per blend unit (= one LDS batch of one wavefront)
+
+// A blend UNIT is one 64-record segment of one tile's sorted list: the independent work item of the
+// blend kernels.  Per unit and pixel (lane) the forward leaves what the other passes need.
 struct BinningView {
-    uint64_t* keys;  // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
-    float4* recs;    // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
-    static BinningView make(void* buf, size_t cap)
+    size_t cap, unit_cap;
+    uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
+    float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
+    uint32_t* unit_tile;  // [unit_cap] tile of each unit
+    float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
+    float* unit_out;      // [unit_cap*5*64] forward partials per pixel: Cr, Cg, Cb, T_out, (last | done<<31)
+    float4* unit_state;   // [unit_cap*64]   backward entry state per pixel: colour behind the unit / T_out, T_out
+    __host__ __device__ static size_t units_for(size_t cap, size_t T) { return cap / kUnit + T + 1; }
+    __host__ __device__ static BinningView make(void* buf, size_t cap, size_t T)
     {
         char* p = static_cast<char*>(buf);
         BinningView b;
-        // recs first: its address does not depend on the capacity, so the backward (which only
-        // needs the records) can find it without knowing the capacity of the forward call
+        b.cap = cap;
+        b.unit_cap = units_for(cap, T);
         b.recs = carve<float4>(p, cap * 3);
         b.keys = carve<uint64_t>(p, cap);
+        b.unit_tile = carve<uint32_t>(p, b.unit_cap);
+        b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
+        b.unit_out = carve<float>(p, b.unit_cap * 5 * kUnit);
+        b.unit_state = carve<float4>(p, b.unit_cap * kUnit);
         return b;
     }
-    static size_t bytes(size_t cap)
+    static size_t bytes(size_t cap, size_t T)
     {
-        BinningView b = make(nullptr, cap);
-        return reinterpret_cast<size_t>(b.keys + cap) + 256;
+        BinningView b = make(nullptr, cap, T);
+        return reinterpret_cast<size_t>(b.unit_state + b.unit_cap * kUnit) + 256;
     }
 };
 

@@ -219,48 +219,66 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&a.counts->num_rendered, s);
 }
 
-// Exclusive scan of the per-tile counts by ONE workgroup; also publishes the frame counts to
-// pinned host memory and builds the list of tiles too long for the in-register sort.
-__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, fr_counts* host_counts)
+// Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
+// (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
+// the unit -> tile table and builds the list of tiles too long for the in-register sort.
+__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, uint32_t* unit_tile,
+                                                     uint32_t unit_cap, fr_counts* host_counts)
 {
     __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_usum[1024];
     __shared__ uint32_t s_max[16];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (T + 1023u) / 1024u;
-    const uint32_t b = tid * per, e = min(T, b + per);
-    uint32_t sum = 0, mx = 0;
+    const uint32_t b = min(T, tid * per), e = min(T, b + per);
+    uint32_t sum = 0, usum = 0, mx = 0;
     for (uint32_t i = b; i < e; i++) {
         const uint32_t c = v.tile_count[i];
         sum += c;
+        usum += (c + kUnit - 1) / kUnit;
         mx = max(mx, c);
         if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&v.counts->large_tiles, 1u)] = i;
     }
     s_sum[tid] = sum;
+    s_usum[tid] = usum;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
     if ((tid & 63) == 0) s_max[tid >> 6] = mx;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partial sums
+    // Hillis-Steele inclusive scans over the 1024 partial sums
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t t = (tid >= off) ? s_sum[tid - off] : 0u;
+        const uint32_t t = (tid >= off) ? s_sum[tid - off] : 0u;
+        const uint32_t u = (tid >= off) ? s_usum[tid - off] : 0u;
         __syncthreads();
         s_sum[tid] += t;
+        s_usum[tid] += u;
         __syncthreads();
     }
-    uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
+    const uint32_t total = s_sum[1023];
+    const bool overflow = (uint64_t)total > capacity;
+    uint32_t run = s_sum[tid] - sum, urun = s_usum[tid] - usum;  // exclusive prefixes of this thread's chunk
     for (uint32_t i = b; i < e; i++) {
+        const uint32_t c = v.tile_count[i];
         v.tile_offset[i] = run;
         v.tile_cursor[i] = run;
-        run += v.tile_count[i];
+        v.unit_offset[i] = urun;
+        const uint32_t nu = (c + kUnit - 1) / kUnit;
+        if (!overflow)
+            for (uint32_t k = 0; k < nu; k++)
+                if (urun + k < unit_cap) unit_tile[urun + k] = i;
+        run += c;
+        urun += nu;
     }
     if (tid == 1023) {
-        const uint32_t total = s_sum[1023];
         uint32_t m = 0;
         for (int i = 0; i < 16; i++) m = max(m, s_max[i]);
         v.tile_offset[T] = total;
+        v.unit_offset[T] = s_usum[1023];
         DeviceCounts* c = v.counts;
         c->num_instances = total;
         c->max_tile_list = m;
-        c->overflow = (uint64_t)total > capacity ? 1u : 0u;
+        c->overflow = overflow ? 1u : 0u;
+        c->num_units = overflow ? 0u : s_usum[1023];
+        c->capacity = (uint32_t)capacity;
         host_counts->num_rendered = c->num_rendered;
         host_counts->num_instances = total;
         host_counts->max_tile_list = m;
@@ -324,8 +342,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     const int P = prm.P, W = prm.W, H = prm.H;
     GeomView g = GeomView::make(geometry, (size_t)P);
     ImageView v = ImageView::make(image, W, H);
-    BinningView b = BinningView::make(binning, (size_t)cap);
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+    BinningView b = BinningView::make(binning, (size_t)cap, (size_t)T);
     const bool debug = prm.debug != 0;
     int rc;
 
@@ -353,7 +371,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     {
         StageScope sc(h, ST_SCAN, s);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, h->host_counts_dev);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, b.unit_tile, (uint32_t)b.unit_cap,
+                           h->host_counts_dev);
     }
     FR_HIP(hipGetLastError());
     FR_HIP(hipEventRecord(h->counts_ready, s));

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
 }
 
 int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          BinningView b, const float* dL_dpix, hipStream_t s, bool debug);
+                          void* binning, const float* dL_dpix, hipStream_t s, bool debug);
 
 int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
                     const void* image, const void* binning, const float* dL_dpix, const fr_grads& gr, hipStream_t s)
@@ -287,10 +287,9 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     if (P <= 0) return FR_OK;
     GeomView g = GeomView::make(geometry, (size_t)P);
     ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
-    BinningView b = BinningView::make(const_cast<void*>(binning), 0);
     const bool debug = prm.debug != 0;
     FR_HIP(hipMemsetAsync(g.accum, 0, sizeof(float) * (size_t)P * kAccumStride, s));
-    int rc = launch_blend_backward(h, prm, in, g, v, b, dL_dpix, s, debug);
+    int rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
     if (rc) return rc;
 
     PreBwdArgs a;

@@ -94,7 +94,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         while True:
-            binning = torch.empty((L.fr_binning_bytes(cap),), dtype=torch.uint8, **opts)
+            binning = torch.empty((L.fr_binning_bytes(cap, W, H),), dtype=torch.uint8, **opts)
             rc = L.fr_forward(h, C.byref(prm), C.byref(inp), out_color.data_ptr(), radii.data_ptr(), geom.data_ptr(),
                               img.data_ptr(), binning.data_ptr(), cap, C.byref(counts), stream)
             if rc == _lib.FR_ERR_BINNING_CAPACITY:

@@ -121,7 +121,7 @@ int fr_profile_read(fr_handle* h, int32_t stage, double* total_ms, uint32_t* lau
  * final transmittance / contributor count and per-tile ranges; binning: `capacity` instances. */
 size_t fr_geometry_bytes(int32_t P);
 size_t fr_image_bytes(int32_t W, int32_t H);
-size_t fr_binning_bytes(uint64_t capacity);
+size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H);
 
 /* out_color [3,H,W], radii [P] (reference semantics: ceil(3*sigma_max), 0 if culled).
  * Returns FR_OK, or FR_ERR_BINNING_CAPACITY with counts->num_instances = capacity required

@@ -55,7 +55,7 @@ def test_scratch_size_queries_are_sane_without_a_gpu():
     g1, g2 = L.fr_geometry_bytes(1000), L.fr_geometry_bytes(2000)
     assert 0 < g1 < g2 <= 2 * g1 + 4096
     assert L.fr_image_bytes(512, 512) > 512 * 512 * 8
-    assert L.fr_binning_bytes(1000) >= 1000 * 56
+    assert L.fr_binning_bytes(1000, 64, 64) >= 1000 * 56
     assert L.fr_knn_workspace_bytes(100000) > 100000 * 16
 
 

@@ -127,12 +127,12 @@ def test_binning_capacity_regrow(gpu_device):
     L = _lib.lib()
     # call the ABI directly with half the needed capacity
     cap = max(1, need // 2)
-    binning = torch.empty((L.fr_binning_bytes(cap),), dtype=torch.uint8, device=gpu_device)
+    c = s.camera
+    binning = torch.empty((L.fr_binning_bytes(cap, c.image_width, c.image_height),), dtype=torch.uint8, device=gpu_device)
     out = torch.empty_like(h1.color)
     radii = torch.empty_like(h1.radii)
     geom = torch.empty_like(h1.geom)
     img = torch.empty_like(h1.img)
-    c = s.camera
     prm = rasterizer._params(s.P, s.sh_degree, s.shs.shape[1], c.image_width, c.image_height, c.tanfovx, c.tanfovy,
                              1.0, False, False)
     inp = rasterizer._inputs(h1.bg, h1.means3D, h1.sh, None, h1.op, h1.scales, h1.rots, None, h1.view, h1.proj,
