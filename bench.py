@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     args = ap.parse_args()
 
     rank, world, local = dp.init_from_env()
@@ -90,19 +92,53 @@ def main():
     H = W = args.res
     target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
 
-    def step():
-        pc.flat.grad.zero_()
+    def frame():
+        pc.zero_grad_flat()
         out = render(cam, pc, bg)
         loss = (out["render"] - target).abs().mean()  # L1 (train/loss.py), the synthetic loop's loss
         loss.backward()
+
+    def eager_step():
+        frame()
         if world > 1:
-            dp.allreduce_mean_(pc.flat.grad)
-        return out
+            dp.allreduce_mean_(pc.flat_grad)
+
+    # eager warm-up: sizes the binning capacity (high-water mark) and fills the allocator pools
+    for _ in range(max(3, args.warmup // 2)):
+        eager_step()
+    torch.cuda.synchronize()
+    counts = rasterizer.last_counts[local]
+
+    graph = None
+    if args.graph:
+        # The per-frame work is launch-bound on the host (~40 small launches): capture ONE frame (activations,
+        # rasterizer forward, loss, backward) into a HIP graph and replay it.  The rasterizer runs in no-wait
+        # mode inside the graph (no host synchronisation at all); overflow of the binning capacity is checked
+        # after the timed region.
+        rasterizer.set_no_wait(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                frame()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            frame()
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            if world > 1:
+                dp.allreduce_mean_(pc.flat_grad)
+        else:
+            eager_step()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    _lib.profile_enable(local, True)
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -111,6 +147,16 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     elapsed = time.perf_counter() - t0
+    if graph is not None:
+        if rasterizer.check_async_overflow(local):
+            raise SystemExit("binning capacity overflowed inside the captured graph; rerun (capacity hint was raised)")
+        rasterizer.set_no_wait(False)
+    # per-kernel durations: HIP events around every stage launch, on the launch stream, over eager replays of
+    # the same frame right after the timed region (event records inside a replayed graph cannot be read back)
+    _lib.profile_enable(local, True)
+    for _ in range(min(args.steps, 50)):
+        eager_step()
+    torch.cuda.synchronize()
     prof = _lib.profile_read(local)
     _lib.profile_enable(local, False)
     counts = rasterizer.last_counts[local]
@@ -154,7 +200,8 @@ def main():
             "config": {"workload": f"BASELINE.json configs[1]: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
                                    "forward+backward through render() + L1 loss",
-                       "frames_per_step_per_gpu": 1, "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
+                       "frames_per_step_per_gpu": 1, "launch": "hipgraph replay" if args.graph else "eager",
+                       "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
                        "num_rendered": R, "tile_instances_8x8": int(counts.num_instances),
                        "max_tile_list": int(counts.max_tile_list)},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages,

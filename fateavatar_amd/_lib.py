@@ -10,13 +10,14 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfr_hip.so")
+SO_PATH = os.environ.get("FR_HIP_LIB", os.path.join(_HERE, "libfr_hip.so"))  # FR_HIP_LIB: experiments only
 
 FR_OK = 0
 FR_ERR_INVALID_ARGUMENT = 1
 FR_ERR_BINNING_CAPACITY = 2
 FR_ERR_HIP = 3
 FR_ERR_UNSUPPORTED = 4
+FR_FLAG_NO_WAIT = 1
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -24,7 +25,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 class fr_params(C.Structure):
     _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
-                ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("flags", C.c_int32)]
 
 
 class fr_inputs(C.Structure):
@@ -43,7 +44,7 @@ class fr_counts(C.Structure):
 
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
-           "fr_binning_bytes", "fr_forward", "fr_backward", "fr_mark_visible", "fr_image_final_T",
+           "fr_binning_bytes", "fr_forward", "fr_read_counts", "fr_backward", "fr_mark_visible", "fr_image_final_T",
            "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2"]
 
 
@@ -90,6 +91,8 @@ def lib():
     L.fr_forward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
                              C.c_uint64, C.POINTER(fr_counts), C.c_void_p]
     L.fr_forward.restype = C.c_int
+    L.fr_read_counts.argtypes = [C.c_void_p, C.POINTER(fr_counts)]
+    L.fr_read_counts.restype = C.c_int
     L.fr_backward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
                               C.POINTER(fr_grads), C.c_void_p]
     L.fr_backward.restype = C.c_int

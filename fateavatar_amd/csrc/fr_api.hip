@@ -128,6 +128,14 @@ int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* 
                           static_cast<hipStream_t>(stream));
 }
 
+int fr_read_counts(fr_handle* hh, fr_counts* counts)
+{
+    fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
+    if (!h || !counts) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument");
+    *counts = *h->host_counts;
+    return FR_OK;
+}
+
 int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,
                 const void* image, const void* binning, const float* dL_dpix, const fr_grads* grads, void* stream)
 {

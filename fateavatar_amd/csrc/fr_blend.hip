@@ -16,35 +16,84 @@ constexpr int kRecQuads = 3;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m)
+// ---- lane exchange by a compile-time xor mask without going through LDS addressing where the
+// hardware offers it: DPP (quad_perm, row mirrors, row rotate) inside 16-lane rows, ds_swizzle bit-mode
+// inside 32 lanes, v_permlane32_swap across the halves.
+template <int MASK>
+__device__ __forceinline__ int lane_xor_i32(int x, int lane)
 {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, m);
-    hi = __shfl_xor(hi, m);
+    if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) return __builtin_amdgcn_mov_dpp(x, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (MASK == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);              // row_shl:4 -> banks 0,2
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                     // row_shr:4 -> banks 1,3
+    } else if constexpr (MASK == 7) return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);   // row_ror:8
+    else if constexpr (MASK == 15) return __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true);  // row_mirror
+    else if constexpr (MASK == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);              // xor 16 within 32 lanes
+    else if constexpr (MASK == 31) return __builtin_amdgcn_ds_swizzle(x, 0x7C1F);              // xor 31 within 32 lanes
+    else if constexpr (MASK == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);   // r[0]=[lo,lo] r[1]=[hi,hi]
+        return (lane < 32) ? (int)r[1] : (int)r[0];
+    } else if constexpr (MASK == 63) return lane_xor_i32<32>(lane_xor_i32<31>(x, lane), lane);
+    else {
+        static_assert(MASK == 1, "unsupported xor mask");
+        return x;
+    }
+}
+template <int MASK>
+__device__ __forceinline__ u64 lane_xor_u64(u64 v, int lane)
+{
+    const uint32_t lo = (uint32_t)lane_xor_i32<MASK>((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)lane_xor_i32<MASK>((int)(uint32_t)(v >> 32), lane);
     return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
 // ---- bitonic network, "flip" formulation (every compare-exchange puts the smaller key at the
-// lower index), element index i = r*64 + lane.
-template <int K>
-__device__ __forceinline__ void lane_xor_stage(u64 (&v)[K], int lane, int mask, int low_bit)
+// lower index), element index i = r*64 + lane (+ 256*wave in the 4-wave variant).
+template <int K, int MASK, int LOWBIT>
+__device__ __forceinline__ void lane_stage(u64 (&v)[K], int lane)
 {
-    // partner = lane ^ mask in the same register; this lane is the lower index iff (lane & low_bit) == 0
-    const bool lower = (lane & low_bit) == 0;
+    // partner = lane ^ MASK in the same register; this lane is the lower index iff (lane & LOWBIT) == 0
+    const bool lower = (lane & LOWBIT) == 0;
 #pragma unroll
     for (int r = 0; r < K; r++) {
         const u64 a = v[r];
-        const u64 b = shfl_xor_u64(a, mask);
+        const u64 b = lane_xor_u64<MASK>(a, lane);
         v[r] = lower ? umin64(a, b) : umax64(a, b);
+    }
+}
+template <int K>
+__device__ __forceinline__ void lane_cleaners_from_32(u64 (&v)[K], int lane)
+{
+    lane_stage<K, 32, 32>(v, lane);
+    lane_stage<K, 16, 16>(v, lane);
+    lane_stage<K, 8, 8>(v, lane);
+    lane_stage<K, 4, 4>(v, lane);
+    lane_stage<K, 2, 2>(v, lane);
+    lane_stage<K, 1, 1>(v, lane);
+}
+template <int K, int JR>
+__device__ __forceinline__ void reg_cleaner(u64 (&v)[K])
+{
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const int rp = r ^ JR;
+        if (rp > r) {
+            const u64 a = v[r], b = v[rp];
+            v[r] = umin64(a, b);
+            v[rp] = umax64(a, b);
+        }
     }
 }
 
 template <int K, int KK>
 __device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
 {
-    // merge step for blocks of KK > 64 elements
+    // merge step for blocks of KK in {128, 256} elements held by one wave
     constexpr int m = (KK >> 6) - 1;
     // flip: partner index = i ^ (KK-1)  ->  register r ^ m, lane ^ 63
 #pragma unroll
@@ -52,40 +101,30 @@ __device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
         const int rp = r ^ m;
         if (rp > r) {
             const u64 a = v[r], b = v[rp];
-            const u64 sa = shfl_xor_u64(a, 63), sb = shfl_xor_u64(b, 63);
+            const u64 sa = lane_xor_u64<63>(a, lane), sb = lane_xor_u64<63>(b, lane);
             v[r] = umin64(a, sb);
             v[rp] = umax64(b, sa);
         }
     }
-    // half-cleaners with distance >= 64: pure register exchanges
-#pragma unroll
-    for (int j = KK >> 2; j >= 64; j >>= 1) {
-        const int jr = j >> 6;
-#pragma unroll
-        for (int r = 0; r < K; r++) {
-            const int rp = r ^ jr;
-            if (rp > r) {
-                const u64 a = v[r], b = v[rp];
-                v[r] = umin64(a, b);
-                v[rp] = umax64(a, b);
-            }
-        }
-    }
-    // half-cleaners with distance < 64
-    for (int j = (KK >> 2) < 32 ? (KK >> 2) : 32; j > 0; j >>= 1) lane_xor_stage<K>(v, lane, j, j);
+    if constexpr (KK >= 256) reg_cleaner<K, 1>(v);  // distance 64
+    lane_cleaners_from_32<K>(v, lane);
 }
 
+// one wave sorts 64*K keys (K <= 4)
 template <int K>
 __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
 {
-    for (int k = 2; k <= 64; k <<= 1) {
-        lane_xor_stage<K>(v, lane, k - 1, k >> 1);  // flip inside blocks of k lanes
-        for (int j = k >> 2; j > 0; j >>= 1) lane_xor_stage<K>(v, lane, j, j);
-    }
+    lane_stage<K, 1, 1>(v, lane);                                   // k = 2
+    lane_stage<K, 3, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);    // k = 4
+    lane_stage<K, 7, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);  // k = 8
+    lane_stage<K, 15, 8>(v, lane); lane_stage<K, 4, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);
+    lane_stage<K, 1, 1>(v, lane);                                   // k = 16
+    lane_stage<K, 31, 16>(v, lane); lane_stage<K, 8, 8>(v, lane); lane_stage<K, 4, 4>(v, lane);
+    lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);    // k = 32
+    lane_stage<K, 63, 32>(v, lane); lane_stage<K, 16, 16>(v, lane); lane_stage<K, 8, 8>(v, lane);
+    lane_stage<K, 4, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);  // k = 64
     if constexpr (K >= 2) big_stage<K, 128>(v, lane);
     if constexpr (K >= 4) big_stage<K, 256>(v, lane);
-    if constexpr (K >= 8) big_stage<K, 512>(v, lane);
-    if constexpr (K >= 16) big_stage<K, 1024>(v, lane);
 }
 
 __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g)
@@ -113,6 +152,52 @@ __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, ui
 #pragma unroll
     for (int r = 0; r < K; r++) {
         const uint32_t i = (uint32_t)(r * 64 + lane);
+        if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
+    }
+}
+
+// Four waves sort up to 1024 keys together: each wave sorts its 256 keys in registers, then the two
+// remaining merge levels exchange registers with the partner wave through LDS (3 exchanges in total).
+typedef u64 SortXchg[4][4][64];
+
+template <bool FLIP>
+__device__ __forceinline__ void cross_wave_stage(u64 (&v)[4], SortXchg& sx, int wave, int lane, int pw, bool lower)
+{
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) sx[wave][r][lane] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 b = FLIP ? sx[pw][r ^ 3][lane ^ 63] : sx[pw][r][lane];
+        v[r] = lower ? umin64(v[r], b) : umax64(v[r], b);
+    }
+}
+
+__device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
+                                const GeomView& g, SortXchg& sx)
+{
+    u64 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t i = (uint32_t)(wave * 256 + r * 64 + lane);
+        v[r] = i < n ? keys[start + i] : ~0ull;
+    }
+    wave_sort<4>(v, lane);
+    // k = 512: flip with wave ^ 1, then distances 128, 64, 32..1 inside the wave
+    cross_wave_stage<true>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
+    reg_cleaner<4, 2>(v);
+    reg_cleaner<4, 1>(v);
+    lane_cleaners_from_32<4>(v, lane);
+    // k = 1024: flip with wave ^ 3, distance 256 with wave ^ 1, then 128, 64, 32..1
+    cross_wave_stage<true>(v, sx, wave, lane, wave ^ 3, (wave & 2) == 0);
+    cross_wave_stage<false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
+    reg_cleaner<4, 2>(v);
+    reg_cleaner<4, 1>(v);
+    lane_cleaners_from_32<4>(v, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t i = (uint32_t)(wave * 256 + r * 64 + lane);
         if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
     }
 }
@@ -151,37 +236,46 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
     }
 }
 
-// Grid: ceil(T/4) "small" workgroups (4 waves = 4 tiles each) followed by kLargeSorters
-// workgroups that drain the queue of over-long tiles.
+// Grid: Q = ceil(T/4) workgroups of 4 waves, followed by kLargeSorters workgroups that drain the queue of
+// lists longer than kSortRegMax.  Workgroup b owns tiles {b, b+Q, b+2Q, b+3Q} (strided, so that the dense
+// neighbouring tiles of one image region land in different workgroups): every wave first sorts its own
+// tile if the list fits one wave (<= 256), then the four waves sort the longer lists (<= 1024) together.
 constexpr int kLargeSorters = 8;
 
-__global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t small_blocks, u64* keys,
-                                                   float4* recs, GeomView g)
+__global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
+                                                   GeomView g)
 {
+    __shared__ SortXchg sx;
     if (v.counts->overflow) return;
-    if (blockIdx.x >= small_blocks) {
-        __shared__ uint32_t s_item;
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_item = atomicAdd(&v.counts->large_cursor, 1u);
-            __syncthreads();
-            const uint32_t item = s_item;
-            if (item >= v.counts->large_tiles) return;
+    if (blockIdx.x >= Q) {
+        // static round-robin over the queue (no work-stealing counter: same-address atomics serialise)
+        const uint32_t nl = v.counts->large_tiles;
+        for (uint32_t item = blockIdx.x - Q; item < nl; item += kLargeSorters) {
             const uint32_t tile = v.large_list[item];
-            sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_count[tile], g);
+            sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g);
         }
+        return;
     }
     const int lane = threadIdx.x & 63;
-    const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (tile >= T) return;
-    const uint32_t n = v.tile_count[tile];
-    if (n == 0 || n > (uint32_t)kSortRegMax) return;
-    const uint32_t start = v.tile_offset[tile];
-    if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
-    else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
-    else if (n <= 256) sort_tile_regs<4>(keys, recs, start, n, lane, g);
-    else if (n <= 512) sort_tile_regs<8>(keys, recs, start, n, lane, g);
-    else sort_tile_regs<16>(keys, recs, start, n, lane, g);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const uint32_t tile = (uint32_t)wave * Q + blockIdx.x;
+        if (tile < T) {
+            const uint32_t start = v.tile_offset[tile];
+            const uint32_t n = v.tile_offset[tile + 1] - start;
+            if (n > 0 && n <= (uint32_t)kSortWaveMax) {
+                if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
+                else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
+                else sort_tile_regs<4>(keys, recs, start, n, lane, g);
+            }
+        }
+    }
+    // medium lists (<= 1024): pulled from a queue so that they spread over all workgroups
+    const uint32_t nm = v.counts->medium_tiles;
+    for (uint32_t item = blockIdx.x; item < nm; item += Q) {
+        const uint32_t tile = v.medium_list[item];
+        sort_tile_group(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
+    }
 }
 
 // ------------------------------------------------------------------ LDS staging of a tile's list
@@ -593,7 +687,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     {
         StageScope sc(h, ST_SORT, s);
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters), dim3(256), 0, s, v, T, small_blocks,
-                           (u64*)b.keys, b.recs, g);
+                           (u64*)b.keys, b.recs, g);  // small_blocks == Q
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;

@@ -13,7 +13,10 @@ constexpr int kWave = 64;
 constexpr int kTile = 8;    // 8x8 pixels = one wavefront
 constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): radii / num_rendered semantics
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
-constexpr int kSortRegMax = 1024; // longest tile list the in-register wave sort handles
+constexpr int kCounterStride = 16; // u32 words between the atomic counters of neighbouring tiles: one 64-B line each
+                                   // (device-scope atomics serialise per cache line, ~11 ns apiece)
+constexpr int kSortRegMax = 1024;
+constexpr int kSortWaveMax = 256;  // longest list one wave sorts alone // longest tile list the in-register wave sort handles
 
 // accumulator slots (blend backward -> preprocess backward)
 enum { ACC_MX = 0, ACC_MY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8 };
@@ -49,6 +52,7 @@ struct GeomView {
     uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
+    uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
     static GeomView make(void* buf, size_t P)
     {
         char* p = static_cast<char*>(buf);
@@ -61,13 +65,14 @@ struct GeomView {
         g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
         g.accum = carve<float>(p, P * kAccumStride);
+        g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
         return g;
     }
     static size_t bytes(size_t P)
     {
         char* p = nullptr;
         GeomView g = make(p, P);
-        return reinterpret_cast<size_t>(g.accum + P * kAccumStride) + 256;
+        return reinterpret_cast<size_t>(g.block_ref_tiles + (P + 255) / 256 + 1) + 256;
     }
 };
 
@@ -78,16 +83,20 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
     uint32_t large_cursor;   // work-queue head for the large-tile sorter
+    uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
+    uint32_t medium_cursor;  // work-queue head for those
+    uint32_t pad2[6];
     uint32_t num_units;      // total number of blend units (64-record segments of tile lists)
     uint32_t capacity;       // binning capacity of this frame (the backward re-derives the binning layout from it)
 };
 
 struct ImageView {
     DeviceCounts* counts;
-    uint32_t* tile_count;    // [T]   instances per 8x8 tile
+    uint32_t* tile_count;    // [T*kCounterStride] instances per 8x8 tile (one counter per 64-B line)
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
-    uint32_t* tile_cursor;   // [T]   emit cursors (start at tile_offset)
+    uint32_t* tile_cursor;   // [T*kCounterStride] emit cursors (start at tile_offset), one per 64-B line
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
+    uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortRegMax (sorted by 4 waves)
     uint32_t* unit_offset;   // [T+1] exclusive scan of ceil(tile_count / 64): first blend unit of each tile
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
@@ -100,10 +109,11 @@ struct ImageView {
         v.tiles_y = (H + kTile - 1) / kTile;
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
-        v.tile_count = carve<uint32_t>(p, T);
+        v.tile_count = carve<uint32_t>(p, T * kCounterStride);
         v.tile_offset = carve<uint32_t>(p, T + 1);
-        v.tile_cursor = carve<uint32_t>(p, T);
+        v.tile_cursor = carve<uint32_t>(p, T * kCounterStride);
         v.large_list = carve<uint32_t>(p, T);
+        v.medium_list = carve<uint32_t>(p, T);
         v.unit_offset = carve<uint32_t>(p, T + 1);
         v.final_T = carve<float>(p, (size_t)W * H);
         v.n_contrib = carve<uint32_t>(p, (size_t)W * H);
@@ -118,7 +128,7 @@ struct ImageView {
     size_t zero_bytes(const void* base) const
     {
         size_t T = (size_t)tiles_x * tiles_y;
-        return reinterpret_cast<const char*>(tile_count + T) - static_cast<const char*>(base);
+        return reinterpret_cast<const char*>(tile_count + T * kCounterStride) - static_cast<const char*>(base);
     }
 };
 

@@ -65,9 +65,47 @@ __device__ __forceinline__ float sh_channel(const float* sh, int c, int deg, flo
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // One thread per Gaussian.  reference: preprocessCUDA, forward.cu:155-256.
+// Coalesced staging of one wave's SH block ([64 Gaussians][M*3] contiguous floats) into LDS with an odd
+// row stride (conflict-free per-lane reads).  A per-thread walk over its own 4*M*3-byte row would touch 64
+// different cache lines per load instruction and refetch every line ~M*3/16 times.
+__device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const float* __restrict__ src, int rows,
+                                                int row_len, int lane)
+{
+    const int total = rows * row_len;
+    for (int c = lane * 4; c < total; c += 64 * 4) {
+        float v[4];
+        if (c + 3 < total) {
+            const float4 q = *reinterpret_cast<const float4*>(src + c);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (int k = 0; k < 4; k++) v[k] = (c + k < total) ? src[c + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = c + k;
+            if (e < total) {
+                const int r = e / row_len;
+                dst[r * stride + (e - r * row_len)] = v[k];
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M3 = a.M * 3, sh_stride = M3 | 1;
+    const float* my_sh = nullptr;
+    if (a.shs && !a.colors_precomp) {
+        float* w_sh = s_sh + (size_t)wave * 64 * sh_stride;
+        const int wave_first = blockIdx.x * 256 + wave * 64;
+        if (wave_first < a.P)
+            stage_wave_rows(w_sh, sh_stride, a.shs + (size_t)wave_first * M3, min(64, a.P - wave_first), M3, lane);
+        my_sh = w_sh + lane * sh_stride;
+    }
+    __syncthreads();
     uint32_t ref_tiles = 0;  // tiles_touched in reference semantics (16x16)
     if (idx < a.P) {
         int radius_out = 0;
@@ -165,7 +203,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 float dx = p_orig.x - a.campos[0], dy = p_orig.y - a.campos[1], dz = p_orig.z - a.campos[2];
                 const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                 dx = dx / len, dy = dy / len, dz = dz / len;
-                const float* sh = a.shs + (size_t)idx * a.M * 3;
+                const float* sh = my_sh;
                 for (int c = 0; c < 3; c++) {
                     const float v = sh_channel(sh, c, a.D, dx, dy, dz);
                     if (v < 0) clamp_bits |= (uint8_t)(1u << c);
@@ -208,23 +246,32 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             const int tx0 = px0 / kTile, tx1 = px1 / kTile + 1, ty0 = py0 / kTile, ty1 = py1 / kTile + 1;
             rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
             for (int ty = ty0; ty < ty1; ty++)
-                for (int tx = tx0; tx < tx1; tx++) atomicAdd(&a.tile_count[ty * a.tiles_x + tx], 1u);
+                for (int tx = tx0; tx < tx1; tx++) atomicAdd(&a.tile_count[(size_t)(ty * a.tiles_x + tx) * kCounterStride], 1u);
         } while (false);
         a.radii[idx] = radius_out;
         a.g.rect[idx] = rect;
     }
-    // num_rendered in reference semantics: one atomic per wave
+    // num_rendered in reference semantics: per-workgroup partial sums, added up by the scan kernel (a single
+    // counter would serialise one device-scope atomic per wave, ~11 ns each)
+    __shared__ uint32_t s_ref[4];
     uint32_t s = ref_tiles;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&a.counts->num_rendered, s);
+    if (lane == 0) s_ref[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.g.block_ref_tiles[blockIdx.x] = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3];
 }
 
 // Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
 // (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
 // the unit -> tile table and builds the list of tiles too long for the in-register sort.
 __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, uint32_t* unit_tile,
-                                                     uint32_t unit_cap, fr_counts* host_counts)
+                                                     uint32_t unit_cap, const uint32_t* block_ref_tiles,
+                                                     uint32_t n_blocks, fr_counts* host_counts)
 {
+    __shared__ uint32_t s_ref[16];
+    __shared__ uint32_t s_heads[2];
+    if (threadIdx.x < 2) s_heads[threadIdx.x] = 0;
+    __syncthreads();
     __shared__ uint32_t s_sum[1024];
     __shared__ uint32_t s_usum[1024];
     __shared__ uint32_t s_max[16];
@@ -233,12 +280,18 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     const uint32_t b = min(T, tid * per), e = min(T, b + per);
     uint32_t sum = 0, usum = 0, mx = 0;
     for (uint32_t i = b; i < e; i++) {
-        const uint32_t c = v.tile_count[i];
+        const uint32_t c = v.tile_count[(size_t)i * kCounterStride];
         sum += c;
         usum += (c + kUnit - 1) / kUnit;
         mx = max(mx, c);
-        if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&v.counts->large_tiles, 1u)] = i;
+        // single workgroup: the list heads live in LDS (a global same-address atomic costs ~11 ns apiece)
+        if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&s_heads[0], 1u)] = i;
+        else if (c > (uint32_t)kSortWaveMax) v.medium_list[atomicAdd(&s_heads[1], 1u)] = i;
     }
+    uint32_t ref = 0;
+    for (uint32_t i = tid; i < n_blocks; i += 1024) ref += block_ref_tiles[i];
+    for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
+    if ((tid & 63) == 0) s_ref[tid >> 6] = ref;
     s_sum[tid] = sum;
     s_usum[tid] = usum;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
@@ -257,9 +310,9 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     const bool overflow = (uint64_t)total > capacity;
     uint32_t run = s_sum[tid] - sum, urun = s_usum[tid] - usum;  // exclusive prefixes of this thread's chunk
     for (uint32_t i = b; i < e; i++) {
-        const uint32_t c = v.tile_count[i];
+        const uint32_t c = v.tile_count[(size_t)i * kCounterStride];
         v.tile_offset[i] = run;
-        v.tile_cursor[i] = run;
+        v.tile_cursor[(size_t)i * kCounterStride] = run;
         v.unit_offset[i] = urun;
         const uint32_t nu = (c + kUnit - 1) / kUnit;
         if (!overflow)
@@ -274,6 +327,11 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         v.tile_offset[T] = total;
         v.unit_offset[T] = s_usum[1023];
         DeviceCounts* c = v.counts;
+        uint32_t nr = 0;
+        for (int i = 0; i < 16; i++) nr += s_ref[i];
+        c->num_rendered = nr;
+        c->large_tiles = s_heads[0];
+        c->medium_tiles = s_heads[1];
         c->num_instances = total;
         c->max_tile_list = m;
         c->overflow = overflow ? 1u : 0u;
@@ -287,23 +345,56 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     }
 }
 
-// One thread per Gaussian: write (depth | id) keys into the per-tile segments.
-// reference counterpart: duplicateWithKeys, rasterizer_impl.cu:70-111 (the tile id is implicit
-// in the segment here, and the order inside a segment is fixed later by the per-tile sort).
+// Write (depth | id) keys into the per-tile segments.  reference counterpart: duplicateWithKeys,
+// rasterizer_impl.cu:70-111 (the tile id is implicit in the segment here, and the order inside a segment
+// is fixed later by the per-tile sort).  A thread looping over its own rectangle would serialise one
+// returning atomic (~1 us round trip) per tile; instead each wave spreads the instances of its 64
+// Gaussians over its lanes (prefix sum + binary search), so a wave needs ceil(instances / 64) round trips.
 __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, ImageView v, uint64_t* keys)
 {
+    __shared__ uint32_t s_excl[4][64];
+    __shared__ uint2 s_rect[4][64];
+    __shared__ uint64_t s_key[4][64];
     if (v.counts->overflow) return;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const uint2 r = g.rect[idx];
-    const int tx0 = r.x & 0xffff, ty0 = r.x >> 16, tx1 = r.y & 0xffff, ty1 = r.y >> 16;
-    if (tx1 <= tx0 || ty1 <= ty0) return;
-    const uint64_t key = ((uint64_t)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
-    for (int ty = ty0; ty < ty1; ty++)
-        for (int tx = tx0; tx < tx1; tx++) {
-            const uint32_t slot = atomicAdd(&v.tile_cursor[ty * v.tiles_x + tx], 1u);
-            keys[slot] = key;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 r = make_uint2(0u, 0u);
+    uint32_t n = 0;
+    uint64_t key = 0;
+    if (idx < P) {
+        r = g.rect[idx];
+        const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
+        if (w > 0 && h > 0) {
+            n = (uint32_t)(w * h);
+            key = ((uint64_t)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
         }
+    }
+    // inclusive scan over the wave
+    uint32_t incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    s_excl[wave][lane] = incl - n;
+    s_rect[wave][lane] = r;
+    s_key[wave][lane] = key;
+    __syncthreads();
+    for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
+        // owner = last lane whose exclusive prefix is <= k (zero-count lanes share a prefix with their successor,
+        // searching for the LAST such lane with a non-zero count: the first lane whose inclusive prefix exceeds k)
+        int lo = 0, hi = 63;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        const uint2 rr = s_rect[wave][lo];
+        const uint32_t j = k - s_excl[wave][lo];
+        const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, w = (rr.y & 0xffff) - x0;
+        const uint32_t ty = y0 + j / w, tx = x0 + (j - (j / w) * w);
+        const uint32_t slot = atomicAdd(&v.tile_cursor[(size_t)(ty * (uint32_t)v.tiles_x + tx) * kCounterStride], 1u);
+        keys[slot] = s_key[wave][lo];
+    }
 }
 
 // reference: checkFrustum, rasterizer_impl.cu:54-66
@@ -364,7 +455,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     if (P > 0) {
         {
             StageScope sc(h, ST_PREPROCESS_FWD, s);
-            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+            const size_t lds = (in.shs && !in.colors_precomp) ? (size_t)4 * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), lds, s, a);
         }
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
@@ -372,10 +464,11 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     {
         StageScope sc(h, ST_SCAN, s);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, b.unit_tile, (uint32_t)b.unit_cap,
-                           h->host_counts_dev);
+                           g.block_ref_tiles, (uint32_t)((P + 255) / 256), h->host_counts_dev);
     }
     FR_HIP(hipGetLastError());
-    FR_HIP(hipEventRecord(h->counts_ready, s));
+    const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
+    if (!no_wait) FR_HIP(hipEventRecord(h->counts_ready, s));
     if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
     if (P > 0) {
         {
@@ -387,6 +480,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
 
+    if (no_wait) return FR_OK;
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).
     FR_HIP(hipEventSynchronize(h->counts_ready));
     fr_counts c = *h->host_counts;

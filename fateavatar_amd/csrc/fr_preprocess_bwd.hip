@@ -38,20 +38,22 @@ __device__ __forceinline__ void store3(float* p, size_t i, float a, float b, flo
     if (p) p[3 * i] = a, p[3 * i + 1] = b, p[3 * i + 2] = c;
 }
 
-__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
+// Everything for ONE Gaussian.  `row` (LDS, may be null) holds this Gaussian's SH coefficients on entry and
+// receives its dL_dsh row in place (the kernel stages both through LDS for coalesced HBM access).
+__device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const int idx, float* row)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P) return;
     const size_t i = (size_t)idx;
     const int Mc = a.M;
     if (!(a.radii[idx] > 0)) {
+        if (row)
+            for (int k = 0; k < Mc * 3; k++) row[k] = 0.f;
         store3(a.out.dL_dmeans2D, i, 0.f, 0.f, 0.f);
         store3(a.out.dL_dcolors, i, 0.f, 0.f, 0.f);
         if (a.out.dL_dopacity) a.out.dL_dopacity[i] = 0.f;
         store3(a.out.dL_dmeans3D, i, 0.f, 0.f, 0.f);
         if (a.out.dL_dcov3D)
             for (int k = 0; k < 6; k++) a.out.dL_dcov3D[6 * i + k] = 0.f;
-        if (a.out.dL_dsh)
+        if (a.out.dL_dsh && !row)
             for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
         store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f);
         if (a.out.dL_drotations)
@@ -157,20 +159,25 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
         const float dox = mean.x - a.campos[0], doy = mean.y - a.campos[1], doz = mean.z - a.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        const float* sh = a.shs + i * Mc * 3;
-        float* dsh = a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr;
+        // `row` is read (SH) and overwritten (dL_dsh) in place: each channel pass loads its coefficients into
+        // registers before it writes anything
+        const float* sh_src = row ? row : a.shs + i * Mc * 3;
+        float* dsh = row ? row : (a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr);
         const uint8_t cl = a.g.clamped[idx];
         float dRGB[3];
         for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1) ? 0 : 1);
         float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
         const int deg = a.D;
         const int used = (deg + 1) * (deg + 1);
-#define SH(k, c) sh[(k) * 3 + (c)]
+#define SH(k, c) shc[(k)]
 #define DSH(k, c, v_)                    \
     do {                                 \
         if (dsh) dsh[(k) * 3 + (c)] = (v_); \
     } while (0)
         for (int c = 0; c < 3; c++) {
+            float shc[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) shc[k] = (k < used) ? sh_src[k * 3 + c] : 0.f;
             DSH(0, c, bSH_C0 * dRGB[c]);
             if (deg > 0) {
                 DSH(1, c, (-bSH_C1 * y) * dRGB[c]);
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
         dmx += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
         dmy += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
         dmz += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
-    } else if (a.out.dL_dsh) {
+    } else if (a.out.dL_dsh && !row) {
         for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
     }
     store3(a.out.dL_dmeans3D, i, dmx, dmy, dmz);
@@ -277,6 +284,63 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
     }
 }
 
+// Coalesced LDS staging of a wave's [64][row_len] block (see fr_preprocess.hip) and its inverse.
+__device__ __forceinline__ void stage_rows(float* dst, int stride, const float* __restrict__ src, int rows, int row_len, int lane)
+{
+    const int total = rows * row_len;
+    for (int c = lane * 4; c < total; c += 64 * 4) {
+        float v[4];
+        if (c + 3 < total) {
+            const float4 q = *reinterpret_cast<const float4*>(src + c);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (int k = 0; k < 4; k++) v[k] = (c + k < total) ? src[c + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = c + k;
+            if (e < total) {
+                const int r = e / row_len;
+                dst[r * stride + (e - r * row_len)] = v[k];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane)
+{
+    const int total = rows * row_len;
+    for (int c = lane * 4; c < total; c += 64 * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = c + k;
+            const int r = e / row_len;
+            v[k] = (e < total) ? src[r * stride + (e - r * row_len)] : 0.f;
+        }
+        if (c + 3 < total) *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int k = 0; k < 4; k++)
+                if (c + k < total) dst[c + k] = v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M3 = a.M * 3, stride = M3 | 1;
+    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int rows = min(64, a.P - wave_first);
+    const bool staged = a.shs != nullptr && a.out.dL_dsh != nullptr;
+    float* w_rows = s_rows + (size_t)wave * 64 * stride;
+    if (staged && rows > 0) stage_rows(w_rows, stride, a.shs + (size_t)wave_first * M3, rows, M3, lane);
+    __syncthreads();
+    if (idx < a.P) preprocess_bwd_one(a, idx, staged ? w_rows + lane * stride : nullptr);
+    __syncthreads();
+    if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane);
+}
+
 int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
                           void* binning, const float* dL_dpix, hipStream_t s, bool debug);
 
@@ -303,7 +367,8 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     a.radii = radii, a.g = g, a.out = gr;
     {
         StageScope sc(h, ST_PREPROCESS_BWD, s);
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, a);
+        const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)4 * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), lds, s, a);
     }
     FR_HIP(hipGetLastError());
     if (debug) FR_HIP(hipStreamSynchronize(s));

@@ -23,23 +23,24 @@ class FlatGaussians(torch.nn.Module):
         self.max_sh_degree = sh_degree
         self.P, self.M = P, M
         sizes = [P * 3, P * M * 3, P, P * 3, P * 4]
-        self.flat = torch.nn.Parameter(torch.empty(sum(sizes), dtype=torch.float32, device=device))
-        self.flat.grad = torch.zeros_like(self.flat)
+        shapes = [(P, 3), (P, M, 3), (P, 1), (P, 3), (P, 4)]
+        # one flat value buffer and one flat gradient buffer; every parameter (and its .grad) is a VIEW into
+        # them, so autograd accumulates in place and the data-parallel exchange is a single all-reduce
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros_like(self.flat)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
         op = t(opacities).reshape(-1).clamp(1e-6, 1 - 1e-6)
         raw = [t(means3D), t(shs), torch.log(op / (1 - op)), torch.log(t(scales)), t(rotations)]
-        self._views, self._gviews = {}, {}
         off = 0
-        shapes = [(P, 3), (P, M, 3), (P, 1), (P, 3), (P, 4)]
-        with torch.no_grad():
-            for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
-                self.flat.data[off:off + n].copy_(r.reshape(-1))
-                self._views[name] = (off, n, shp)
-                off += n
+        for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
+            self.flat[off:off + n].copy_(r.reshape(-1))
+            p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
+            p.grad = self.flat_grad[off:off + n].view(shp)
+            setattr(self, name, p)
+            off += n
 
     def _p(self, name):
-        off, n, shp = self._views[name]
-        return self.flat[off:off + n].view(shp)
+        return getattr(self, name)
 
     # ---- the reference getters
     @property
@@ -63,8 +64,10 @@ class FlatGaussians(torch.nn.Module):
         return torch.nn.functional.normalize(self._p("_rotation"))
 
     def grad_of(self, name):
-        off, n, shp = self._views[name]
-        return self.flat.grad[off:off + n].view(shp)
+        return getattr(self, name).grad
+
+    def zero_grad_flat(self):
+        self.flat_grad.zero_()
 
 
 class TorchCamera:

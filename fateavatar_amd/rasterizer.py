@@ -49,9 +49,38 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
 
 
+# When True, forwards never wait for their instance counts (graph-capturable, zero host syncs): the binning
+# capacity is the current high-water mark and overflow is only detected by `check_async_overflow()`.
+_no_wait = False
+
+
+def set_no_wait(on: bool) -> None:
+    """Capture mode: make rasterize_gaussians free of host synchronisation (see FR_FLAG_NO_WAIT)."""
+    global _no_wait
+    _no_wait = bool(on)
+
+
+def read_counts(device_index: int = 0):
+    """fr_counts of the most recent frame on this device (synchronise first)."""
+    c = _lib.fr_counts()
+    _check(_lib.lib().fr_read_counts(_lib.handle(device_index), C.byref(c)), "fr_read_counts")
+    return c
+
+
+def check_async_overflow(device_index: int = 0) -> bool:
+    """After synchronising: True if the last no-wait frame overflowed its binning capacity (its outputs are
+    then invalid); the capacity hint is raised so that the next frame fits."""
+    c = read_counts(device_index)
+    last_counts[device_index] = c
+    if c.overflow:
+        _capacity_hint[device_index] = int(c.num_instances * 1.25) + 1024
+    return bool(c.overflow)
+
+
 def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug) -> _lib.fr_params:
     return _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
-                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)))
+                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
+                          _lib.FR_FLAG_NO_WAIT if _no_wait else 0)
 
 
 def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
@@ -102,6 +131,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 continue
             _check(rc, "fr_forward")
             break
+    if _no_wait:  # counts arrive later (read_counts / check_async_overflow)
+        return 0, out_color, radii, geom, binning, img
     _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(counts.num_instances * 1.25) + 1024)
     last_counts[dev] = counts
     return int(counts.num_rendered), out_color, radii, geom, binning, img

@@ -64,7 +64,13 @@ typedef struct fr_params {
     float scale_modifier;
     int32_t prefiltered;  /* accepted for interface parity; the near-plane cull is always applied */
     int32_t debug;        /* !=0: synchronise and check after every stage (auxiliary.h:166-173) */
+    int32_t flags;        /* FR_FLAG_* */
 } fr_params;
+
+/* fr_forward does not wait for the frame counts: nothing in the call blocks or touches an event, so it can
+ * be captured into a hipGraph.  `counts` is not filled; after the stream has been synchronised read them with
+ * fr_read_counts.  If counts.overflow is set the frame's outputs are invalid: rerun with a larger capacity. */
+#define FR_FLAG_NO_WAIT 1
 
 /* Device pointers.  NULL = the "empty tensor" of the reference glue
  * (rasterize_points.cu:94-103 passes data_ptr() of empty tensors; kernels branch on nullptr). */
@@ -129,6 +135,9 @@ size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H);
 int fr_forward(fr_handle* h, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
                void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts,
                void* hip_stream);
+
+/* Counts of the most recent frame enqueued through this handle (valid once its stream has been synchronised). */
+int fr_read_counts(fr_handle* h, fr_counts* counts);
 
 /* geometry/image/binning: the buffers a successful fr_forward of the same frame filled.
  * dL_dpix [3,H,W]. */

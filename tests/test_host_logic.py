@@ -76,8 +76,11 @@ def test_flat_gaussians_getters_reproduce_activated_values():
     assert pc.get_features.shape == (50, 4, 3)
     # gradients of every field land in ONE flat buffer
     (pc.get_opacity.sum() + pc.get_scaling.sum() + pc.get_xyz.sum()).backward()
-    assert pc.flat.grad.shape == pc.flat.shape and pc.flat.grad.abs().sum() > 0
+    assert pc.flat_grad.shape == pc.flat.shape and pc.flat_grad.abs().sum() > 0
     assert torch.equal(pc.grad_of("_xyz"), torch.ones(50, 3))
+    assert pc.grad_of("_xyz").data_ptr() == pc.flat_grad.data_ptr()  # views, not copies
+    pc.zero_grad_flat()
+    assert pc.grad_of("_scaling").abs().sum() == 0
 
 
 def test_head_scene_and_view_orbit():
