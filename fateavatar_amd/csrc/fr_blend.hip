@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
 // wave-uniform addresses (LDS broadcast), four at a time so that the four exp/alpha evaluations
 // are independent instruction streams and only the short T / colour recurrence is serial.
 constexpr int kBatch = 64;
-constexpr uint32_t kUnitGrid = 8192;  // workgroups of the unit kernels (grid-stride over the device-side unit count)
+constexpr uint32_t kUnitGrid = 2048;  // workgroups (of 4 waves) of the unit kernels: grid-stride over the unit count
 constexpr int kGroup = 4;
 
 struct RecRegs {
@@ -353,18 +353,27 @@ __device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint32_t* __rest
     return i;
 }
 
+// The unit kernels run 4 independent waves per workgroup (workgroup dispatch rate, not work, bounded the
+// one-wave-per-workgroup version) and stride over the units by the number of waves in the grid.
+constexpr int kWavesPerWG = 4;
+#define FR_UNIT_LOOP_BEGIN                                                                       \
+    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];                                \
+    const int lane = threadIdx.x & 63;                                                           \
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                     \
+    float4* s_rec = s_rec_all[wave_in_wg];                                                       \
+    const uint32_t nu = counts->num_units;                                                       \
+    const uint32_t wave_stride = gridDim.x * kWavesPerWG;                                        \
+    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
+
 // ---- pass A
-__global__ void __launch_bounds__(64) k_unit_tseg(const DeviceCounts* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_unit_tseg(const DeviceCounts* __restrict__ counts,
                                                   const uint32_t* __restrict__ unit_tile,
                                                   const uint32_t* __restrict__ unit_offset,
                                                   const uint32_t* __restrict__ tile_offset,
                                                   const float4* __restrict__ recs, int W, int H, int tiles_x,
                                                   float* __restrict__ unit_tseg)
 {
-    __shared__ float4 s_rec[kBatch * kRecQuads];
-    const int lane = threadIdx.x;
-    const uint32_t nu = counts->num_units;
-    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    FR_UNIT_LOOP_BEGIN
     const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
     if (ui.base + kUnit >= ui.n) continue;  // the last unit's product is never needed
     stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
@@ -387,17 +396,14 @@ __global__ void __launch_bounds__(64) k_unit_tseg(const DeviceCounts* __restrict
 }
 
 // ---- pass B (reference: renderCUDA, forward.cu:261-374, restricted to one unit)
-__global__ void __launch_bounds__(64) k_unit_blend(const DeviceCounts* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restrict__ counts,
                                                    const uint32_t* __restrict__ unit_tile,
                                                    const uint32_t* __restrict__ unit_offset,
                                                    const uint32_t* __restrict__ tile_offset,
                                                    const float4* __restrict__ recs, int W, int H, int tiles_x,
                                                    const float* __restrict__ unit_tseg, float* __restrict__ unit_out)
 {
-    __shared__ float4 s_rec[kBatch * kRecQuads];
-    const int lane = threadIdx.x;
-    const uint32_t nu = counts->num_units;
-    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    FR_UNIT_LOOP_BEGIN
     const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
     stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
     const float fx = (float)ui.px, fy = (float)ui.py;
@@ -450,15 +456,17 @@ __global__ void __launch_bounds__(64) k_unit_blend(const DeviceCounts* __restric
 }
 
 // ---- pass C: one wave per tile
-__global__ void __launch_bounds__(64) k_tile_combine(const DeviceCounts* __restrict__ counts,
-                                                     const uint32_t* __restrict__ unit_offset, int W, int H, int tiles_x,
-                                                     const float* __restrict__ bg, const float* __restrict__ unit_out,
+__global__ void __launch_bounds__(256) k_tile_combine(const DeviceCounts* __restrict__ counts,
+                                                     const uint32_t* __restrict__ unit_offset, uint32_t n_tiles, int W,
+                                                     int H, int tiles_x, const float* __restrict__ bg,
+                                                     const float* __restrict__ unit_out,
                                                      float4* __restrict__ unit_state, float* __restrict__ out_color,
                                                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
     if (counts->overflow) return;
-    const uint32_t tile = blockIdx.x;
-    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x * kWavesPerWG + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
     const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
     const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -559,19 +567,15 @@ __device__ __forceinline__ int bitrev6(int l)
     return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
 }
 
-__global__ void __launch_bounds__(64) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
+__global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                        void* binning, int W, int H, const float* __restrict__ bg,
                                                        const float* __restrict__ dL_dpix, float* __restrict__ accum)
 {
-    __shared__ float4 s_rec[kBatch * kRecQuads];
-    const int lane = threadIdx.x;
-    const uint32_t nu = counts->num_units;
     const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
     // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
-    const int vv = bitrev6(lane);
+    const int vv = bitrev6((int)(threadIdx.x & 63));
     const int own_u = vv / 9, own_c = vv - own_u * 9;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+    FR_UNIT_LOOP_BEGIN
     const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
     const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
     const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
@@ -587,7 +591,6 @@ __global__ void __launch_bounds__(64) k_unit_blend_bwd(const DeviceCounts* __res
     if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
     const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
     float acc_r = st.x, acc_g = st.y, acc_b = st.z;  // accum_rec entering the unit from behind
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
     const int m = (int)ui.m;
 
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
@@ -613,37 +616,33 @@ __global__ void __launch_bounds__(64) k_unit_blend_bwd(const DeviceCounts* __res
         float s[kGroup * 9];
 #pragma unroll
         for (int k = kGroup - 1; k >= 0; k--) {  // back to front
-            const bool c = ok[k];
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha[k]);
-            T = c ? T * inv : T;
-            const float dchannel_dcolor = c ? alpha[k] * T : 0.f;
-            // accum_rec[ch] = last_alpha*last_color[ch] + (1-last_alpha)*accum_rec[ch]
-            const float nr = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-            const float ng = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-            const float nbl = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-            acc_r = c ? nr : acc_r, acc_g = c ? ng : acc_g, acc_b = c ? nbl : acc_b;
-            last_r = c ? q1[k].z : last_r, last_g = c ? q1[k].w : last_g, last_b = c ? q2x[k] : last_b;
-            float dL_dalpha = ((q1[k].z - acc_r) * dpr + (q1[k].w - acc_g) * dpg) + (q2x[k] - acc_b) * dpb;
-            dL_dalpha *= T;
-            last_alpha = c ? alpha[k] : last_alpha;
-            dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-            dL_dalpha = c ? dL_dalpha : 0.f;
-
-            const float Gc = c ? G[k] : 0.f;  // G may be inf/NaN on lanes that failed the tests
-            const float dL_dG = q1[k].y * dL_dalpha;
-            const float gdx = Gc * dx[k], gdy = Gc * dy[k];
-            const float dG_ddelx = -gdx * q0[k].z - gdy * q0[k].w;
-            const float dG_ddely = -gdy * q1[k].x - gdx * q0[k].w;
+            // Lanes that fail the tests take alpha = G = 0: every state update below is then the identity and
+            // every partial gradient is zero, so nothing needs a per-lane select.
+            const float a_e = ok[k] ? alpha[k] : 0.f;
+            const float G_e = ok[k] ? G[k] : 0.f;
+            const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
+            T *= inv;  // transmittance in front of this Gaussian (backward.cu:503)
+            // (acc_r, acc_g, acc_b) is the reference's accum_rec as this Gaussian sees it: the colour blended
+            // behind it (backward.cu:515)
+            const float er = q1[k].z - acc_r, eg = q1[k].w - acc_g, eb = q2x[k] - acc_b;
+            float dL_dalpha = (er * dpr + eg * dpg) + eb * dpb;
+            dL_dalpha = dL_dalpha * T + (-T_final * inv) * bg_dot_dpixel;  // backward.cu:525-534
+            acc_r += a_e * er, acc_g += a_e * eg, acc_b += a_e * eb;       // accum_rec for the next (closer) Gaussian
+            const float wgt = a_e * T;                                     // dchannel_dcolor
+            // q = dL_dG * G.  The reference's per-pair updates are all q times a monomial of (dx, dy); their
+            // combination with the conic / opacity happens once per Gaussian in k_preprocess_bwd.
+            const float q = (q1[k].y * dL_dalpha) * G_e;
+            const float qdx = q * dx[k], qdy = q * dy[k];
             float* su = s + k * 9;
-            su[ACC_MX] = dL_dG * dG_ddelx * ddelx_dx;
-            su[ACC_MY] = dL_dG * dG_ddely * ddely_dy;
-            su[ACC_CA] = -0.5f * gdx * dx[k] * dL_dG;
-            su[ACC_CB] = -0.5f * gdx * dy[k] * dL_dG;
-            su[ACC_CC] = -0.5f * gdy * dy[k] * dL_dG;
-            su[ACC_OP] = Gc * dL_dalpha;
-            su[ACC_R] = dchannel_dcolor * dpr;
-            su[ACC_G] = dchannel_dcolor * dpg;
-            su[ACC_B] = dchannel_dcolor * dpb;
+            su[ACC_MX] = qdx;
+            su[ACC_MY] = qdy;
+            su[ACC_CA] = qdx * dx[k];
+            su[ACC_CB] = qdx * dy[k];
+            su[ACC_CC] = qdy * dy[k];
+            su[ACC_OP] = q;
+            su[ACC_R] = wgt * dpr;
+            su[ACC_G] = wgt * dpg;
+            su[ACC_B] = wgt * dpb;
         }
         const float total = reduce_scatter_36(reinterpret_cast<const float(&)[36]>(s), lane);
         if (vv < kGroup * 9 && (j + own_u) < m) {
@@ -682,7 +681,8 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
 {
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
     const uint32_t small_blocks = (T + 3) / 4;
-    const uint32_t unit_grid = (uint32_t)(b.unit_cap < kUnitGrid ? b.unit_cap : kUnitGrid);
+    const uint32_t unit_wgs = (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG);
+    const uint32_t unit_grid = unit_wgs < kUnitGrid ? unit_wgs : kUnitGrid;
     int rc;
     {
         StageScope sc(h, ST_SORT, s);
@@ -693,11 +693,12 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
     {
         StageScope sc(h, ST_BLEND_FWD, s);
-        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64), 0, s, v.counts, b.unit_tile, v.unit_offset,
+        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, v.unit_offset,
                            v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
-        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64), 0, s, v.counts, b.unit_tile, v.unit_offset,
+        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, v.unit_offset,
                            v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
-        hipLaunchKernelGGL(k_tile_combine, dim3(T), dim3(64), 0, s, v.counts, v.unit_offset, prm.W, prm.H, v.tiles_x,
+        hipLaunchKernelGGL(k_tile_combine, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s,
+                           v.counts, v.unit_offset, T, prm.W, prm.H, v.tiles_x,
                            in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);
     }
     FR_HIP(hipGetLastError());
@@ -712,7 +713,7 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     const uint32_t unit_grid = kUnitGrid;
     {
         StageScope sc(h, ST_BLEND_BWD, s);
-        hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64), 0, s, v.counts, v, binning, prm.W, prm.H,
+        hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W, prm.H,
                            in.background, dL_dpix, g.accum);
     }
     FR_HIP(hipGetLastError());

@@ -18,7 +18,10 @@ constexpr int kCounterStride = 16; // u32 words between the atomic counters of n
 constexpr int kSortRegMax = 1024;
 constexpr int kSortWaveMax = 256;  // longest list one wave sorts alone // longest tile list the in-register wave sort handles
 
-// accumulator slots (blend backward -> preprocess backward)
+// accumulator slots (blend backward -> preprocess backward).  With q = dL/dG * G of a (pixel, Gaussian) pair
+// and d = splat centre - pixel, the slots hold the sums over pixels of:
+//   MX: q*dx   MY: q*dy   CA: q*dx*dx   CB: q*dx*dy   CC: q*dy*dy   OP: q   R,G,B: alpha*T*dL/dpixel
+// k_preprocess_bwd turns them into the reference's dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.
 enum { ACC_MX = 0, ACC_MY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8 };
 
 extern thread_local char g_err[512];

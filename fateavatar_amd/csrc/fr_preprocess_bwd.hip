@@ -18,7 +18,7 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
 struct PreBwdArgs {
-    int P, D, M;
+    int P, D, M, W, H;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     const float* means3D;
     const float* scales;
@@ -61,9 +61,14 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
         return;
     }
     const float* acc = a.g.accum + i * kAccumStride;
-    const float g2x = acc[ACC_MX], g2y = acc[ACC_MY];
-    const float dcx = acc[ACC_CA], dcy = acc[ACC_CB], dcz = acc[ACC_CC];
-    const float dop = acc[ACC_OP];
+    // moments of q = dL/dG * G accumulated by the blend backward -> the reference's per-Gaussian sums
+    // (backward.cu:538-554): dG/ddelx = -G*(dx*A + dy*B), dG/ddely = -G*(dy*C + dx*B)
+    const float4 co = a.g.conic_opacity[idx];
+    const float sx = acc[ACC_MX], sy = acc[ACC_MY];
+    const float g2x = -(co.x * sx + co.y * sy) * (0.5f * a.W);
+    const float g2y = -(co.z * sy + co.y * sx) * (0.5f * a.H);
+    const float dcx = -0.5f * acc[ACC_CA], dcy = -0.5f * acc[ACC_CB], dcz = -0.5f * acc[ACC_CC];
+    const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
     store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f);
     store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2]);
@@ -357,7 +362,7 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     if (rc) return rc;
 
     PreBwdArgs a;
-    a.P = P, a.D = prm.D, a.M = prm.M;
+    a.P = P, a.D = prm.D, a.M = prm.M, a.W = prm.W, a.H = prm.H;
     a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
     a.focal_y = prm.H / (2.0f * prm.tan_fovy);
     a.focal_x = prm.W / (2.0f * prm.tan_fovx);
