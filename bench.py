@@ -90,18 +90,20 @@ def main():
     cam = TorchCamera(scene.camera, dev)
     bg = torch.from_numpy(scene.bg).to(dev)
     H = W = args.res
-    target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    # upstream gradient of the image: d(L1-mean against a fixed random target)/d(pixel) has magnitude 1/(3HW) and
+    # a random sign; it is fixed, so the step is exactly render + backward
+    dL_dpix = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)) < 0.5).float() * 2 - 1)
+    dL_dpix = (dL_dpix / (3 * H * W)).to(dev)
 
     def frame():
-        pc.zero_grad_flat()
-        out = render(cam, pc, bg)
-        loss = (out["render"] - target).abs().mean()  # L1 (train/loss.py), the synthetic loop's loss
-        loss.backward()
+        pc.begin_step()                       # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        out = render(cam, pc, bg)             # activations (stock PyTorch) + HIP rasterizer forward
+        torch.autograd.backward(out["render"], grad_tensors=dL_dpix)  # HIP rasterizer backward + activation backward
 
     def eager_step():
         frame()
         if world > 1:
-            dp.allreduce_mean_(pc.flat_grad)
+            dp.allreduce_mean_(pc.collect_grads())
 
     # eager warm-up: sizes the binning capacity (high-water mark) and fills the allocator pools
     for _ in range(max(3, args.warmup // 2)):
@@ -132,7 +134,7 @@ def main():
         if graph is not None:
             graph.replay()
             if world > 1:
-                dp.allreduce_mean_(pc.flat_grad)
+                dp.allreduce_mean_(pc.collect_grads())
         else:
             eager_step()
 
@@ -199,7 +201,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
-                                   "forward+backward through render() + L1 loss",
+                                   "forward+backward through render() with a fixed dL/dpixel",
                        "frames_per_step_per_gpu": 1, "launch": "hipgraph replay" if args.graph else "eager",
                        "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
                        "num_rendered": R, "tile_instances_8x8": int(counts.num_instances),

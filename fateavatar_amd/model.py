@@ -31,11 +31,17 @@ class FlatGaussians(torch.nn.Module):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
         op = t(opacities).reshape(-1).clamp(1e-6, 1 - 1e-6)
         raw = [t(means3D), t(shs), torch.log(op / (1 - op)), torch.log(t(scales)), t(rotations)]
+        self._grad_views = {}
         off = 0
         for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
             self.flat[off:off + n].copy_(r.reshape(-1))
             p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
-            p.grad = self.flat_grad[off:off + n].view(shp)
+            gv = self.flat_grad[off:off + n].view(shp)
+            self._grad_views[name] = gv
+            if name in ("_xyz", "_features"):
+                # these two reach the rasterizer untouched: it writes their gradient straight into the flat
+                # buffer (rasterizer.py `_fr_grad_out`), no accumulation kernel, no zero-fill
+                p._fr_grad_out = gv
             setattr(self, name, p)
             off += n
 
@@ -66,8 +72,22 @@ class FlatGaussians(torch.nn.Module):
     def grad_of(self, name):
         return getattr(self, name).grad
 
-    def zero_grad_flat(self):
-        self.flat_grad.zero_()
+    def begin_step(self):
+        """Drop the previous gradients (set_to_none, like the reference's zero_grad(set_to_none=True),
+        train/iteration.py:49): the next backward ASSIGNS instead of accumulating."""
+        for name, _ in self.FIELDS:
+            getattr(self, name).grad = None
+
+    def collect_grads(self) -> torch.Tensor:
+        """After backward: make `flat_grad` hold every parameter's gradient (xyz / features are already there;
+        the three activated parameters are copied in).  Returns the flat buffer for the data-parallel exchange."""
+        for name, _ in self.FIELDS:
+            g, view = getattr(self, name).grad, self._grad_views[name]
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+        return self.flat_grad
 
 
 class TorchCamera:

@@ -140,7 +140,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None):
     """`_C.rasterize_gaussians_backward` (rasterize_points.cu:117-196).
 
     Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
@@ -156,6 +156,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         return tuple(torch.zeros(s, **opts) for s in shapes.values())
     # the kernel writes every row of every array it is given, so uninitialised memory is fine
     g = {k: (torch.empty(s, **opts) if (_want is None or k in _want) else None) for k, s in shapes.items()}
+    if _out:  # caller-provided gradient buffers (e.g. views into a flat gradient buffer): written in place
+        for k, buf in _out.items():
+            if buf is not None:
+                assert buf.shape == shapes[k] and buf.is_contiguous() and buf.dtype == torch.float32, k
+                g[k] = buf
 
     background, means3D = _f32c(background), _f32c(means3D)
     colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
@@ -231,6 +236,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # optional extension: an input tensor may carry `_fr_grad_out`, a preallocated buffer that receives its
+        # gradient (zero-copy into e.g. a flat data-parallel gradient buffer)
+        ctx.grad_out = {"dL_dmeans3D": getattr(means3D, "_fr_grad_out", None),
+                        "dL_dsh": getattr(sh, "_fr_grad_out", None) if sh.numel() else None}
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -254,7 +263,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads = rasterize_gaussians_backward(*args)
+            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

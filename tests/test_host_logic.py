@@ -76,11 +76,13 @@ def test_flat_gaussians_getters_reproduce_activated_values():
     assert pc.get_features.shape == (50, 4, 3)
     # gradients of every field land in ONE flat buffer
     (pc.get_opacity.sum() + pc.get_scaling.sum() + pc.get_xyz.sum()).backward()
-    assert pc.flat_grad.shape == pc.flat.shape and pc.flat_grad.abs().sum() > 0
+    flat = pc.collect_grads()
+    assert flat.shape == pc.flat.shape and flat.abs().sum() > 0
     assert torch.equal(pc.grad_of("_xyz"), torch.ones(50, 3))
-    assert pc.grad_of("_xyz").data_ptr() == pc.flat_grad.data_ptr()  # views, not copies
-    pc.zero_grad_flat()
-    assert pc.grad_of("_scaling").abs().sum() == 0
+    assert torch.equal(flat[:150].view(50, 3), torch.ones(50, 3))
+    assert flat[150:150 + 50 * 4 * 3].abs().sum() == 0  # features had no gradient in this graph
+    pc.begin_step()
+    assert pc.grad_of("_scaling") is None
 
 
 def test_head_scene_and_view_orbit():
