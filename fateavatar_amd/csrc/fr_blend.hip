@@ -63,7 +63,8 @@ __device__ __forceinline__ void lane_stage(u64 (&v)[K], int lane)
     for (int r = 0; r < K; r++) {
         const u64 a = v[r];
         const u64 b = lane_xor_u64<MASK>(a, lane);
-        v[r] = lower ? umin64(a, b) : umax64(a, b);
+        // keep a iff it is the min (lower lane) / the max (upper lane): one 64-bit compare + one select
+        v[r] = ((a < b) == lower) ? a : b;
     }
 }
 template <int K>
@@ -102,8 +103,8 @@ __device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
         if (rp > r) {
             const u64 a = v[r], b = v[rp];
             const u64 sa = lane_xor_u64<63>(a, lane), sb = lane_xor_u64<63>(b, lane);
-            v[r] = umin64(a, sb);
-            v[rp] = umax64(b, sa);
+            v[r] = (a < sb) ? a : sb;
+            v[rp] = (b < sa) ? sa : b;
         }
     }
     if constexpr (KK >= 256) reg_cleaner<K, 1>(v);  // distance 64
@@ -170,7 +171,7 @@ __device__ __forceinline__ void cross_wave_stage(u64 (&v)[4], SortXchg& sx, int 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const u64 b = FLIP ? sx[pw][r ^ 3][lane ^ 63] : sx[pw][r][lane];
-        v[r] = lower ? umin64(v[r], b) : umax64(v[r], b);
+        v[r] = ((v[r] < b) == lower) ? v[r] : b;
     }
 }
 
@@ -241,16 +242,29 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
 // neighbouring tiles of one image region land in different workgroups): every wave first sorts its own
 // tile if the list fits one wave (<= 256), then the four waves sort the longer lists (<= 1024) together.
 constexpr int kLargeSorters = 8;
+constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
                                                    GeomView g)
 {
     __shared__ SortXchg sx;
     if (v.counts->overflow) return;
-    if (blockIdx.x >= Q) {
+    // longest jobs first in dispatch order: medium lists, then the (rare) over-long ones, then the short ones
+    if (blockIdx.x < kMediumSorters) {
+        // medium lists (<= 1024): four waves each, static round-robin over the list built by the scan kernel
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t nm = v.counts->medium_tiles;
+        for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
+            const uint32_t tile = v.medium_list[item];
+            sort_tile_group(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
+        }
+        return;
+    }
+    if (blockIdx.x < kMediumSorters + kLargeSorters) {
         // static round-robin over the queue (no work-stealing counter: same-address atomics serialise)
         const uint32_t nl = v.counts->large_tiles;
-        for (uint32_t item = blockIdx.x - Q; item < nl; item += kLargeSorters) {
+        for (uint32_t item = blockIdx.x - kMediumSorters; item < nl; item += kLargeSorters) {
             const uint32_t tile = v.large_list[item];
             sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g);
         }
@@ -259,7 +273,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     {
-        const uint32_t tile = (uint32_t)wave * Q + blockIdx.x;
+        const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters - kLargeSorters);
         if (tile < T) {
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_offset[tile + 1] - start;
@@ -269,12 +283,6 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
                 else sort_tile_regs<4>(keys, recs, start, n, lane, g);
             }
         }
-    }
-    // medium lists (<= 1024): pulled from a queue so that they spread over all workgroups
-    const uint32_t nm = v.counts->medium_tiles;
-    for (uint32_t item = blockIdx.x; item < nm; item += Q) {
-        const uint32_t tile = v.medium_list[item];
-        sort_tile_group(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
     }
 }
 
@@ -336,15 +344,18 @@ struct UnitInfo {
     bool inside;
 };
 
-__device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint32_t* __restrict__ unit_tile,
+__device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint4* __restrict__ unit_tile,
                                               const uint32_t* __restrict__ unit_offset,
                                               const uint32_t* __restrict__ tile_offset, int W, int H, int tiles_x, int lane)
 {
     UnitInfo i;
-    i.tile = unit_tile[u];
-    i.seg = u - unit_offset[i.tile];
-    i.start = tile_offset[i.tile];
-    i.n = tile_offset[i.tile + 1] - i.start;
+    const uint4 d = unit_tile[u];  // one load: (tile, segment, list start, list length)
+    i.tile = d.x;
+    i.seg = d.y;
+    i.start = d.z;
+    i.n = d.w;
+    (void)unit_offset;
+    (void)tile_offset;
     i.base = i.seg * kUnit;
     i.m = min((uint32_t)kUnit, i.n - i.base);
     i.px = (int)(i.tile % (uint32_t)tiles_x) * kTile + (lane & 7);
@@ -367,7 +378,7 @@ constexpr int kWavesPerWG = 4;
 
 // ---- pass A
 __global__ void __launch_bounds__(256) k_unit_tseg(const DeviceCounts* __restrict__ counts,
-                                                  const uint32_t* __restrict__ unit_tile,
+                                                  const uint4* __restrict__ unit_tile,
                                                   const uint32_t* __restrict__ unit_offset,
                                                   const uint32_t* __restrict__ tile_offset,
                                                   const float4* __restrict__ recs, int W, int H, int tiles_x,
@@ -397,7 +408,7 @@ __global__ void __launch_bounds__(256) k_unit_tseg(const DeviceCounts* __restric
 
 // ---- pass B (reference: renderCUDA, forward.cu:261-374, restricted to one unit)
 __global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restrict__ counts,
-                                                   const uint32_t* __restrict__ unit_tile,
+                                                   const uint4* __restrict__ unit_tile,
                                                    const uint32_t* __restrict__ unit_offset,
                                                    const uint32_t* __restrict__ tile_offset,
                                                    const float4* __restrict__ recs, int W, int H, int tiles_x,
@@ -686,7 +697,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     int rc;
     {
         StageScope sc(h, ST_SORT, s);
-        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters), dim3(256), 0, s, v, T, small_blocks,
+        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g);  // small_blocks == Q
     }
     FR_HIP(hipGetLastError());

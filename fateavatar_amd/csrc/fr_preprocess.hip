@@ -72,6 +72,7 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
                                                 int row_len, int lane)
 {
     const int total = rows * row_len;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
     for (int c = lane * 4; c < total; c += 64 * 4) {
         float v[4];
         if (c + 3 < total) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
         for (int k = 0; k < 4; k++) {
             const int e = c + k;
             if (e < total) {
-                const int r = e / row_len;
+                const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
                 dst[r * stride + (e - r * row_len)] = v[k];
             }
         }
@@ -264,7 +265,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 // Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
 // (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
 // the unit -> tile table and builds the list of tiles too long for the in-register sort.
-__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, uint32_t* unit_tile,
+__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, uint4* unit_tile,
                                                      uint32_t unit_cap, const uint32_t* block_ref_tiles,
                                                      uint32_t n_blocks, fr_counts* host_counts)
 {
@@ -292,20 +293,27 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     for (uint32_t i = tid; i < n_blocks; i += 1024) ref += block_ref_tiles[i];
     for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
     if ((tid & 63) == 0) s_ref[tid >> 6] = ref;
-    s_sum[tid] = sum;
-    s_usum[tid] = usum;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
     if ((tid & 63) == 0) s_max[tid >> 6] = mx;
-    __syncthreads();
-    // Hillis-Steele inclusive scans over the 1024 partial sums
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t t = (tid >= off) ? s_sum[tid - off] : 0u;
-        const uint32_t u = (tid >= off) ? s_usum[tid - off] : 0u;
-        __syncthreads();
-        s_sum[tid] += t;
-        s_usum[tid] += u;
-        __syncthreads();
+    // two-level scan: inclusive scan inside each wave (shuffles, no barrier), then over the 16 wave totals
+    uint32_t inc = sum, uinc = usum;
+    const int ln = tid & 63, wv = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off), u = __shfl_up(uinc, off);
+        if (ln >= off) inc += t, uinc += u;
     }
+    if (ln == 63) s_sum[wv] = inc, s_usum[wv] = uinc;
+    __syncthreads();
+    uint32_t wbase = 0, uwbase = 0, tot = 0, utot = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wv) wbase += s_sum[w], uwbase += s_usum[w];
+        tot += s_sum[w], utot += s_usum[w];
+    }
+    __syncthreads();
+    s_sum[tid] = wbase + inc;     // inclusive prefix over the whole workgroup (as before)
+    s_usum[tid] = uwbase + uinc;
+    if (tid == 1023) s_sum[1023] = tot, s_usum[1023] = utot;
+    __syncthreads();
     const uint32_t total = s_sum[1023];
     const bool overflow = (uint64_t)total > capacity;
     uint32_t run = s_sum[tid] - sum, urun = s_usum[tid] - usum;  // exclusive prefixes of this thread's chunk
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         const uint32_t nu = (c + kUnit - 1) / kUnit;
         if (!overflow)
             for (uint32_t k = 0; k < nu; k++)
-                if (urun + k < unit_cap) unit_tile[urun + k] = i;
+                if (urun + k < unit_cap) unit_tile[urun + k] = make_uint4(i, k, run, c);
         run += c;
         urun += nu;
     }
@@ -340,8 +348,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         host_counts->num_rendered = c->num_rendered;
         host_counts->num_instances = total;
         host_counts->max_tile_list = m;
-        host_counts->overflow = c->overflow;
-        __threadfence_system();
+        host_counts->overflow = c->overflow;  // made visible to the host by the end-of-kernel release
     }
 }
 

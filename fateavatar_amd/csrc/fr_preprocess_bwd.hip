@@ -293,6 +293,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
 __device__ __forceinline__ void stage_rows(float* dst, int stride, const float* __restrict__ src, int rows, int row_len, int lane)
 {
     const int total = rows * row_len;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
     for (int c = lane * 4; c < total; c += 64 * 4) {
         float v[4];
         if (c + 3 < total) {
@@ -305,7 +306,7 @@ __device__ __forceinline__ void stage_rows(float* dst, int stride, const float* 
         for (int k = 0; k < 4; k++) {
             const int e = c + k;
             if (e < total) {
-                const int r = e / row_len;
+                const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
                 dst[r * stride + (e - r * row_len)] = v[k];
             }
         }
@@ -314,12 +315,13 @@ __device__ __forceinline__ void stage_rows(float* dst, int stride, const float* 
 __device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane)
 {
     const int total = rows * row_len;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
     for (int c = lane * 4; c < total; c += 64 * 4) {
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int e = c + k;
-            const int r = e / row_len;
+            const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
             v[k] = (e < total) ? src[r * stride + (e - r * row_len)] : 0.f;
         }
         if (c + 3 < total) *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
