@@ -15,6 +15,7 @@ constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): rad
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
 constexpr int kCounterStride = 16; // u32 words between the atomic counters of neighbouring tiles: one 64-B line each
                                    // (device-scope atomics serialise per cache line, ~11 ns apiece)
+constexpr int kInlineSlots = 8;    // instances per Gaussian whose segment position is remembered from the counting pass
 constexpr int kSortRegMax = 1024;
 constexpr int kSortWaveMax = 256;  // longest list one wave sorts alone // longest tile list the in-register wave sort handles
 
@@ -56,6 +57,8 @@ struct GeomView {
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
     uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
+    uint32_t* inline_slots;     // [P*kInlineSlots] position inside its tile's segment of each of a Gaussian's first
+                                // kInlineSlots instances (handed out by the counting atomic of the preprocess)
     static GeomView make(void* buf, size_t P)
     {
         char* p = static_cast<char*>(buf);
@@ -69,13 +72,14 @@ struct GeomView {
         g.clamped = carve<uint8_t>(p, P);
         g.accum = carve<float>(p, P * kAccumStride);
         g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
+        g.inline_slots = carve<uint32_t>(p, P * kInlineSlots);
         return g;
     }
     static size_t bytes(size_t P)
     {
         char* p = nullptr;
         GeomView g = make(p, P);
-        return reinterpret_cast<size_t>(g.block_ref_tiles + (P + 255) / 256 + 1) + 256;
+        return reinterpret_cast<size_t>(g.inline_slots + P * kInlineSlots) + 256;
     }
 };
 
@@ -95,7 +99,8 @@ struct DeviceCounts {  // lives at the head of the image buffer
 
 struct ImageView {
     DeviceCounts* counts;
-    uint32_t* tile_count;    // [T*kCounterStride] instances per 8x8 tile (one counter per 64-B line)
+    uint32_t* tile_count;    // [T*kCounterStride] per 8x8 tile: instances with a remembered position (one counter per 64-B line)
+    uint32_t* tile_over;     // [T*kCounterStride] per 8x8 tile: instances beyond kInlineSlots of their Gaussian
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
     uint32_t* tile_cursor;   // [T*kCounterStride] emit cursors (start at tile_offset), one per 64-B line
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
@@ -113,6 +118,7 @@ struct ImageView {
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
         v.tile_count = carve<uint32_t>(p, T * kCounterStride);
+        v.tile_over = v.tile_count + 1;  // same 64-B line as the tile's main counter (rarely touched)
         v.tile_offset = carve<uint32_t>(p, T + 1);
         v.tile_cursor = carve<uint32_t>(p, T * kCounterStride);
         v.large_list = carve<uint32_t>(p, T);

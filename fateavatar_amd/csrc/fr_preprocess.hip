@@ -32,6 +32,7 @@ struct PreArgs {
     int* radii;
     GeomView g;
     uint32_t* tile_count;
+    uint32_t* tile_over;
     DeviceCounts* counts;
     int tiles_x, tiles_y;   // 8x8 tiles
     int ref_gx, ref_gy;     // 16x16 tiles (reference grid)
@@ -108,9 +109,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     }
     __syncthreads();
     uint32_t ref_tiles = 0;  // tiles_touched in reference semantics (16x16)
+    uint2 rect = make_uint2(0u, 0u);
     if (idx < a.P) {
         int radius_out = 0;
-        uint2 rect = make_uint2(0u, 0u);
         do {
             const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
             // near cull only (auxiliary.h:154)
@@ -235,8 +236,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                     tau = tau * (1.0 + 1.6e-5 * cond + 1e-5) + 1e-4;      // fp32 evaluation slack of `power`
                     const double ex = sqrt(2.0 * tau * C / dq) * (1.0 + 1e-6) + 1e-3;
                     const double ey = sqrt(2.0 * tau * A / dq) * (1.0 + 1e-6) + 1e-3;
-                    const double x_lo = floor((double)pix_x - ex), x_hi = ceil((double)pix_x + ex);
-                    const double y_lo = floor((double)pix_y - ey), y_hi = ceil((double)pix_y + ey);
+                    // integer pixel coordinates p with |p - centre| <= extent (extent already carries the slack)
+                    const double x_lo = ceil((double)pix_x - ex), x_hi = floor((double)pix_x + ex);
+                    const double y_lo = ceil((double)pix_y - ey), y_hi = floor((double)pix_y + ey);
                     if (x_lo > (double)px0) px0 = (int)fmin(x_lo, (double)px1 + 1.0);
                     if (x_hi < (double)px1) px1 = (int)fmax(x_hi, (double)px0 - 1.0);
                     if (y_lo > (double)py0) py0 = (int)fmin(y_lo, (double)py1 + 1.0);
@@ -246,11 +248,45 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             if (px1 < px0 || py1 < py0) break;
             const int tx0 = px0 / kTile, tx1 = px1 / kTile + 1, ty0 = py0 / kTile, ty1 = py1 / kTile + 1;
             rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
-            for (int ty = ty0; ty < ty1; ty++)
-                for (int tx = tx0; tx < tx1; tx++) atomicAdd(&a.tile_count[(size_t)(ty * a.tiles_x + tx) * kCounterStride], 1u);
         } while (false);
         a.radii[idx] = radius_out;
         a.g.rect[idx] = rect;
+    }
+    // ---- count the (tile, Gaussian) instances.  The atomic that counts an instance also hands out its
+    // position inside the tile's segment, which is remembered (first kInlineSlots instances of a Gaussian) so
+    // that the emit pass needs no second atomic.  The wave spreads its instances over its lanes: one returning
+    // atomic round trip per 64 instances instead of one per tile of the widest rectangle.
+    {
+        __shared__ uint32_t s_excl[4][64];
+        __shared__ uint2 s_rect[4][64];
+        const int w = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), h = (int)(rect.y >> 16) - (int)(rect.x >> 16);
+        const uint32_t n = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
+        uint32_t incl = n;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        s_excl[wave][lane] = incl - n;
+        s_rect[wave][lane] = rect;
+        __syncthreads();
+        const int wave_first = blockIdx.x * 256 + wave * 64;
+        for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            const uint2 rr = s_rect[wave][lo];
+            const uint32_t j = k - s_excl[wave][lo];
+            const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
+            const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
+            const size_t t = (size_t)(ty * (uint32_t)a.tiles_x + tx) * kCounterStride;
+            if (j < (uint32_t)kInlineSlots)
+                a.g.inline_slots[(size_t)(wave_first + lo) * kInlineSlots + j] = atomicAdd(&a.tile_count[t], 1u);
+            else
+                atomicAdd(&a.tile_over[t], 1u);
+        }
     }
     // num_rendered in reference semantics: per-workgroup partial sums, added up by the scan kernel (a single
     // counter would serialise one device-scope atomic per wave, ~11 ns each)
@@ -280,8 +316,18 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     const uint32_t per = (T + 1023u) / 1024u;
     const uint32_t b = min(T, tid * per), e = min(T, b + per);
     uint32_t sum = 0, usum = 0, mx = 0;
+    // (remembered, un-remembered) instance counts of this thread's tiles; cached in registers for the second pass
+    constexpr int kCache = 4;
+    uint2 cc[kCache];
+#pragma unroll
+    for (int q = 0; q < kCache; q++) {
+        const uint32_t i = b + q;
+        cc[q] = (i < e) ? *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride) : make_uint2(0u, 0u);
+    }
     for (uint32_t i = b; i < e; i++) {
-        const uint32_t c = v.tile_count[(size_t)i * kCounterStride];
+        const uint2 c2 = (i - b < (uint32_t)kCache) ? cc[(i - b) & (kCache - 1)]
+                                                    : *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride);
+        const uint32_t c = c2.x + c2.y;
         sum += c;
         usum += (c + kUnit - 1) / kUnit;
         mx = max(mx, c);
@@ -318,9 +364,11 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     const bool overflow = (uint64_t)total > capacity;
     uint32_t run = s_sum[tid] - sum, urun = s_usum[tid] - usum;  // exclusive prefixes of this thread's chunk
     for (uint32_t i = b; i < e; i++) {
-        const uint32_t c = v.tile_count[(size_t)i * kCounterStride];
+        const uint2 c2 = (i - b < (uint32_t)kCache) ? cc[(i - b) & (kCache - 1)]
+                                                    : *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride);
+        const uint32_t ci = c2.x, c = c2.x + c2.y;
         v.tile_offset[i] = run;
-        v.tile_cursor[(size_t)i * kCounterStride] = run;
+        v.tile_cursor[(size_t)i * kCounterStride] = run + ci;  // the un-remembered instances go behind the remembered ones
         v.unit_offset[i] = urun;
         const uint32_t nu = (c + kUnit - 1) / kUnit;
         if (!overflow)
@@ -399,7 +447,12 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
         const uint32_t j = k - s_excl[wave][lo];
         const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, w = (rr.y & 0xffff) - x0;
         const uint32_t ty = y0 + j / w, tx = x0 + (j - (j / w) * w);
-        const uint32_t slot = atomicAdd(&v.tile_cursor[(size_t)(ty * (uint32_t)v.tiles_x + tx) * kCounterStride], 1u);
+        const uint32_t tile = ty * (uint32_t)v.tiles_x + tx;
+        uint32_t slot;
+        if (j < (uint32_t)kInlineSlots)
+            slot = v.tile_offset[tile] + g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
+        else
+            slot = atomicAdd(&v.tile_cursor[(size_t)tile * kCounterStride], 1u);
         keys[slot] = s_key[wave][lo];
     }
 }
@@ -456,7 +509,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.opacities = in.opacities;
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
-    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.counts = v.counts;
+    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.tile_over = v.tile_over, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
     if (P > 0) {
