@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--fused-activations", dest="fused_activations", action="store_true", default=True,
+                    help="sigmoid/exp/normalize inside the HIP kernels (SURVEY.md §8f row 1)")
+    ap.add_argument("--torch-activations", dest="fused_activations", action="store_false",
+                    help="reference behaviour: activations as stock PyTorch ops")
     args = ap.parse_args()
 
     rank, world, local = dp.init_from_env()
@@ -86,7 +90,8 @@ def main():
 
     # replicated Gaussians (same seed on every rank), one view per rank
     scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1))
-    pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree, dev)
+    pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree, dev,
+                       fused_activations=args.fused_activations)
     cam = TorchCamera(scene.camera, dev)
     bg = torch.from_numpy(scene.bg).to(dev)
     H = W = args.res
@@ -202,7 +207,9 @@ def main():
             "config": {"workload": f"BASELINE.json configs[1]: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
-                       "frames_per_step_per_gpu": 1, "launch": "hipgraph replay" if args.graph else "eager",
+                       "frames_per_step_per_gpu": 1,
+                       "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
+                       "launch": "hipgraph replay" if args.graph else "eager",
                        "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
                        "num_rendered": R, "tile_instances_8x8": int(counts.num_instances),
                        "max_tile_list": int(counts.max_tile_list)},

@@ -18,6 +18,7 @@ FR_ERR_BINNING_CAPACITY = 2
 FR_ERR_HIP = 3
 FR_ERR_UNSUPPORTED = 4
 FR_FLAG_NO_WAIT = 1
+FR_FLAG_RAW_ACTIVATIONS = 2
 
 _fp = C.c_void_p  # device pointers travel as integers
 

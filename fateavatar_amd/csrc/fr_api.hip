@@ -38,6 +38,8 @@ static int check_frame(const fr_params* prm, const fr_inputs* in, bool forward)
     const bool sr = in->scales && in->rotations;
     if ((in->scales == nullptr) != (in->rotations == nullptr) || (sr == (in->cov3D_precomp != nullptr)))
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "provide exactly one of scales+rotations / cov3D_precomp");
+    if ((prm->flags & FR_FLAG_RAW_ACTIVATIONS) && !sr)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "FR_FLAG_RAW_ACTIVATIONS needs scales + rotations");
     if (in->shs && prm->M < (prm->D + 1) * (prm->D + 1))
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "M smaller than (D+1)^2");
     return FR_OK;

@@ -228,6 +228,14 @@ int launch_selftest_reduce(const float* in, float* out, hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- device helpers
+// the reference GaussianModel's activations (gaussian_model.py:39-50), applied in-kernel when
+// FR_FLAG_RAW_ACTIVATIONS is set
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_exp(float x) { return expf(x); }
+__device__ __forceinline__ float act_rot_inv_norm(float r, float x, float y, float z)
+{
+    return 1.0f / fmaxf(sqrtf(r * r + x * x + y * y + z * z), 1e-12f);  // torch.nn.functional.normalize, eps 1e-12
+}
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // HW fp32 atomic add (global_atomic_add_f32), no return value needed.

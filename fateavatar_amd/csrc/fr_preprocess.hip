@@ -17,7 +17,7 @@ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
 struct PreArgs {
-    int P, D, M, W, H;
+    int P, D, M, W, H, raw;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     const float* means3D;
     const float* scales;
@@ -127,10 +127,15 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             if (a.cov3D_precomp) {
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                const float s0 = a.scale_modifier * a.scales[3 * idx], s1 = a.scale_modifier * a.scales[3 * idx + 1],
-                            s2 = a.scale_modifier * a.scales[3 * idx + 2];
-                const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-                            z = a.rotations[4 * idx + 3];
+                float sc0 = a.scales[3 * idx], sc1 = a.scales[3 * idx + 1], sc2 = a.scales[3 * idx + 2];
+                float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
+                      z = a.rotations[4 * idx + 3];
+                if (a.raw) {
+                    sc0 = act_exp(sc0), sc1 = act_exp(sc1), sc2 = act_exp(sc2);
+                    const float inv = act_rot_inv_norm(r, x, y, z);
+                    r *= inv, x *= inv, y *= inv, z *= inv;
+                }
+                const float s0 = a.scale_modifier * sc0, s1 = a.scale_modifier * sc1, s2 = a.scale_modifier * sc2;
                 // rows of the rotation matrix, each entry scaled by the scale of its COLUMN index
                 const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)),
                             m02 = s2 * (2.f * (x * z + r * y));
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 }
             }
 
-            const float opacity = a.opacities[idx];
+            const float opacity = a.raw ? act_sigmoid(a.opacities[idx]) : a.opacities[idx];
             radius_out = mr;
             a.g.depth[idx] = p_view.z;
             a.g.means2D[idx] = make_float2(pix_x, pix_y);
@@ -502,6 +507,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
 
     PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
+    a.raw = (prm.flags & FR_FLAG_RAW_ACTIVATIONS) ? 1 : 0;
     a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
     a.focal_y = H / (2.0f * prm.tan_fovy);  // rasterizer_impl.cu:222-223
     a.focal_x = W / (2.0f * prm.tan_fovx);

@@ -18,7 +18,7 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
 struct PreBwdArgs {
-    int P, D, M, W, H;
+    int P, D, M, W, H, raw;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     const float* means3D;
     const float* scales;
@@ -72,7 +72,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
     store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f);
     store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2]);
-    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = dop;
+    // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
+    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = a.raw ? dop * co.w * (1.0f - co.w) : dop;
 
     const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     const float* vm = a.view;
@@ -247,10 +248,16 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
 
     // ---------------- Sigma3D -> scale, quaternion (backward.cu:278-341)
     if (a.scales) {
-        const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-                    z = a.rotations[4 * idx + 3];
-        const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                            a.scale_modifier * a.scales[3 * idx + 2]};
+        float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
+              z = a.rotations[4 * idx + 3];
+        float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        float rot_inv = 1.0f;
+        if (a.raw) {
+            sc[0] = act_exp(sc[0]), sc[1] = act_exp(sc[1]), sc[2] = act_exp(sc[2]);
+            rot_inv = act_rot_inv_norm(r, x, y, z);
+            r *= rot_inv, x *= rot_inv, y *= rot_inv, z *= rot_inv;
+        }
+        const float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
         // Rc[c][w]: the reference's column-major R (its column c is row c of the usual rotation matrix)
         const float Rc[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                                 {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -271,7 +278,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
         const float dsx = Rc[0][0] * dMt[0][0] + Rc[1][0] * dMt[0][1] + Rc[2][0] * dMt[0][2];
         const float dsy = Rc[0][1] * dMt[1][0] + Rc[1][1] * dMt[1][1] + Rc[2][1] * dMt[1][2];
         const float dsz = Rc[0][2] * dMt[2][0] + Rc[1][2] * dMt[2][1] + Rc[2][2] * dMt[2][2];
-        store3(a.out.dL_dscales, i, dsx, dsy, dsz);
+        // raw-parameter mode: d exp = the activated scale
+        if (a.raw) store3(a.out.dL_dscales, i, dsx * sc[0], dsy * sc[1], dsz * sc[2]);
+        else store3(a.out.dL_dscales, i, dsx, dsy, dsz);
         for (int w = 0; w < 3; w++) dMt[0][w] *= s[0], dMt[1][w] *= s[1], dMt[2][w] *= s[2];
 #define Dm(c_, r_) dMt[c_][r_]
         if (a.out.dL_drotations) {
@@ -280,6 +289,14 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
             dq[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
             dq[2] = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
             dq[3] = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
+            if (a.raw) {
+                // through q_hat = q / |q|:  dL/dq = (g - q_hat (q_hat . g)) / |q|
+                const float dot = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+                dq[0] = (dq[0] - r * dot) * rot_inv;
+                dq[1] = (dq[1] - x * dot) * rot_inv;
+                dq[2] = (dq[2] - y * dot) * rot_inv;
+                dq[3] = (dq[3] - z * dot) * rot_inv;
+            }
         }
 #undef Dm
     } else {
@@ -365,6 +382,7 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
 
     PreBwdArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = prm.W, a.H = prm.H;
+    a.raw = (prm.flags & FR_FLAG_RAW_ACTIVATIONS) ? 1 : 0;
     a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
     a.focal_y = prm.H / (2.0f * prm.tan_fovy);
     a.focal_x = prm.W / (2.0f * prm.tan_fovx);

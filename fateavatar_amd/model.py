@@ -15,13 +15,15 @@ import torch
 class FlatGaussians(torch.nn.Module):
     FIELDS = (("_xyz", 3), ("_features", None), ("_opacity", 1), ("_scaling", 3), ("_rotation", 4))
 
-    def __init__(self, means3D, shs, opacities, scales, rotations, sh_degree: int, device):
+    def __init__(self, means3D, shs, opacities, scales, rotations, sh_degree: int, device, fused_activations=False):
         """Arguments are ACTIVATED values (numpy): they are inverted into raw parameters like
         create_from_pcd does (gaussian_model.py:137-160)."""
         super().__init__()
         P, M = means3D.shape[0], shs.shape[1]
         self.max_sh_degree = sh_degree
         self.P, self.M = P, M
+        # True: render() passes the raw parameters and the rasterizer kernels apply the activations themselves
+        self.fused_activations = bool(fused_activations)
         sizes = [P * 3, P * M * 3, P, P * 3, P * 4]
         shapes = [(P, 3), (P, M, 3), (P, 1), (P, 3), (P, 4)]
         # one flat value buffer and one flat gradient buffer; every parameter (and its .grad) is a VIEW into
@@ -38,7 +40,7 @@ class FlatGaussians(torch.nn.Module):
             p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
             gv = self.flat_grad[off:off + n].view(shp)
             self._grad_views[name] = gv
-            if name in ("_xyz", "_features"):
+            if name in ("_xyz", "_features") or self.fused_activations:
                 # these two reach the rasterizer untouched: it writes their gradient straight into the flat
                 # buffer (rasterizer.py `_fr_grad_out`), no accumulation kernel, no zero-fill
                 p._fr_grad_out = gv

@@ -77,10 +77,10 @@ def check_async_overflow(device_index: int = 0) -> bool:
     return bool(c.overflow)
 
 
-def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug) -> _lib.fr_params:
+def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw=False) -> _lib.fr_params:
+    flags = (_lib.FR_FLAG_NO_WAIT if _no_wait else 0) | (_lib.FR_FLAG_RAW_ACTIVATIONS if raw else 0)
     return _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
-                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
-                          _lib.FR_FLAG_NO_WAIT if _no_wait else 0)
+                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)), flags)
 
 
 def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
@@ -90,8 +90,9 @@ def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """`_C.rasterize_gaussians` (rasterize_points.cu:35-115).
+                        prefiltered, debug, _raw=False):
+    """`_C.rasterize_gaussians` (rasterize_points.cu:35-115).  `_raw=True` (extension, FR_FLAG_RAW_ACTIVATIONS):
+    opacity / scales / rotations are the RAW parameters and the kernels apply sigmoid / exp / normalize.
 
     Returns (num_rendered, out_color[3,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer); the three
     byte buffers are opaque and must be handed back to `rasterize_gaussians_backward`."""
@@ -113,7 +114,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
     L = _lib.lib()
     h = _lib.handle(dev)
-    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, _raw)
     inp = _inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
     geom = torch.empty((L.fr_geometry_bytes(P),), dtype=torch.uint8, **opts)
@@ -140,7 +141,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None, _raw=False):
     """`_C.rasterize_gaussians_backward` (rasterize_points.cu:117-196).
 
     Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
@@ -170,7 +171,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
     L = _lib.lib()
     h = _lib.handle(dev)
-    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw)
     inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
     grads = _lib.fr_grads(*[_ptr(g[k]) for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D",
@@ -219,27 +220,32 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, raw_activations=False):
         rs = raster_settings
+        ctx.raw = bool(raw_activations)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args, _raw=ctx.raw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args, _raw=ctx.raw)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # optional extension: an input tensor may carry `_fr_grad_out`, a preallocated buffer that receives its
         # gradient (zero-copy into e.g. a flat data-parallel gradient buffer)
         ctx.grad_out = {"dL_dmeans3D": getattr(means3D, "_fr_grad_out", None),
                         "dL_dsh": getattr(sh, "_fr_grad_out", None) if sh.numel() else None}
+        if ctx.raw:  # raw parameters reach the kernels directly: their gradients can be written in place too
+            ctx.grad_out.update(dL_dopacity=getattr(opacities, "_fr_grad_out", None),
+                                dL_dscales=getattr(scales, "_fr_grad_out", None),
+                                dL_drotations=getattr(rotations, "_fr_grad_out", None))
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -257,23 +263,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads = rasterize_gaussians_backward(*args)
+                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out)
+            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None)
+                grad_rotations, grad_cov3Ds_precomp, None, None)
 
 
 def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 raster_settings):
+                                 raster_settings, raw_activations=False):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, raw_activations)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -304,7 +310,9 @@ class GaussianRasterizer(nn.Module):
             return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, raw_activations=False):
+        """`raw_activations=True` (extension, not in the reference): opacities / scales / rotations are the RAW
+        parameters; sigmoid / exp / normalize and their derivatives run inside the HIP kernels."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -322,5 +330,7 @@ class GaussianRasterizer(nn.Module):
             rotations = empty
         if cov3D_precomp is None:
             cov3D_precomp = empty
+        if raw_activations and (scales is None or scales.numel() == 0):
+            raise Exception('raw_activations needs the scale/rotation pair')
         return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, rs)
+                                            cov3D_precomp, rs, raw_activations)

@@ -43,9 +43,16 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, o
     )
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
+    # Extension: a holder that sets `fused_activations` hands over its RAW opacity / scaling /
+    # rotation and the HIP kernels apply sigmoid / exp / normalize (and their derivatives) themselves, instead of
+    # ~15 small PyTorch kernels per frame.  The default is the reference behaviour.
+    fused = bool(getattr(pc, "fused_activations", False))
+    if fused:
+        opacity, scales, rotations = pc._opacity, pc._scaling, pc._rotation
+    else:
+        opacity = pc.get_opacity
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
     cov3D_precomp = None
     shs = pc.get_features
     if override_color is None:
@@ -55,6 +62,6 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, o
         shs = None
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations,
-                                       cov3D_precomp=cov3D_precomp)
+                                       cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if fused else {}))
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}

@@ -72,6 +72,12 @@ typedef struct fr_params {
  * fr_read_counts.  If counts.overflow is set the frame's outputs are invalid: rerun with a larger capacity. */
 #define FR_FLAG_NO_WAIT 1
 
+/* Fused activations (reference volume_rendering/gaussian_model.py:39-50,105-128):
+ * inputs.opacities / scales / rotations hold the RAW parameters and the kernels apply sigmoid / exp /
+ * normalize (x / max(|x|, 1e-12)) themselves; fr_backward then returns dL/d(raw) in dL_dopacity, dL_dscales,
+ * dL_drotations.  Requires scales + rotations (not cov3D_precomp).  Pass the same flag to fr_backward. */
+#define FR_FLAG_RAW_ACTIVATIONS 2
+
 /* Device pointers.  NULL = the "empty tensor" of the reference glue
  * (rasterize_points.cu:94-103 passes data_ptr() of empty tensors; kernels branch on nullptr). */
 typedef struct fr_inputs {

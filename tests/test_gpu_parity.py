@@ -233,3 +233,32 @@ def test_render_api_autograd_path(gpu_device):
     assert util.rel_l2(pc.grad_of("_opacity").cpu().numpy(), b.dL_dopacity * op * (1 - op)) < 2e-4
     sc = pc.get_scaling.detach().cpu().numpy()
     assert util.rel_l2(pc.grad_of("_scaling").cpu().numpy(), b.dL_dscales * sc) < 2e-4
+
+
+def test_fused_activations_match_torch_activations(gpu_device):
+    """render() with raw parameters + in-kernel sigmoid/exp/normalize == render() with PyTorch activations
+    (which the oracle tests pin), forward and every raw-parameter gradient."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    s = scenes.random_scene(3000, 96, 80, sh_degree=2, seed=12, M=16, scale_lo=0.01, scale_hi=0.06, opacity_lo=0.05,
+                            opacity_hi=0.95, bg=(0.1, 0.6, 0.3))
+    rng = np.random.default_rng(4)
+    rot_raw = (s.rotations * rng.uniform(0.3, 3.0, (s.P, 1))).astype(np.float32)  # un-normalised raw quaternions
+    cam = TorchCamera(s.camera, gpu_device)
+    bg = torch.from_numpy(s.bg).to(gpu_device)
+    w = torch.from_numpy((rng.uniform(-1, 1, (3, 96, 80)) / (3 * 96 * 80)).astype(np.float32)).to(gpu_device)
+    res = {}
+    for fused in (False, True):
+        pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, rot_raw, 2, gpu_device, fused_activations=fused)
+        out = render(cam, pc, bg)
+        torch.autograd.backward(out["render"], grad_tensors=w)
+        res[fused] = dict(img=out["render"].detach().cpu().numpy(), radii=out["radii"].cpu().numpy(),
+                          g2=out["viewspace_points"].grad.cpu().numpy(),
+                          **{n: pc.grad_of(n).cpu().numpy() for n, _ in pc.FIELDS})
+    a, b = res[False], res[True]
+    assert np.mean(a["radii"] == b["radii"]) > 0.999
+    assert util.frac_close(b["img"], a["img"], 1e-4, 1e-5) >= 0.9999
+    for k in ["g2", "_xyz", "_features", "_opacity", "_scaling", "_rotation"]:
+        assert util.rel_l2(b[k], a[k]) < 2e-4, (k, util.rel_l2(b[k], a[k]))
+        assert np.abs(a[k]).max() > 0
