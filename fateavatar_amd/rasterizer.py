@@ -161,7 +161,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         for k, buf in _out.items():
             if buf is not None:
                 assert buf.shape == shapes[k] and buf.is_contiguous() and buf.dtype == torch.float32, k
-                g[k] = buf
+                # a FRESH view object: autograd's AccumulateGrad only adopts an incoming gradient without
+                # cloning it when nobody else holds a reference to that tensor object
+                g[k] = buf.view(buf.shape)
 
     background, means3D = _f32c(background), _f32c(means3D)
     colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
