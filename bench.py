@@ -131,7 +131,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             frame()
         torch.cuda.synchronize()
 
@@ -156,7 +157,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if graph is not None:
         if rasterizer.check_async_overflow(local):
-            raise SystemExit("binning capacity overflowed inside the captured graph; rerun (capacity hint was raised)")
+            c = rasterizer.last_counts[local]
+            raise SystemExit(f"rank {rank}: binning capacity overflowed inside the captured graph "
+                             f"(instances {c.num_instances}, num_rendered {c.num_rendered}, max list {c.max_tile_list}); "
+                             "rerun (capacity hint was raised)")
         rasterizer.set_no_wait(False)
     # per-kernel durations: HIP events around every stage launch, on the launch stream, over eager replays of
     # the same frame right after the timed region (event records inside a replayed graph cannot be read back)

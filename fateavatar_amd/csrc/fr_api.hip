@@ -45,6 +45,23 @@ static int check_frame(const fr_params* prm, const fr_inputs* in, bool forward)
     return FR_OK;
 }
 
+__global__ void __launch_bounds__(256) k_zero16(uint4* p, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int launch_zero(void* ptr, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return FR_OK;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero16, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint4*>(ptr), n16);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
 }  // namespace fr
 
 using namespace fr;

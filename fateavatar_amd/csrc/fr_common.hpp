@@ -224,6 +224,10 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
+// zero `bytes` (multiple of 16, 16-byte aligned) with a plain kernel.  hipMemsetAsync is avoided on purpose: as a
+// memset NODE of a captured graph it stopped taking effect once an eager kernel had been launched between two
+// replays (ROCm 7.0 runtime shipped with PyTorch 2.10; reproduced with tools/dbg_graph.py).
+int launch_zero(void* ptr, size_t bytes, hipStream_t s);
 int launch_selftest_reduce(const float* in, float* out, hipStream_t s);
 
 #if defined(__HIPCC__)

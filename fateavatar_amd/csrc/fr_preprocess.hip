@@ -503,7 +503,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     const bool debug = prm.debug != 0;
     int rc;
 
-    FR_HIP(hipMemsetAsync(image, 0, v.zero_bytes(image), s));
+    if ((rc = launch_zero(image, v.zero_bytes(image), s))) return rc;
 
     PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;

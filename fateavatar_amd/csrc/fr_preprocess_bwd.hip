@@ -376,8 +376,9 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     GeomView g = GeomView::make(geometry, (size_t)P);
     ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
     const bool debug = prm.debug != 0;
-    FR_HIP(hipMemsetAsync(g.accum, 0, sizeof(float) * (size_t)P * kAccumStride, s));
-    int rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
+    int rc = launch_zero(g.accum, sizeof(float) * (size_t)P * kAccumStride, s);
+    if (rc) return rc;
+    rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
     if (rc) return rc;
 
     PreBwdArgs a;

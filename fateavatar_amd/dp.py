@@ -27,10 +27,14 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # FR_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with fewer GPUs than ranks
+            backend = os.environ.get("FR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        elif torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
+            dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local

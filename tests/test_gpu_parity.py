@@ -262,3 +262,56 @@ def test_fused_activations_match_torch_activations(gpu_device):
     for k in ["g2", "_xyz", "_features", "_opacity", "_scaling", "_rotation"]:
         assert util.rel_l2(b[k], a[k]) < 2e-4, (k, util.rel_l2(b[k], a[k]))
         assert np.abs(a[k]).max() > 0
+
+
+def test_graph_replay_survives_interleaved_eager_kernels(gpu_device):
+    """A frame captured in a HIP graph (FR_FLAG_NO_WAIT) must give the same image and counts on every replay,
+    also when eager kernels run between replays (regression: hipMemsetAsync as a graph node did not)."""
+    import torch
+    from fateavatar_amd import rasterizer
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    s = scenes.head_scene(P=20000, res=256, sh_degree=3, seed=0)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 3, gpu_device, fused_activations=True)
+    cam = TorchCamera(s.camera, gpu_device)
+    bg = torch.from_numpy(s.bg).to(gpu_device)
+    g = torch.rand(3, 256, 256, device=gpu_device) / (3 * 256 * 256)
+    static_img = torch.zeros(3, 256, 256, device=gpu_device)
+
+    def frame():
+        pc.begin_step()
+        out = render(cam, pc, bg)
+        torch.autograd.backward(out["render"], grad_tensors=g)
+        static_img.copy_(out["render"].detach())
+
+    for _ in range(3):
+        frame()
+    torch.cuda.synchronize()
+    ref_img = static_img.clone()
+    ref_grad = pc.collect_grads().clone()
+    ref_counts = rasterizer.last_counts[0]
+    try:
+        rasterizer.set_no_wait(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            frame()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            frame()
+        other = torch.ones(4096, device=gpu_device)
+        for i in range(6):
+            graph.replay()
+            other.mul_(1.5)               # eager kernels between replays
+            pc.collect_grads().mul_(1.0)
+        torch.cuda.synchronize()
+        c = rasterizer.read_counts(0)
+        assert not rasterizer.check_async_overflow(0)
+    finally:
+        rasterizer.set_no_wait(False)
+    assert (c.num_instances, c.num_rendered, c.max_tile_list) == (ref_counts.num_instances, ref_counts.num_rendered,
+                                                                  ref_counts.max_tile_list)
+    assert torch.equal(static_img, ref_img)
+    assert util.rel_l2(pc.flat_grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-5
