@@ -91,10 +91,20 @@ __device__ __forceinline__ void reg_cleaner(u64 (&v)[K])
     }
 }
 
+template <int K, int JR>
+__device__ __forceinline__ void reg_cleaners_from(u64 (&v)[K])
+{
+    // half-cleaners at register distances JR, JR/2, ..., 1 (element distances 64*JR ... 64)
+    if constexpr (JR >= 1) {
+        reg_cleaner<K, JR>(v);
+        reg_cleaners_from<K, JR / 2>(v);
+    }
+}
+
 template <int K, int KK>
 __device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
 {
-    // merge step for blocks of KK in {128, 256} elements held by one wave
+    // merge step for blocks of KK in {128 ... 1024} elements held by one wave
     constexpr int m = (KK >> 6) - 1;
     // flip: partner index = i ^ (KK-1)  ->  register r ^ m, lane ^ 63
 #pragma unroll
@@ -107,7 +117,7 @@ __device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
             v[rp] = (b < sa) ? sa : b;
         }
     }
-    if constexpr (KK >= 256) reg_cleaner<K, 1>(v);  // distance 64
+    reg_cleaners_from<K, (KK >> 8)>(v);  // distances KK/4 ... 64
     lane_cleaners_from_32<K>(v, lane);
 }
 
@@ -126,6 +136,8 @@ __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
     lane_stage<K, 4, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);  // k = 64
     if constexpr (K >= 2) big_stage<K, 128>(v, lane);
     if constexpr (K >= 4) big_stage<K, 256>(v, lane);
+    if constexpr (K >= 8) big_stage<K, 512>(v, lane);
+    if constexpr (K >= 16) big_stage<K, 1024>(v, lane);
 }
 
 __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g)
@@ -157,52 +169,59 @@ __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, ui
     }
 }
 
-// Four waves sort up to 1024 keys together: each wave sorts its 256 keys in registers, then the two
-// remaining merge levels exchange registers with the partner wave through LDS (3 exchanges in total).
-typedef u64 SortXchg[4][4][64];
+// Four waves sort up to 4 * 64 * K keys together (K = 4: 1024, K = 16: 4096): each wave sorts its 64*K keys in
+// registers, then the two remaining merge levels exchange registers with the partner wave through LDS
+// (3 exchanges in total).
+template <int K>
+struct SortXchgT {
+    u64 a[4][K][64];
+    __device__ __forceinline__ u64 (&operator[](int w))[K][64] { return a[w]; }
+};
+#define SortXchg SortXchgT<K>
 
-template <bool FLIP>
-__device__ __forceinline__ void cross_wave_stage(u64 (&v)[4], SortXchg& sx, int wave, int lane, int pw, bool lower)
+template <int K, bool FLIP>
+__device__ __forceinline__ void cross_wave_stage(u64 (&v)[K], SortXchg& sx, int wave, int lane, int pw, bool lower)
 {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) sx[wave][r][lane] = v[r];
+    for (int r = 0; r < K; r++) sx[wave][r][lane] = v[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const u64 b = FLIP ? sx[pw][r ^ 3][lane ^ 63] : sx[pw][r][lane];
+    for (int r = 0; r < K; r++) {
+        const u64 b = FLIP ? sx[pw][r ^ (K - 1)][lane ^ 63] : sx[pw][r][lane];
         v[r] = ((v[r] < b) == lower) ? v[r] : b;
     }
 }
 
+template <int K>
 __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
                                 const GeomView& g, SortXchg& sx)
 {
-    u64 v[4];
+    constexpr int KW = 64 * K;  // keys per wave
+    u64 v[K];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t i = (uint32_t)(wave * 256 + r * 64 + lane);
+    for (int r = 0; r < K; r++) {
+        const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
         v[r] = i < n ? keys[start + i] : ~0ull;
     }
-    wave_sort<4>(v, lane);
-    // k = 512: flip with wave ^ 1, then distances 128, 64, 32..1 inside the wave
-    cross_wave_stage<true>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaner<4, 2>(v);
-    reg_cleaner<4, 1>(v);
-    lane_cleaners_from_32<4>(v, lane);
-    // k = 1024: flip with wave ^ 3, distance 256 with wave ^ 1, then 128, 64, 32..1
-    cross_wave_stage<true>(v, sx, wave, lane, wave ^ 3, (wave & 2) == 0);
-    cross_wave_stage<false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaner<4, 2>(v);
-    reg_cleaner<4, 1>(v);
-    lane_cleaners_from_32<4>(v, lane);
+    wave_sort<K>(v, lane);
+    // blocks of 2*KW: flip with wave ^ 1, then register / lane distances inside the wave
+    cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
+    reg_cleaners_from<K, K / 2>(v);
+    lane_cleaners_from_32<K>(v, lane);
+    // blocks of 4*KW: flip with wave ^ 3, distance KW with wave ^ 1, then inside the wave
+    cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 3, (wave & 2) == 0);
+    cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
+    reg_cleaners_from<K, K / 2>(v);
+    lane_cleaners_from_32<K>(v, lane);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t i = (uint32_t)(wave * 256 + r * 64 + lane);
+    for (int r = 0; r < K; r++) {
+        const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
         if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
     }
 }
 
+#undef SortXchg
 // Slow path for a tile list longer than kSortRegMax: bitonic network over the tile's key segment
 // in global memory by one 256-thread workgroup (virtual +inf padding: a compare-exchange whose
 // upper index is >= n is a no-op in the flip formulation).  Agent-scope accesses keep the data
@@ -241,13 +260,12 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
 // lists longer than kSortRegMax.  Workgroup b owns tiles {b, b+Q, b+2Q, b+3Q} (strided, so that the dense
 // neighbouring tiles of one image region land in different workgroups): every wave first sorts its own
 // tile if the list fits one wave (<= 256), then the four waves sort the longer lists (<= 1024) together.
-constexpr int kLargeSorters = 8;
 constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
                                                    GeomView g)
 {
-    __shared__ SortXchg sx;
+    __shared__ SortXchgT<4> sx;
     if (v.counts->overflow) return;
     // longest jobs first in dispatch order: medium lists, then the (rare) over-long ones, then the short ones
     if (blockIdx.x < kMediumSorters) {
@@ -257,23 +275,14 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
         const uint32_t nm = v.counts->medium_tiles;
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
-        }
-        return;
-    }
-    if (blockIdx.x < kMediumSorters + kLargeSorters) {
-        // static round-robin over the queue (no work-stealing counter: same-address atomics serialise)
-        const uint32_t nl = v.counts->large_tiles;
-        for (uint32_t item = blockIdx.x - kMediumSorters; item < nl; item += kLargeSorters) {
-            const uint32_t tile = v.large_list[item];
-            sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g);
+            sort_tile_group<4>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
         }
         return;
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     {
-        const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters - kLargeSorters);
+        const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
         if (tile < T) {
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_offset[tile + 1] - start;
@@ -283,6 +292,28 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
                 else sort_tile_regs<4>(keys, recs, start, n, lane, g);
             }
         }
+    }
+}
+
+// Lists longer than kSortGroupMax (dense / zoomed-in scenes): 4 waves x 16 keys per lane up to 4096, the
+// global-memory network beyond.  A separate kernel so that its register budget (16 keys per lane) does not
+// lower the occupancy of the common path.
+constexpr uint32_t kBigSorters = 128;
+
+__global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, float4* recs, GeomView g)
+{
+    __shared__ SortXchgT<16> sx;
+    if (v.counts->overflow) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
+    for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
+        const uint32_t tile = v.big_list[item];
+        sort_tile_group<16>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
+    }
+    for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
+        const uint32_t tile = v.large_list[item];
+        sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g);
     }
 }
 
@@ -697,8 +728,9 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     int rc;
     {
         StageScope sc(h, ST_SORT, s);
-        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kLargeSorters + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
+        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g);  // small_blocks == Q
+        hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;

@@ -16,7 +16,8 @@ constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumul
 constexpr int kCounterStride = 16; // u32 words between the atomic counters of neighbouring tiles: one 64-B line each
                                    // (device-scope atomics serialise per cache line, ~11 ns apiece)
 constexpr int kInlineSlots = 8;    // instances per Gaussian whose segment position is remembered from the counting pass
-constexpr int kSortRegMax = 1024;
+constexpr int kSortRegMax = 4096;   // longest list sorted in registers (4 waves x 16 keys per lane); longer ones: global-memory fallback
+constexpr int kSortGroupMax = 1024; // longest list the main sort kernel handles (4 waves x 4 keys per lane)
 constexpr int kSortWaveMax = 256;  // longest list one wave sorts alone // longest tile list the in-register wave sort handles
 
 // accumulator slots (blend backward -> preprocess backward).  With q = dL/dG * G of a (pixel, Gaussian) pair
@@ -91,7 +92,7 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
     uint32_t large_cursor;   // work-queue head for the large-tile sorter
     uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
-    uint32_t medium_cursor;  // work-queue head for those
+    uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
     uint32_t pad2[6];
     uint32_t num_units;      // total number of blend units (64-record segments of tile lists)
     uint32_t capacity;       // binning capacity of this frame (the backward re-derives the binning layout from it)
@@ -104,7 +105,8 @@ struct ImageView {
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
     uint32_t* tile_cursor;   // [T*kCounterStride] emit cursors (start at tile_offset), one per 64-B line
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
-    uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortRegMax (sorted by 4 waves)
+    uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
+    uint32_t* big_list;      // [T]   ids of tiles with kSortGroupMax < entries <= kSortRegMax
     uint32_t* unit_offset;   // [T+1] exclusive scan of ceil(tile_count / 64): first blend unit of each tile
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
@@ -123,6 +125,7 @@ struct ImageView {
         v.tile_cursor = carve<uint32_t>(p, T * kCounterStride);
         v.large_list = carve<uint32_t>(p, T);
         v.medium_list = carve<uint32_t>(p, T);
+        v.big_list = carve<uint32_t>(p, T);
         v.unit_offset = carve<uint32_t>(p, T + 1);
         v.final_T = carve<float>(p, (size_t)W * H);
         v.n_contrib = carve<uint32_t>(p, (size_t)W * H);

@@ -311,8 +311,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
                                                      uint32_t n_blocks, fr_counts* host_counts)
 {
     __shared__ uint32_t s_ref[16];
-    __shared__ uint32_t s_heads[2];
-    if (threadIdx.x < 2) s_heads[threadIdx.x] = 0;
+    __shared__ uint32_t s_heads[3];
+    if (threadIdx.x < 3) s_heads[threadIdx.x] = 0;
     __syncthreads();
     __shared__ uint32_t s_sum[1024];
     __shared__ uint32_t s_usum[1024];
@@ -338,6 +338,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         mx = max(mx, c);
         // single workgroup: the list heads live in LDS (a global same-address atomic costs ~11 ns apiece)
         if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&s_heads[0], 1u)] = i;
+        else if (c > (uint32_t)kSortGroupMax) v.big_list[atomicAdd(&s_heads[2], 1u)] = i;
         else if (c > (uint32_t)kSortWaveMax) v.medium_list[atomicAdd(&s_heads[1], 1u)] = i;
     }
     uint32_t ref = 0;
@@ -393,6 +394,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         c->num_rendered = nr;
         c->large_tiles = s_heads[0];
         c->medium_tiles = s_heads[1];
+        c->big_tiles = s_heads[2];
         c->num_instances = total;
         c->max_tile_list = m;
         c->overflow = overflow ? 1u : 0u;

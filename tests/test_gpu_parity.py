@@ -145,16 +145,24 @@ def test_binning_capacity_regrow(gpu_device):
     torch.cuda.synchronize()
 
 
-def test_long_tile_lists_take_the_slow_sort(gpu_device):
-    """> 1024 Gaussians on one 8x8 tile: exercises the global-memory sorter; result must still match."""
+@pytest.mark.parametrize("P,lo,hi", [(700, 256, 1024), (3000, 1024, 4096), (6000, 4096, 1 << 30)])
+def test_long_tile_lists_take_the_multi_wave_and_fallback_sorts(P, lo, hi, gpu_device):
+    """Many Gaussians on one 8x8 tile: the 4-wave register sorts (<= 1024, <= 4096 keys) and the global-memory
+    fallback (> 4096) must give the same blend order as the oracle (equal depths included: ties break by id)."""
     rng = np.random.default_rng(3)
-    s = scenes.random_scene(3000, 32, 32, sh_degree=0, seed=9, spread=0.004, scale_lo=0.002, scale_hi=0.004,
+    s = scenes.random_scene(P, 32, 32, sh_degree=0, seed=9, spread=0.004, scale_lo=0.002, scale_hi=0.004,
                             opacity_lo=0.02, opacity_hi=0.05)
     s.means3D[:, 2] = 1.0 + rng.uniform(0, 0.5, s.P).astype(np.float32)
+    s.means3D[::7, 2] = 1.25  # exact depth ties
     o = util.oracle_forward(s)
     h = util.HipFrame(s, gpu_device)
-    assert h.counts.max_tile_list > 1024
+    assert lo < h.counts.max_tile_list <= hi, h.counts.max_tile_list
     _check_forward(o, h, "long_lists")
+    dpix = (rng.uniform(-1, 1, (3, 32, 32)) / (32 * 32)).astype(np.float32)
+    from oracle import oracle
+    ob, hb = oracle.backward(o, dpix), h.backward(dpix)
+    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 2e-4
+    assert util.rel_l2(hb["dL_dopacity"], ob.dL_dopacity) < 2e-4
 
 
 def test_mark_visible(gpu_device):
