@@ -23,10 +23,15 @@ FR_FLAG_RAW_ACTIVATIONS = 2
 _fp = C.c_void_p  # device pointers travel as integers
 
 
+class fr_aux(C.Structure):
+    _fields_ = [("visible", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p)]
+
+
 class fr_params(C.Structure):
     _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
-                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("flags", C.c_int32)]
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("flags", C.c_int32),
+                ("aux", C.POINTER(fr_aux))]
 
 
 class fr_inputs(C.Structure):

@@ -96,6 +96,7 @@ int fr_destroy(fr_handle* hh)
             (void)hipEventDestroy(h->ev[st].stop[i]);
         }
     (void)hipHostFree(h->host_counts);
+    if (h->tile_counters) (void)hipFree(h->tile_counters);
     delete h;
     return FR_OK;
 }

@@ -256,19 +256,21 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
     }
 }
 
-// Grid: Q = ceil(T/4) workgroups of 4 waves, followed by kLargeSorters workgroups that drain the queue of
-// lists longer than kSortRegMax.  Workgroup b owns tiles {b, b+Q, b+2Q, b+3Q} (strided, so that the dense
-// neighbouring tiles of one image region land in different workgroups): every wave first sorts its own
-// tile if the list fits one wave (<= 256), then the four waves sort the longer lists (<= 1024) together.
+// Grid: kMediumSorters workgroups that sort the medium lists (257..1024 keys, four waves per list, static
+// round-robin over the list the scan kernel built), followed by Q = ceil(T/4) workgroups of 4 waves for the
+// short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
+// image region land in different workgroups) and sorts it in registers if it has <= 256 keys.  Lists longer
+// than 1024 are left to k_tile_sort_big.
 constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
-                                                   GeomView g)
+                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap)
 {
     __shared__ SortXchgT<4> sx;
-    if (v.counts->overflow) return;
-    // longest jobs first in dispatch order: medium lists, then the (rare) over-long ones, then the short ones
+    const bool overflow = v.counts->overflow != 0;
+    // longest jobs first in dispatch order: medium lists, then the short ones
     if (blockIdx.x < kMediumSorters) {
+        if (overflow) return;
         // medium lists (<= 1024): four waves each, static round-robin over the list built by the scan kernel
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -284,8 +286,15 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     {
         const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
         if (tile < T) {
+            // the binning counters of this tile have been consumed (scan, emit): leave them zeroed for the next frame
+            if (lane == 0) *reinterpret_cast<uint2*>(v.tile_count + (size_t)tile * kCounterStride) = make_uint2(0u, 0u);
+            if (overflow) return;
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_offset[tile + 1] - start;
+            // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
+            const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
+            for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
+                if (u0 + k < unit_cap) unit_tile[u0 + k] = make_uint4(tile, k, start, n);
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
                 if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
                 else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
@@ -729,7 +738,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     {
         StageScope sc(h, ST_SORT, s);
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
-                           (u64*)b.keys, b.recs, g);  // small_blocks == Q
+                           (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap);  // small_blocks == Q
         hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());

@@ -100,10 +100,12 @@ struct DeviceCounts {  // lives at the head of the image buffer
 
 struct ImageView {
     DeviceCounts* counts;
+    // The per-tile counters do NOT live in the image buffer: they belong to the handle (fr_handle_impl::tile_counters),
+    // are zero between frames (k_tile_sort re-zeroes each tile's line once it is done with it) and so need no
+    // zeroing launch per frame.  launch_forward points these two members at them.
     uint32_t* tile_count;    // [T*kCounterStride] per 8x8 tile: instances with a remembered position (one counter per 64-B line)
     uint32_t* tile_over;     // [T*kCounterStride] per 8x8 tile: instances beyond kInlineSlots of their Gaussian
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
-    uint32_t* tile_cursor;   // [T*kCounterStride] emit cursors (start at tile_offset), one per 64-B line
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
     uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
     uint32_t* big_list;      // [T]   ids of tiles with kSortGroupMax < entries <= kSortRegMax
@@ -119,10 +121,8 @@ struct ImageView {
         v.tiles_y = (H + kTile - 1) / kTile;
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
-        v.tile_count = carve<uint32_t>(p, T * kCounterStride);
-        v.tile_over = v.tile_count + 1;  // same 64-B line as the tile's main counter (rarely touched)
+        v.tile_count = v.tile_over = nullptr;
         v.tile_offset = carve<uint32_t>(p, T + 1);
-        v.tile_cursor = carve<uint32_t>(p, T * kCounterStride);
         v.large_list = carve<uint32_t>(p, T);
         v.medium_list = carve<uint32_t>(p, T);
         v.big_list = carve<uint32_t>(p, T);
@@ -135,12 +135,6 @@ struct ImageView {
     {
         ImageView v = make(nullptr, W, H);
         return reinterpret_cast<size_t>(v.n_contrib + (size_t)W * H) + 256;
-    }
-    // bytes from the start of the buffer that must be zero before a forward (counts + tile_count)
-    size_t zero_bytes(const void* base) const
-    {
-        size_t T = (size_t)tiles_x * tiles_y;
-        return reinterpret_cast<const char*>(tile_count + T * kCounterStride) - static_cast<const char*>(base);
     }
 };
 
@@ -190,6 +184,10 @@ struct fr_handle_impl {
     fr_counts* host_counts;      // pinned, mapped
     fr_counts* host_counts_dev;  // device view of the same memory
     hipEvent_t counts_ready;
+    // per-tile instance counters (see ImageView): device memory owned by the handle, all zero between frames
+    uint32_t* tile_counters = nullptr;
+    size_t tile_counter_tiles = 0;
+    bool counters_clean = false;
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];
 };

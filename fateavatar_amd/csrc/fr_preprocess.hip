@@ -30,6 +30,7 @@ struct PreArgs {
     const float* proj;
     const float* campos;
     int* radii;
+    uint8_t* visible;       // optional (fr_aux): radii > 0
     GeomView g;
     uint32_t* tile_count;
     uint32_t* tile_over;
@@ -112,6 +113,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     uint2 rect = make_uint2(0u, 0u);
     if (idx < a.P) {
         int radius_out = 0;
+        {   // the blend backward ADDS into this row (9 of its 16 floats); k_preprocess_bwd zeroes it again after reading
+            float4* acc = reinterpret_cast<float4*>(a.g.accum + (size_t)idx * kAccumStride);
+            acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         do {
             const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
             // near cull only (auxiliary.h:154)
@@ -255,6 +260,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
         } while (false);
         a.radii[idx] = radius_out;
+        if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
         a.g.rect[idx] = rect;
     }
     // ---- count the (tile, Gaussian) instances.  The atomic that counts an instance also hands out its
@@ -306,9 +312,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 // Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
 // (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
 // the unit -> tile table and builds the list of tiles too long for the in-register sort.
-__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity, uint4* unit_tile,
-                                                     uint32_t unit_cap, const uint32_t* block_ref_tiles,
-                                                     uint32_t n_blocks, fr_counts* host_counts)
+__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity,
+                                                     const uint32_t* block_ref_tiles, uint32_t n_blocks,
+                                                     fr_counts* host_counts)
 {
     __shared__ uint32_t s_ref[16];
     __shared__ uint32_t s_heads[3];
@@ -372,16 +378,13 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     for (uint32_t i = b; i < e; i++) {
         const uint2 c2 = (i - b < (uint32_t)kCache) ? cc[(i - b) & (kCache - 1)]
                                                     : *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride);
-        const uint32_t ci = c2.x, c = c2.x + c2.y;
+        // (the unit descriptors are written by k_tile_sort, one coalesced store per tile: scattered stores from
+        // this single workgroup were most of its run time)
+        const uint32_t c = c2.x + c2.y;
         v.tile_offset[i] = run;
-        v.tile_cursor[(size_t)i * kCounterStride] = run + ci;  // the un-remembered instances go behind the remembered ones
         v.unit_offset[i] = urun;
-        const uint32_t nu = (c + kUnit - 1) / kUnit;
-        if (!overflow)
-            for (uint32_t k = 0; k < nu; k++)
-                if (urun + k < unit_cap) unit_tile[urun + k] = make_uint4(i, k, run, c);
         run += c;
-        urun += nu;
+        urun += (c + kUnit - 1) / kUnit;
     }
     if (tid == 1023) {
         uint32_t m = 0;
@@ -458,8 +461,9 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
         uint32_t slot;
         if (j < (uint32_t)kInlineSlots)
             slot = v.tile_offset[tile] + g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
-        else
-            slot = atomicAdd(&v.tile_cursor[(size_t)tile * kCounterStride], 1u);
+        else  // un-remembered instances go behind the remembered ones; the overflow counter counts back down to 0
+            slot = v.tile_offset[tile] + v.tile_count[(size_t)tile * kCounterStride] +
+                   (atomicSub(&v.tile_over[(size_t)tile * kCounterStride], 1u) - 1u);
         keys[slot] = s_key[wave][lo];
     }
 }
@@ -505,7 +509,20 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     const bool debug = prm.debug != 0;
     int rc;
 
-    if ((rc = launch_zero(image, v.zero_bytes(image), s))) return rc;
+    // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
+    // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
+    // stream is being captured into a graph: run one eager frame of the same size first.
+    if (T > h->tile_counter_tiles) {
+        if (h->tile_counters) FR_HIP(hipFree(h->tile_counters));
+        h->tile_counters = nullptr, h->tile_counter_tiles = 0;
+        FR_HIP(hipMalloc(&h->tile_counters, (size_t)T * kCounterStride * sizeof(uint32_t)));
+        h->tile_counter_tiles = T;
+        h->counters_clean = false;
+    }
+    if (!h->counters_clean)
+        if ((rc = launch_zero(h->tile_counters, h->tile_counter_tiles * kCounterStride * sizeof(uint32_t), s))) return rc;
+    h->counters_clean = false;  // until every stage of this frame has been enqueued
+    v.tile_count = h->tile_counters, v.tile_over = h->tile_counters + 1;  // same 64-B line (the second is rarely touched)
 
     PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
@@ -517,6 +534,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.opacities = in.opacities;
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
+    a.visible = prm.aux ? prm.aux->visible : nullptr;
     a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.tile_over = v.tile_over, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
@@ -531,8 +549,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     {
         StageScope sc(h, ST_SCAN, s);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, b.unit_tile, (uint32_t)b.unit_cap,
-                           g.block_ref_tiles, (uint32_t)((P + 255) / 256), h->host_counts_dev);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, g.block_ref_tiles,
+                           (uint32_t)((P + 255) / 256), h->host_counts_dev);
     }
     FR_HIP(hipGetLastError());
     const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
@@ -547,6 +565,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
         if ((rc = debug_sync(debug, s, "emit_instances"))) return rc;
     }
     if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
+    h->counters_clean = true;
 
     if (no_wait) return FR_OK;
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).

@@ -31,6 +31,8 @@ struct PreBwdArgs {
     const int* radii;
     GeomView g;
     fr_grads out;
+    float* grad_accum;  // optional (fr_aux): += ||dL_dmeans2D[:, :2]|| of visible Gaussians
+    float* denom;       // optional (fr_aux): += 1 for visible Gaussians
 };
 
 __device__ __forceinline__ void store3(float* p, size_t i, float a, float b, float c)
@@ -60,7 +62,16 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
         return;
     }
-    const float* acc = a.g.accum + i * kAccumStride;
+    // read the accumulator row and leave it zeroed for the next backward over this frame (the forward zeroed it
+    // the first time): no separate zeroing launch
+    float acc[12];
+    {
+        float4* row4 = reinterpret_cast<float4*>(a.g.accum + i * kAccumStride);
+        const float4 r0 = row4[0], r1 = row4[1], r2 = row4[2];
+        row4[0] = row4[1] = row4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[0] = r0.x, acc[1] = r0.y, acc[2] = r0.z, acc[3] = r0.w, acc[4] = r1.x, acc[5] = r1.y, acc[6] = r1.z,
+        acc[7] = r1.w, acc[8] = r2.x, acc[9] = r2.y, acc[10] = r2.z, acc[11] = r2.w;
+    }
     // moments of q = dL/dG * G accumulated by the blend backward -> the reference's per-Gaussian sums
     // (backward.cu:538-554): dG/ddelx = -G*(dx*A + dy*B), dG/ddely = -G*(dy*C + dx*B)
     const float4 co = a.g.conic_opacity[idx];
@@ -71,6 +82,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
     const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
     store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f);
+    // fused _add_densification_stats (model/fateavatar.py:734-737); this branch is radii > 0
+    if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
+    if (a.denom) a.denom[i] += 1.0f;
     store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2]);
     // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
     if (a.out.dL_dopacity) a.out.dL_dopacity[i] = a.raw ? dop * co.w * (1.0f - co.w) : dop;
@@ -376,9 +390,8 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     GeomView g = GeomView::make(geometry, (size_t)P);
     ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
     const bool debug = prm.debug != 0;
-    int rc = launch_zero(g.accum, sizeof(float) * (size_t)P * kAccumStride, s);
-    if (rc) return rc;
-    rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
+    // g.accum is all zero here: zeroed by k_preprocess_fwd, and again by k_preprocess_bwd after every backward
+    int rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
     if (rc) return rc;
 
     PreBwdArgs a;
@@ -391,6 +404,8 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.shs = in.shs;
     a.cov3D_precomp = in.cov3D_precomp, a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.radii = radii, a.g = g, a.out = gr;
+    a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
+    a.denom = prm.aux ? prm.aux->denom : nullptr;
     {
         StageScope sc(h, ST_PREPROCESS_BWD, s);
         const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)4 * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;

@@ -77,10 +77,25 @@ def check_async_overflow(device_index: int = 0) -> bool:
     return bool(c.overflow)
 
 
-def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw=False) -> _lib.fr_params:
+def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw=False,
+            aux=None) -> _lib.fr_params:
     flags = (_lib.FR_FLAG_NO_WAIT if _no_wait else 0) | (_lib.FR_FLAG_RAW_ACTIVATIONS if raw else 0)
-    return _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
-                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)), flags)
+    prm = _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
+                         float(scale_modifier), int(bool(prefiltered)), int(bool(debug)), flags)
+    if aux is not None:
+        prm._aux_keepalive = aux
+        prm.aux = C.pointer(aux)
+    return prm
+
+
+def _aux(visible=None, grad_accum=None, denom=None):
+    """fr_aux (optional fused side outputs) from torch tensors, or None if nothing is asked for."""
+    if visible is None and grad_accum is None and denom is None:
+        return None
+    for t, dt in ((visible, (torch.bool, torch.uint8)), (grad_accum, (torch.float32,)), (denom, (torch.float32,))):
+        if t is not None and (t.dtype not in dt or not t.is_contiguous() or not t.is_cuda):
+            raise RuntimeError("fused side outputs must be contiguous device tensors (bool/uint8 mask, float32 stats)")
+    return _lib.fr_aux(*(t.data_ptr() if t is not None else None for t in (visible, grad_accum, denom)))
 
 
 def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
@@ -90,7 +105,7 @@ def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, _raw=False):
+                        prefiltered, debug, _raw=False, _visible=None):
     """`_C.rasterize_gaussians` (rasterize_points.cu:35-115).  `_raw=True` (extension, FR_FLAG_RAW_ACTIVATIONS):
     opacity / scales / rotations are the RAW parameters and the kernels apply sigmoid / exp / normalize.
 
@@ -114,7 +129,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
     L = _lib.lib()
     h = _lib.handle(dev)
-    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, _raw)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, _raw,
+                  _aux(visible=_visible))
     inp = _inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
     geom = torch.empty((L.fr_geometry_bytes(P),), dtype=torch.uint8, **opts)
@@ -141,11 +157,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None, _raw=False):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None, _raw=False,
+                                 _stats=None):
     """`_C.rasterize_gaussians_backward` (rasterize_points.cu:117-196).
 
     Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
-    dL_dscales[P,3], dL_drotations[P,4])."""
+    dL_dscales[P,3], dL_drotations[P,4]).  `_stats=(xyz_gradient_accum[P,1], denom[P,1])` (extension): the kernel
+    also does `_add_densification_stats` (model/fateavatar.py:734-737) for the Gaussians with radii > 0."""
     dev = _dev_index(means3D)
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -173,7 +191,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
     L = _lib.lib()
     h = _lib.handle(dev)
-    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw)
+    aux = _aux(grad_accum=_stats[0], denom=_stats[1]) if _stats is not None else None
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw, aux)
     inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
     grads = _lib.fr_grads(*[_ptr(g[k]) for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D",
@@ -225,19 +244,31 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings, raw_activations=False):
         rs = raster_settings
         ctx.raw = bool(raw_activations)
+        # the gradient slot of the int32 `radii` output would otherwise be materialised as a zero tensor per backward
+        ctx.set_materialize_grads(False)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        # extension: the visibility mask (radii > 0) comes out of the preprocess kernel; render() picks it up from
+        # `radii._fr_visible` instead of launching a compare kernel
+        vis = torch.empty((means3D.shape[0],), dtype=torch.bool, device=means3D.device) if means3D.is_cuda else None
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args, _raw=ctx.raw)
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = \
+                    rasterize_gaussians(*args, _raw=ctx.raw, _visible=vis)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians(*args, _raw=ctx.raw)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = \
+                rasterize_gaussians(*args, _raw=ctx.raw, _visible=vis)
+        if vis is not None and means3D.shape[0] > 0:
+            radii._fr_visible = vis
+        # extension: `means2D._fr_densification_stats = (xyz_gradient_accum, denom)` makes the backward kernel
+        # accumulate the densification statistics itself
+        ctx.stats = getattr(means2D, "_fr_densification_stats", None)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # optional extension: an input tensor may carry `_fr_grad_out`, a preallocated buffer that receives its
@@ -257,6 +288,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _):
         num_rendered = ctx.num_rendered
         rs = ctx.raster_settings
+        if grad_out_color is None:
+            return (None,) * 10
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
             ctx.saved_tensors
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -265,13 +298,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw)
+                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw, _stats=ctx.stats)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw)
+            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw, _stats=ctx.stats)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

@@ -14,11 +14,32 @@ import torch
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_zero_cache = {}
+
+
+def _zero_points(means3D: torch.Tensor) -> torch.Tensor:
+    """A fresh leaf tensor of zeros shaped like means3D that requires grad.  Nothing ever writes its values (the
+    rasterizer only uses it as the slot whose .grad receives dL/dmeans2D), so the zeros themselves are a cached
+    constant per (shape, dtype, device) and every call returns a new leaf aliasing them: no fill kernel per frame."""
+    key = (tuple(means3D.shape), means3D.dtype, means3D.device)
+    z = _zero_cache.get(key)
+    if z is None:
+        if len(_zero_cache) > 8:
+            _zero_cache.clear()
+        z = _zero_cache[key] = torch.zeros_like(means3D, requires_grad=False)
+    return z.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color: torch.Tensor = None,
            device='cuda'):
     means3D = pc.get_xyz
-    # zero tensor whose .grad receives the screen-space mean gradients (render_3dgs.py:21-27)
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
+    # zero tensor whose .grad receives the screen-space mean gradients (render_3dgs.py:21-27).  The reference adds
+    # `+ 0` and retains the gradient of the resulting non-leaf; a leaf collects the same .grad with one kernel less
+    # and lets autograd adopt the rasterizer's gradient buffer instead of copying it.
+    screenspace_points = _zero_points(means3D)
+    stats = getattr(pc, "fused_densification_stats", None)
+    if stats is not None:  # extension: (xyz_gradient_accum, denom) updated inside the backward kernel
+        screenspace_points._fr_densification_stats = stats
     if screenspace_points.requires_grad:
         try:
             screenspace_points.retain_grad()
@@ -63,5 +84,6 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, o
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations,
                                        cov3D_precomp=cov3D_precomp, **({"raw_activations": True} if fused else {}))
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii}
+    visible = getattr(radii, "_fr_visible", None)  # written by the preprocess kernel (same values as radii > 0)
+    return {"render": rendered_image, "viewspace_points": screenspace_points,
+            "visibility_filter": visible if visible is not None else radii > 0, "radii": radii}

@@ -52,7 +52,21 @@ extern "C" {
 #define FR_ERR_HIP 3              /* a HIP runtime call failed; see fr_last_error() */
 #define FR_ERR_UNSUPPORTED 4
 
-typedef struct fr_handle fr_handle; /* per-device context: pinned count slots, events */
+/* Per-device context: pinned count slot, event, and the per-tile binning counters (device memory, kept zero
+ * between frames so that a frame needs no zeroing launch).  Calls on one handle must be issued by one host thread
+ * and be ordered on the stream(s) they are enqueued on: two fr_forward calls of the same handle must not run
+ * concurrently.  The counters grow with the tile grid (hipMalloc — not while the stream is being captured into a
+ * hipGraph: run one eager frame of that image size first). */
+typedef struct fr_handle fr_handle;
+
+/* Optional fused side outputs: per-Gaussian values the caller's step otherwise derives
+ * from the rasterizer's outputs with extra elementwise kernels.  Device pointers; any member may be NULL. */
+typedef struct fr_aux {
+    uint8_t* visible;   /* fr_forward  out    [P]: radii > 0, i.e. render()'s visibility_filter (render_3dgs.py:80) */
+    float* grad_accum;  /* fr_backward in/out [P]: += ||dL_dmeans2D[i,:2]|| where radii > 0 — xyz_gradient_accum of
+                           _add_densification_stats (model/fateavatar.py:734-737) */
+    float* denom;       /* fr_backward in/out [P]: += 1 where radii > 0 (same function) */
+} fr_aux;
 
 /* Frame parameters: the scalar arguments of Rasterizer::forward/backward. */
 typedef struct fr_params {
@@ -65,6 +79,7 @@ typedef struct fr_params {
     int32_t prefiltered;  /* accepted for interface parity; the near-plane cull is always applied */
     int32_t debug;        /* !=0: synchronise and check after every stage (auxiliary.h:166-173) */
     int32_t flags;        /* FR_FLAG_* */
+    const fr_aux* aux;    /* optional fused side outputs (host pointer to a struct of device pointers), or NULL */
 } fr_params;
 
 /* fr_forward does not wait for the frame counts: nothing in the call blocks or touches an event, so it can

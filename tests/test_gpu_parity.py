@@ -243,6 +243,35 @@ def test_render_api_autograd_path(gpu_device):
     assert util.rel_l2(pc.grad_of("_scaling").cpu().numpy(), b.dL_dscales * sc) < 2e-4
 
 
+def test_fused_visibility_mask_and_densification_stats(gpu_device):
+    """fr_aux: the bool mask written by the preprocess kernel == radii > 0, and the statistics the backward kernel
+    accumulates == _add_densification_stats (model/fateavatar.py:734-737) done with torch on the same gradients."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    P = 8000
+    s0 = scenes.head_scene(P=P, res=128, sh_degree=1, seed=2)
+    pc = FlatGaussians(s0.means3D, s0.shs, s0.opacities, s0.scales, s0.rotations, 1, gpu_device)
+    accum = torch.zeros((P, 1), device=gpu_device)
+    denom = torch.zeros((P, 1), device=gpu_device)
+    ref_accum, ref_denom = torch.zeros_like(accum), torch.zeros_like(denom)
+    pc.fused_densification_stats = (accum, denom)
+    rng = np.random.default_rng(5)
+    for view in range(3):
+        s = scenes.head_scene(P=P, res=128, sh_degree=1, seed=2, view=view, n_views=3)
+        out = render(TorchCamera(s.camera, gpu_device), pc, torch.from_numpy(s.bg).to(gpu_device))
+        w = torch.from_numpy((rng.uniform(-1, 1, (3, 128, 128)) / (128 * 128)).astype(np.float32)).to(gpu_device)
+        pc.begin_step()
+        torch.autograd.backward(out["render"], grad_tensors=w)
+        vis = out["visibility_filter"]
+        assert vis.dtype == torch.bool and torch.equal(vis, out["radii"] > 0) and 0 < int(vis.sum()) < P
+        g = out["viewspace_points"].grad
+        ref_accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)
+        ref_denom[vis] += 1
+    assert torch.equal(denom, ref_denom) and float(denom.max()) == 3.0
+    assert torch.allclose(accum, ref_accum, rtol=1e-5, atol=0.0) and float(accum.max()) > 0
+
+
 def test_fused_activations_match_torch_activations(gpu_device):
     """render() with raw parameters + in-kernel sigmoid/exp/normalize == render() with PyTorch activations
     (which the oracle tests pin), forward and every raw-parameter gradient."""
