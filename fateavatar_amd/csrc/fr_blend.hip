@@ -587,10 +587,28 @@ __device__ __forceinline__ float swap16_add(float a, float b)
 __device__ __forceinline__ float reduce_scatter_36(const float (&r)[36], int lane)
 {
     float a[18], b[9], c[5], d[3], e[2];
+    // the swaps exchange halves (quarters) of two registers in place; the additions that follow are independent,
+    // so two of them go into one packed v_pk_add_f32
+    typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 18; i++) a[i] = swap32_add(r[2 * i], r[2 * i + 1]);  // lane bit 5 <- value bit 0
+    for (int i = 0; i < 18; i += 2) {                                        // lane bit 5 <- value bit 0
+        auto p0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r[2 * i]), __builtin_bit_cast(unsigned, r[2 * i + 1]), false, false);
+        auto p1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r[2 * i + 2]), __builtin_bit_cast(unsigned, r[2 * i + 3]), false, false);
+        const v2f x = {__builtin_bit_cast(float, (unsigned)p0[0]), __builtin_bit_cast(float, (unsigned)p1[0])};
+        const v2f y = {__builtin_bit_cast(float, (unsigned)p0[1]), __builtin_bit_cast(float, (unsigned)p1[1])};
+        const v2f z = x + y;
+        a[i] = z.x, a[i + 1] = z.y;
+    }
 #pragma unroll
-    for (int i = 0; i < 9; i++) b[i] = swap16_add(a[2 * i], a[2 * i + 1]);   // lane bit 4 <- value bit 1
+    for (int i = 0; i < 8; i += 2) {                                         // lane bit 4 <- value bit 1
+        auto p0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a[2 * i]), __builtin_bit_cast(unsigned, a[2 * i + 1]), false, false);
+        auto p1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a[2 * i + 2]), __builtin_bit_cast(unsigned, a[2 * i + 3]), false, false);
+        const v2f x = {__builtin_bit_cast(float, (unsigned)p0[0]), __builtin_bit_cast(float, (unsigned)p1[0])};
+        const v2f y = {__builtin_bit_cast(float, (unsigned)p0[1]), __builtin_bit_cast(float, (unsigned)p1[1])};
+        const v2f z = x + y;
+        b[i] = z.x, b[i + 1] = z.y;
+    }
+    b[8] = swap16_add(a[16], a[17]);
     const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {                                            // lane bit 3 <- value bit 2
@@ -641,26 +659,27 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
     float dpr = 0.f, dpg = 0.f, dpb = 0.f;
     if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
     const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
-    float acc_r = st.x, acc_g = st.y, acc_b = st.z;  // accum_rec entering the unit from behind
+    // The reference's accum_rec (colour blended behind the current Gaussian, backward.cu:515) only ever enters
+    // through its dot product with dL/dpixel, and its recurrence is linear: carry that scalar instead of three
+    // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
+    float A = (st.x * dpr + st.y * dpg) + st.z * dpb;
     const int m = (int)ui.m;
 
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
-        float G[kGroup], alpha[kGroup], dx[kGroup], dy[kGroup];
-        float4 q0[kGroup], q1[kGroup];
-        float q2x[kGroup];
+        float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup];
         bool ok[kGroup];
         bool any_ok = false;
 #pragma unroll
         for (int k = 0; k < kGroup; k++) {
-            q0[k] = s_rec[(j + k) * kRecQuads + 0];
-            q1[k] = s_rec[(j + k) * kRecQuads + 1];
-            q2x[k] = s_rec[(j + k) * kRecQuads + 2].x;
-            dx[k] = q0[k].x - fx, dy[k] = q0[k].y - fy;
-            const float power = -0.5f * (q0[k].z * dx[k] * dx[k] + q1[k].x * dy[k] * dy[k]) - q0[k].w * dx[k] * dy[k];
-            G[k] = __expf(power);
-            alpha[k] = fminf(0.99f, q1[k].y * G[k]);
-            ok[k] = (ui.base + (uint32_t)(j + k) < last) && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+            const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
+            const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
+            const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
+            dx[k] = q0.x - fx, dy[k] = q0.y - fy;
+            const float power = -0.5f * (q0.z * dx[k] * dx[k] + q1.x * dy[k] * dy[k]) - q0.w * dx[k] * dy[k];
+            araw[k] = q1.y * __expf(power);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
+            ok[k] = (ui.base + (uint32_t)(j + k) < last) && !(power > 0.0f) && !(araw[k] < 1.0f / 255.0f);
             any_ok = any_ok || ok[k];
+            cd[k] = (q1.z * dpr + q1.w * dpg) + q2x * dpb;  // colour . dL_dpixel
         }
         if (!__any(any_ok)) continue;
 
@@ -669,20 +688,18 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
         for (int k = kGroup - 1; k >= 0; k--) {  // back to front
             // Lanes that fail the tests take alpha = G = 0: every state update below is then the identity and
             // every partial gradient is zero, so nothing needs a per-lane select.
-            const float a_e = ok[k] ? alpha[k] : 0.f;
-            const float G_e = ok[k] ? G[k] : 0.f;
+            const float ar_e = ok[k] ? araw[k] : 0.f;   // opacity * G, or 0
+            const float a_e = fminf(0.99f, ar_e);        // alpha, or 0
             const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
             T *= inv;  // transmittance in front of this Gaussian (backward.cu:503)
-            // (acc_r, acc_g, acc_b) is the reference's accum_rec as this Gaussian sees it: the colour blended
-            // behind it (backward.cu:515)
-            const float er = q1[k].z - acc_r, eg = q1[k].w - acc_g, eb = q2x[k] - acc_b;
-            float dL_dalpha = (er * dpr + eg * dpg) + eb * dpb;
-            dL_dalpha = dL_dalpha * T + (-T_final * inv) * bg_dot_dpixel;  // backward.cu:525-534
-            acc_r += a_e * er, acc_g += a_e * eg, acc_b += a_e * eb;       // accum_rec for the next (closer) Gaussian
-            const float wgt = a_e * T;                                     // dchannel_dcolor
-            // q = dL_dG * G.  The reference's per-pair updates are all q times a monomial of (dx, dy); their
+            const float e = cd[k] - A;                   // (colour - accum_rec) . dL_dpixel
+            const float dL_dalpha = e * T + (-T_final * inv) * bg_dot_dpixel;  // backward.cu:525-534
+            A += a_e * e;                                // accum_rec for the next (closer) Gaussian
+            const float wgt = a_e * T;                   // dchannel_dcolor
+            // q = dL_dG * G = (opacity * dL_dalpha) * G: the gradient ignores the 0.99 clamp, as the reference
+            // does.  The reference's per-pair updates are all q times a monomial of (dx, dy); their
             // combination with the conic / opacity happens once per Gaussian in k_preprocess_bwd.
-            const float q = (q1[k].y * dL_dalpha) * G_e;
+            const float q = dL_dalpha * ar_e;
             const float qdx = q * dx[k], qdy = q * dy[k];
             float* su = s + k * 9;
             su[ACC_MX] = qdx;

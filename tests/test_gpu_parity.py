@@ -251,6 +251,7 @@ def test_fused_visibility_mask_and_densification_stats(gpu_device):
     from fateavatar_amd.render import render
     P = 8000
     s0 = scenes.head_scene(P=P, res=128, sh_degree=1, seed=2)
+    s0.means3D[::5, 0] += 50.0  # every fifth Gaussian far off screen: culled, radii == 0
     pc = FlatGaussians(s0.means3D, s0.shs, s0.opacities, s0.scales, s0.rotations, 1, gpu_device)
     accum = torch.zeros((P, 1), device=gpu_device)
     denom = torch.zeros((P, 1), device=gpu_device)
