@@ -146,8 +146,11 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
     const float4 co = g.conic_opacity[id];
     const float4 c = g.rgba[id];
     float4* r = recs + (size_t)pos * kRecQuads;
-    r[0] = make_float4(xy.x, xy.y, co.x, co.y);
-    r[1] = make_float4(co.z, co.w, c.x, c.y);
+    // the conic is stored pre-scaled so that the blend loops get log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into
+    // v_exp_f32 (two multiplies less per pixel x Gaussian pair): a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
+    constexpr float kLog2e = 1.4426950408889634f;
+    r[0] = make_float4(xy.x, xy.y, co.x * (-0.5f * kLog2e), co.y * (-kLog2e));
+    r[1] = make_float4(co.z * (-0.5f * kLog2e), co.w, c.x, c.y);
     r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);
 }
 
@@ -336,6 +339,15 @@ constexpr int kBatch = 64;
 constexpr uint32_t kUnitGrid = 2048;  // workgroups (of 4 waves) of the unit kernels: grid-stride over the unit count
 constexpr int kGroup = 4;
 
+// log2 of the Gaussian falloff of one (pixel, record) pair from the record's pre-scaled conic (write_record):
+// the reference's power = -0.5 (a dx^2 + c dy^2) - b dx dy (forward.cu:340), times log2(e)
+__device__ __forceinline__ float pair_log2G(float a2, float b2, float c2, float dx, float dy)
+{
+    float p = (a2 * dx) * dx;
+    p = fmaf(c2 * dy, dy, p);
+    return fmaf(b2 * dx, dy, p);
+}
+
 struct RecRegs {
     float4 q0, q1, q2;
 };
@@ -436,8 +448,8 @@ __global__ void __launch_bounds__(256) k_unit_tseg(const DeviceCounts* __restric
             const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
             const float2 q1 = *reinterpret_cast<const float2*>(&s_rec[(j + k) * kRecQuads + 1]);
             const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+            const float alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
             const bool ok = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             t = ok ? t * (1.f - alpha) : t;
         }
@@ -476,8 +488,8 @@ __global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restri
             const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
             const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
             const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-            alpha[k] = fminf(0.99f, q1.y * __expf(power));
+            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
             ok[k] = !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
             cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
         }
@@ -664,6 +676,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
     // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
     float A = (st.x * dpr + st.y * dpg) + st.z * dpb;
     const int m = (int)ui.m;
+    const int lim = (int)last - (int)ui.base;  // records of this unit at or behind the pixel's last contributor do nothing
 
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
         float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup];
@@ -675,9 +688,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
             const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
             const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
             dx[k] = q0.x - fx, dy[k] = q0.y - fy;
-            const float power = -0.5f * (q0.z * dx[k] * dx[k] + q1.x * dy[k] * dy[k]) - q0.w * dx[k] * dy[k];
-            araw[k] = q1.y * __expf(power);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
-            ok[k] = (ui.base + (uint32_t)(j + k) < last) && !(power > 0.0f) && !(araw[k] < 1.0f / 255.0f);
+            const float power = pair_log2G(q0.z, q0.w, q1.x, dx[k], dy[k]);
+            araw[k] = q1.y * __builtin_amdgcn_exp2f(power);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
+            ok[k] = (j + k < lim) && !(power > 0.0f) && !(araw[k] < 1.0f / 255.0f);
             any_ok = any_ok || ok[k];
             cd[k] = (q1.z * dpr + q1.w * dpg) + q2x * dpb;  // colour . dL_dpixel
         }
@@ -689,7 +702,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
             // Lanes that fail the tests take alpha = G = 0: every state update below is then the identity and
             // every partial gradient is zero, so nothing needs a per-lane select.
             const float ar_e = ok[k] ? araw[k] : 0.f;   // opacity * G, or 0
-            const float a_e = fminf(0.99f, ar_e);        // alpha, or 0
+            const float a_e = __builtin_amdgcn_fmed3f(ar_e, 0.f, 0.99f);  // alpha = min(0.99, .), or 0 (ar_e >= 0)
             const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
             T *= inv;  // transmittance in front of this Gaussian (backward.cu:503)
             const float e = cd[k] - A;                   // (colour - accum_rec) . dL_dpixel
