@@ -612,15 +612,8 @@ __device__ __forceinline__ float reduce_scatter_36(const float (&r)[36], int lan
         a[i] = z.x, a[i + 1] = z.y;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {                                         // lane bit 4 <- value bit 1
-        auto p0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a[2 * i]), __builtin_bit_cast(unsigned, a[2 * i + 1]), false, false);
-        auto p1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a[2 * i + 2]), __builtin_bit_cast(unsigned, a[2 * i + 3]), false, false);
-        const v2f x = {__builtin_bit_cast(float, (unsigned)p0[0]), __builtin_bit_cast(float, (unsigned)p1[0])};
-        const v2f y = {__builtin_bit_cast(float, (unsigned)p0[1]), __builtin_bit_cast(float, (unsigned)p1[1])};
-        const v2f z = x + y;
-        b[i] = z.x, b[i + 1] = z.y;
-    }
-    b[8] = swap16_add(a[16], a[17]);
+    for (int i = 0; i < 9; i++) b[i] = swap16_add(a[2 * i], a[2 * i + 1]);   // lane bit 4 <- value bit 1 (pairing these
+                                                                             // for packed adds costs more moves than it saves)
     const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {                                            // lane bit 3 <- value bit 2

@@ -56,6 +56,8 @@ struct GeomView {
     float* cov3D;           // [P*6]
     uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
+    float* cull_tau2;       // [P] threshold of the per-tile footprint test: a pixel can only reach alpha >= 1/255 where
+                            //     a dx^2 + 2 b dx dy + c dy^2 <= cull_tau2 (evaluation slack included; +inf = never cull)
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
     uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
     uint32_t* inline_slots;     // [P*kInlineSlots] position inside its tile's segment of each of a Gaussian's first
@@ -71,6 +73,7 @@ struct GeomView {
         g.cov3D = carve<float>(p, P * 6);
         g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
+        g.cull_tau2 = carve<float>(p, P);
         g.accum = carve<float>(p, P * kAccumStride);
         g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
         g.inline_slots = carve<uint32_t>(p, P * kInlineSlots);

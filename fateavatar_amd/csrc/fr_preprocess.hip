@@ -94,6 +94,33 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
     }
 }
 
+// Can any pixel centre of 8x8 tile (tx, ty) lie inside the alpha >= 1/255 footprint of a Gaussian?  The footprint is
+// the ellipse q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2 around `ctr`; the minimum of the convex q over the tile's
+// pixel rectangle is at the centre if that is inside, otherwise on an edge FACING the centre (walking from the
+// minimiser towards the centre decreases q and can only leave the rectangle through such an edge).  Evaluated in
+// double from the float geometry, so that k_preprocess_fwd (counting) and k_emit_instances (writing) take the same
+// decision; the slack for the blend kernels' fp32 arithmetic is inside tau2.
+__device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, const float2 ctr, uint32_t tx, uint32_t ty)
+{
+    if (!(conic_tau2.w < 3.0e38f)) return true;
+    const double A = conic_tau2.x, B = conic_tau2.y, C = conic_tau2.z, t2 = conic_tau2.w;
+    const double lox = (double)(tx * kTile) - (double)ctr.x, hix = lox + (double)(kTile - 1);
+    const double loy = (double)(ty * kTile) - (double)ctr.y, hiy = loy + (double)(kTile - 1);
+    const double qx = lox > 0.0 ? lox : (hix < 0.0 ? hix : 0.0);
+    const double qy = loy > 0.0 ? loy : (hiy < 0.0 ? hiy : 0.0);
+    if (qx == 0.0 && qy == 0.0) return true;
+    double qmin = 1.0e300;
+    if (qx != 0.0) {  // edge dx = qx: best dy = -b qx / c, clamped to the edge
+        const double dy = fmin(fmax(-B * qx / C, loy), hiy);
+        qmin = A * qx * qx + 2.0 * B * qx * dy + C * dy * dy;
+    }
+    if (qy != 0.0) {
+        const double dx = fmin(fmax(-B * qy / A, lox), hix);
+        qmin = fmin(qmin, A * dx * dx + 2.0 * B * dx * qy + C * qy * qy);
+    }
+    return qmin <= t2;
+}
+
 __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
@@ -111,6 +138,8 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     __syncthreads();
     uint32_t ref_tiles = 0;  // tiles_touched in reference semantics (16x16)
     uint2 rect = make_uint2(0u, 0u);
+    float4 cull = make_float4(0.f, 0.f, 0.f, __builtin_inff());  // conic + footprint threshold (per-tile culling)
+    float2 ctr = make_float2(0.f, 0.f);
     if (idx < a.P) {
         int radius_out = 0;
         {   // the blend backward ADDS into this row (9 of its 16 floats); k_preprocess_bwd zeroes it again after reading
@@ -253,8 +282,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                     if (x_hi < (double)px1) px1 = (int)fmax(x_hi, (double)px0 - 1.0);
                     if (y_lo > (double)py0) py0 = (int)fmin(y_lo, (double)py1 + 1.0);
                     if (y_hi < (double)py1) py1 = (int)fmax(y_hi, (double)py0 - 1.0);
+                    cull = make_float4(conic_a, conic_b, conic_c, (float)(2.0 * tau * (1.0 + 2e-7)));
                 }
             }
+            ctr = make_float2(pix_x, pix_y);
             if (px1 < px0 || py1 < py0) break;
             const int tx0 = px0 / kTile, tx1 = px1 / kTile + 1, ty0 = py0 / kTile, ty1 = py1 / kTile + 1;
             rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
@@ -262,6 +293,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         a.radii[idx] = radius_out;
         if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
         a.g.rect[idx] = rect;
+        a.g.cull_tau2[idx] = cull.w;
     }
     // ---- count the (tile, Gaussian) instances.  The atomic that counts an instance also hands out its
     // position inside the tile's segment, which is remembered (first kInlineSlots instances of a Gaussian) so
@@ -270,6 +302,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     {
         __shared__ uint32_t s_excl[4][64];
         __shared__ uint2 s_rect[4][64];
+        __shared__ float4 s_cull[4][64];
+        __shared__ float2 s_ctr[4][64];
+        s_cull[wave][lane] = cull;
+        s_ctr[wave][lane] = ctr;
         const int w = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), h = (int)(rect.y >> 16) - (int)(rect.x >> 16);
         const uint32_t n = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
         uint32_t incl = n;
@@ -282,21 +318,41 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         s_rect[wave][lane] = rect;
         __syncthreads();
         const int wave_first = blockIdx.x * 256 + wave * 64;
-        for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
-            int lo = 0, hi = 63;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+        // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
+        // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several)
+        constexpr int kCountUnroll = 4;
+        for (uint32_t k0 = (uint32_t)lane; k0 < total; k0 += 64 * kCountUnroll) {
+            uint32_t pos[kCountUnroll];
+            size_t where[kCountUnroll];
+            bool remember[kCountUnroll];
+#pragma unroll
+            for (int u = 0; u < kCountUnroll; u++) {
+                const uint32_t k = k0 + 64u * (uint32_t)u;
+                remember[u] = false;
+                pos[u] = 0, where[u] = 0;
+                if (k >= total) continue;
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                }
+                const uint2 rr = s_rect[wave][lo];
+                const uint32_t j = k - s_excl[wave][lo];
+                const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
+                const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
+                if (!footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;
+                const size_t t = (size_t)(ty * (uint32_t)a.tiles_x + tx) * kCounterStride;
+                if (j < (uint32_t)kInlineSlots) {
+                    pos[u] = atomicAdd(&a.tile_count[t], 1u);
+                    where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
+                    remember[u] = true;
+                } else {
+                    atomicAdd(&a.tile_over[t], 1u);
+                }
             }
-            const uint2 rr = s_rect[wave][lo];
-            const uint32_t j = k - s_excl[wave][lo];
-            const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
-            const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
-            const size_t t = (size_t)(ty * (uint32_t)a.tiles_x + tx) * kCounterStride;
-            if (j < (uint32_t)kInlineSlots)
-                a.g.inline_slots[(size_t)(wave_first + lo) * kInlineSlots + j] = atomicAdd(&a.tile_count[t], 1u);
-            else
-                atomicAdd(&a.tile_over[t], 1u);
+#pragma unroll
+            for (int u = 0; u < kCountUnroll; u++)
+                if (remember[u]) a.g.inline_slots[where[u]] = pos[u];
         }
     }
     // num_rendered in reference semantics: per-workgroup partial sums, added up by the scan kernel (a single
@@ -426,7 +482,12 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
     uint2 r = make_uint2(0u, 0u);
     uint32_t n = 0;
     uint64_t key = 0;
+    __shared__ float4 s_cull[4][64];
+    __shared__ float2 s_ctr[4][64];
     if (idx < P) {
+        const float4 co = g.conic_opacity[idx];
+        s_cull[wave][lane] = make_float4(co.x, co.y, co.z, g.cull_tau2[idx]);
+        s_ctr[wave][lane] = g.means2D[idx];
         r = g.rect[idx];
         const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
         if (w > 0 && h > 0) {
@@ -457,6 +518,7 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
         const uint32_t j = k - s_excl[wave][lo];
         const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, w = (rr.y & 0xffff) - x0;
         const uint32_t ty = y0 + j / w, tx = x0 + (j - (j / w) * w);
+        if (!footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;  // same test as the count
         const uint32_t tile = ty * (uint32_t)v.tiles_x + tx;
         uint32_t slot;
         if (j < (uint32_t)kInlineSlots)
