@@ -215,4 +215,23 @@ int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspac
     return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                 uint64_t n, float* state, void* stream)
+{
+    if (!cfg || cfg->n_segments < 1 || cfg->n_segments > FR_ADAM_MAX_SEGMENTS)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: 1..FR_ADAM_MAX_SEGMENTS segments");
+    if (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !state))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: null array");
+    uint64_t prev = 0;
+    for (int i = 0; i < cfg->n_segments; i++) {
+        if (cfg->segment_end[i] < prev) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: segment ends must ascend");
+        prev = cfg->segment_end[i];
+    }
+    if (prev != n) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: the last segment must end at n");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: arrays must be 16-byte aligned");
+    return launch_adam(*cfg, param, grad, exp_avg, exp_avg_sq, n, state, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

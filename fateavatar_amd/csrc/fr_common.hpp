@@ -232,6 +232,8 @@ size_t knn_workspace_bytes(int P);
 // memset NODE of a captured graph it stopped taking effect once an eager kernel had been launched between two
 // replays (ROCm 7.0 runtime shipped with PyTorch 2.10; reproduced with tools/dbg_graph.py).
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
+int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                unsigned long long n, float* state, hipStream_t s);
 int launch_selftest_reduce(const float* in, float* out, hipStream_t s);
 
 #if defined(__HIPCC__)

@@ -101,3 +101,12 @@ class TorchCamera:
         self.world_view_transform = torch.from_numpy(cam.world_view_transform).to(device)
         self.full_proj_transform = torch.from_numpy(cam.full_proj_transform).to(device)
         self.camera_center = torch.from_numpy(cam.camera_center).to(device)
+
+    def copy_from(self, other: "TorchCamera") -> None:
+        """Overwrite the matrices in place (same intrinsics): lets a captured HIP graph render a new view."""
+        if (other.image_height, other.image_width, other.FoVx, other.FoVy) != \
+                (self.image_height, self.image_width, self.FoVx, self.FoVy):
+            raise ValueError("copy_from needs a camera with the same image size and field of view")
+        self.world_view_transform.copy_(other.world_view_transform, non_blocking=True)
+        self.full_proj_transform.copy_(other.full_proj_transform, non_blocking=True)
+        self.camera_center.copy_(other.camera_center, non_blocking=True)

@@ -1,0 +1,68 @@
+"""Fused Adam over a flat parameter buffer.
+
+Replaces `torch.optim.Adam(groups, lr=0.0).step()` over the Gaussian parameter groups
+(reference: train/optim.py:11-37, called at train/iteration.py:58-60): same update rule and defaults
+(betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), ONE kernel over the flat buffer instead of
+a dozen `foreach` kernels, and nothing step-dependent on the host, so the step can sit inside a HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    """`segments`: consecutive (n_elements, lr) or (n_elements, lr, period, split, lr2) runs of the flat buffer —
+    the reference's param groups.  The 5-tuple form gives element e of the run lr if e % period < split else lr2
+    (SH coefficients stored [P, M, 3]: DC at lr, the rest at lr / 20, train/optim.py:49-50)."""
+
+    def __init__(self, flat_param: torch.Tensor, flat_grad: torch.Tensor, segments: Sequence[tuple],
+                 betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        if not (flat_param.is_cuda and flat_grad.is_cuda):
+            raise RuntimeError("FusedAdam needs device tensors (there is no CPU path)")
+        for t in (flat_param, flat_grad):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1:
+                raise RuntimeError("FusedAdam works on flat contiguous float32 buffers")
+        if flat_param.shape != flat_grad.shape:
+            raise RuntimeError("parameter and gradient buffers differ in size")
+        if not 1 <= len(segments) <= _lib.FR_ADAM_MAX_SEGMENTS:
+            raise RuntimeError(f"1..{_lib.FR_ADAM_MAX_SEGMENTS} segments")
+        self.param, self.grad = flat_param, flat_grad
+        self.exp_avg = torch.zeros_like(flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat_param)
+        self.state = torch.zeros(4, dtype=torch.float32, device=flat_param.device)  # step, 1 - beta1^t, 1 - beta2^t, -
+        cfg = _lib.fr_adam_config()
+        cfg.n_segments = len(segments)
+        end = 0
+        for i, seg in enumerate(segments):
+            n, lr = int(seg[0]), float(seg[1])
+            end += n
+            cfg.segment_end[i] = end
+            cfg.segment_lr[i] = lr
+            if len(seg) == 5:
+                cfg.segment_period[i], cfg.segment_split[i], cfg.segment_lr2[i] = int(seg[2]), int(seg[3]), float(seg[4])
+        if end != flat_param.numel():
+            raise RuntimeError(f"segments cover {end} elements, the buffer has {flat_param.numel()}")
+        cfg.beta1, cfg.beta2, cfg.eps, cfg.grad_scale = float(betas[0]), float(betas[1]), float(eps), float(grad_scale)
+        self.cfg = cfg
+
+    def set_grad_scale(self, s: float) -> None:
+        self.cfg.grad_scale = float(s)
+
+    @torch.no_grad()
+    def step(self) -> None:
+        dev = self.param.device
+        with torch.cuda.device(dev):
+            rc = _lib.lib().fr_adam_step(C.byref(self.cfg), self.param.data_ptr(), self.grad.data_ptr(),
+                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.param.numel(),
+                                         self.state.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _lib.FR_OK:
+            raise RuntimeError(f"fr_adam_step failed: {_lib.last_error()}")
+
+    @property
+    def step_count(self) -> int:
+        return int(self.state[0].item())

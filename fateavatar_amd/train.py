@@ -1,0 +1,124 @@
+"""The per-frame optimisation step around the path.
+
+reference loop: `iteration_step_fateavatar`, train/iteration.py:21-89 —
+    zero_grad(set_to_none) -> render -> L1(mean) -> backward -> _add_densification_stats -> Adam.step()
+with the Adam groups of train/optim.py:11-37 and the learning rates of config/fateavatar.yaml:34-39
+(generic-3DGS variant for the positions).  Densify / prune / opacity reset are
+reference model surgery outside the path and are not reproduced.
+
+What is fused here compared with the reference: the activations and the densification statistics run inside
+the rasterizer kernels (FR_FLAG_RAW_ACTIVATIONS, fr_aux), Adam is one kernel over the flat parameter buffer
+(fr_adam_step), and the whole step — about 20 kernel launches instead of about 90 — is replayed as ONE HIP graph.
+Data-parallel (one frame per rank): the flat gradient is summed over ranks with one RCCL
+all-reduce between the backward and the Adam kernel (which applies 1/world); the densification statistics are
+plain sums over frames, so every rank accumulates its own and `reduce_densification_stats()` adds them up
+when they are needed.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import dp
+from .model import FlatGaussians, TorchCamera
+from .optim import FusedAdam
+from .render import render
+
+# config/fateavatar.yaml:34-39 (+ the generic 3DGS position rate; FateAvatar optimises a mesh offset instead)
+DEFAULT_LRS = dict(xyz=1.6e-4, feature_dc=2.5e-3, feature_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3)
+
+
+class TrainStep:
+    def __init__(self, pc: FlatGaussians, camera: TorchCamera, bg: torch.Tensor, lrs: Optional[dict] = None,
+                 use_graph: bool = True):
+        if not pc.fused_activations:
+            raise ValueError("TrainStep drives the fused path: build FlatGaussians(..., fused_activations=True)")
+        self.pc, self.bg = pc, bg
+        self.dev = pc.flat.device
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        lr = dict(DEFAULT_LRS, **(lrs or {}))
+        P, M = pc.P, pc.M
+        self.adam = FusedAdam(pc.flat, pc.flat_grad, [
+            (P * 3, lr["xyz"]),
+            (P * M * 3, lr["feature_dc"], M * 3, 3, lr["feature_rest"]),
+            (P, lr["opacity"]), (P * 3, lr["scaling"]), (P * 4, lr["rotation"])], grad_scale=1.0 / self.world)
+        # _add_densification_stats accumulators (model/fateavatar.py:186-188,734-737), updated by the backward kernel
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=self.dev)
+        self.denom = torch.zeros((P, 1), device=self.dev)
+        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom)
+        # static inputs of the captured step
+        self.cam = camera
+        self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
+        self.loss = torch.zeros((), device=self.dev)
+        self.out = None
+        self.use_graph = bool(use_graph)
+        self._graph = None       # render .. backward (.. Adam when world == 1)
+        self._eager_steps = 0
+
+    # -- the step body: everything between zero_grad and the gradient exchange
+    def _forward_backward(self):
+        self.pc.begin_step()                                   # zero_grad(set_to_none=True), iteration.py:48-49
+        out = render(self.cam, self.pc, self.bg)               # activations + rasterizer (fused)
+        loss = torch.nn.functional.l1_loss(out["render"], self.gt)   # nn.L1Loss(reduction='mean'), loss.py:92
+        loss.backward()                                        # rasterizer backward; stats fused (fr_aux)
+        self.loss.copy_(loss.detach())
+        # keep the step's outputs WITHOUT their autograd graph: a graph kept alive across steps keeps its
+        # AccumulateGrad nodes (and the stream they were created on) alive, which breaks a later stream capture
+        self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
+
+    def _body(self):
+        self._forward_backward()
+        if self.world == 1:
+            self.adam.step()
+
+    def _capture(self):
+        from . import rasterizer
+        rasterizer.set_no_wait(True)  # nothing in the captured frame may wait on the host
+        # one frame on a side stream warms the allocator pools of the capture path; it is not a step (no Adam), so
+        # the statistics it accumulated are put back
+        acc, den = self.xyz_gradient_accum.clone(), self.denom.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._forward_backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.xyz_gradient_accum.copy_(acc)
+        self.denom.copy_(den)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # thread_local: an RCCL watchdog thread may exist
+            self._body()
+        torch.cuda.synchronize()
+        self._graph = g
+
+    def step(self, camera: TorchCamera, gt_image: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on this rank's frame.  Returns the (device) loss scalar of the step."""
+        if camera is not self.cam:
+            self.cam.copy_from(camera)
+        self.gt.copy_(gt_image, non_blocking=True)
+        if self.use_graph and self._graph is None and self._eager_steps >= 2:
+            self._capture()
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body()              # eager: first steps size the binning capacity (high-water mark)
+            self._eager_steps += 1
+        if self.world > 1:
+            dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
+            self.adam.step()
+        return self.loss
+
+    def check(self) -> None:
+        """After synchronising: raise if a captured (no-wait) frame overflowed its binning capacity."""
+        from . import rasterizer
+        if self._graph is not None and rasterizer.check_async_overflow(self.dev.index or 0):
+            raise RuntimeError("binning capacity overflowed inside the captured step; re-create the TrainStep")
+
+    def reduce_densification_stats(self):
+        """(xyz_gradient_accum, denom) summed over all ranks (they are sums over the frames each rank has seen)."""
+        acc, den = self.xyz_gradient_accum.clone(), self.denom.clone()
+        if self.world > 1:
+            dp.allreduce_sum_(acc)
+            dp.allreduce_sum_(den)
+        return acc, den

@@ -16,6 +16,7 @@
  *   fr_mark_visible   replaces CudaRasterizer::Rasterizer::markVisible
  *                     (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153),
  *                     called from markVisible (rasterize_points.cu:198-217)
+ *   fr_adam_step      replaces torch.optim.Adam.step() over the Gaussian groups (train/optim.py:11-37)
  *   fr_knn_mean_dist2 replaces SimpleKNN::knn (simple_knn.h, simple_knn.cu:186-222),
  *                     called from distCUDA2 (spatial.cu:14-25)
  *
@@ -165,6 +166,32 @@ int fr_read_counts(fr_handle* h, fr_counts* counts);
 int fr_backward(fr_handle* h, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,
                 const void* image, const void* binning, const float* dL_dpix, const fr_grads* grads,
                 void* hip_stream);
+
+/* ---- fused Adam over a flat parameter buffer (replaces torch.optim.Adam.step() over the
+ * Gaussian parameter groups of train/optim.py:11-37: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
+ * The buffer is cut into up to FR_ADAM_MAX_SEGMENTS consecutive segments, each with its own learning rate (the
+ * reference's param groups); param / grad / exp_avg / exp_avg_sq are device arrays of n floats with the same
+ * layout.  `state` is a device array of 4 floats owned by the caller, zero-initialised once: {step, 1 - beta1^step,
+ * 1 - beta2^step, unused}; every call first advances it on the device (so the call is hipGraph-capturable: nothing
+ * step-dependent is a kernel argument) and then applies
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * with g = grad_scale * grad (grad_scale: e.g. 1/world_size after a SUM all-reduce). */
+#define FR_ADAM_MAX_SEGMENTS 16
+typedef struct fr_adam_config {
+    int32_t n_segments;
+    uint64_t segment_end[FR_ADAM_MAX_SEGMENTS]; /* exclusive end offset (in floats) of each segment, ascending; last == n */
+    float segment_lr[FR_ADAM_MAX_SEGMENTS];
+    /* optional two-rate pattern inside a segment (SH coefficients stored [P,M,3] with the DC term at lr and the
+     * rest at lr/20, train/optim.py:49-50): element e (relative to the segment start) uses segment_lr if
+     * e % segment_period < segment_split, else segment_lr2.  segment_period == 0: segment_lr everywhere. */
+    uint32_t segment_period[FR_ADAM_MAX_SEGMENTS];
+    uint32_t segment_split[FR_ADAM_MAX_SEGMENTS];
+    float segment_lr2[FR_ADAM_MAX_SEGMENTS];
+    double beta1, beta2, eps; /* doubles, like torch's hyper-parameters: 1 - beta is rounded to float from here */
+    float grad_scale;
+} fr_adam_config;
+int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                 uint64_t n, float* state, void* hip_stream);
 
 /* present[i] = view-space z of means3D[i] > 0.2 (auxiliary.h:154). */
 int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

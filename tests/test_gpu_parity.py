@@ -353,3 +353,81 @@ def test_graph_replay_survives_interleaved_eager_kernels(gpu_device):
                                                                   ref_counts.max_tile_list)
     assert torch.equal(static_img, ref_img)
     assert util.rel_l2(pc.flat_grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-5
+
+
+def test_fused_adam_matches_torch_adam(gpu_device):
+    """fr_adam_step over a flat buffer with per-segment (and two-rate) learning rates == torch.optim.Adam over the
+    equivalent parameter groups (train/optim.py:11-37), step by step, including the bias correction."""
+    import torch
+    from fateavatar_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    P, M = 1001, 4  # 1001 * (3 + 12 + 1) = 16016 elements; segment boundaries not multiples of 4
+    sizes = [P * 3, P * M * 3, P]
+    n = sum(sizes)
+    flat = torch.randn(n, device=gpu_device)
+    grad = torch.zeros_like(flat)
+    lrs = dict(xyz=1.6e-4, dc=2.5e-3, rest=2.5e-3 / 20, op=0.05)
+    opt = FusedAdam(flat, grad, [(sizes[0], lrs["xyz"]), (sizes[1], lrs["dc"], M * 3, 3, lrs["rest"]), (sizes[2], lrs["op"])],
+                    grad_scale=0.5)
+    o0, o1 = sizes[0], sizes[0] + sizes[1]
+    feat = flat[o0:o1].view(P, M * 3)
+    ref = [flat[:o0].clone().requires_grad_(), feat[:, :3].clone().requires_grad_(), feat[:, 3:].clone().requires_grad_(),
+           flat[o1:].clone().requires_grad_()]
+    topt = torch.optim.Adam([dict(params=[ref[0]], lr=lrs["xyz"]), dict(params=[ref[1]], lr=lrs["dc"]),
+                             dict(params=[ref[2]], lr=lrs["rest"]), dict(params=[ref[3]], lr=lrs["op"])], lr=0.0)
+    for step in range(6):
+        g = torch.randn(n, device=gpu_device) * (10.0 ** (step - 3))
+        g[::7] = 0.0
+        grad.copy_(g)
+        gs = 0.5 * g  # grad_scale
+        gf = gs[o0:o1].view(P, M * 3)
+        for p, gg in zip(ref, (gs[:o0], gf[:, :3], gf[:, 3:], gs[o1:])):
+            p.grad = gg.clone().contiguous()
+        opt.step()
+        topt.step()
+        got = flat.clone()
+        want = torch.cat([ref[0].detach(), torch.cat([ref[1].detach(), ref[2].detach()], dim=1).reshape(-1), ref[3].detach()])
+        assert torch.allclose(got, want, rtol=2e-6, atol=1e-7), (step, float((got - want).abs().max()))
+    assert opt.step_count == 6
+
+
+def test_train_step_graph_equals_eager_and_fits(gpu_device):
+    """Row H harness: zero_grad -> render -> L1 -> backward -> stats -> Adam.  The HIP-graph replay of the step must
+    track the eager step, and a short fit against images of a hidden Gaussian set must reduce the loss."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from fateavatar_amd.train import TrainStep
+    P, res, views = 4000, 96, 4
+    truth = scenes.head_scene(P=P, res=res, sh_degree=1, seed=3, opacity=0.6)
+    cams = [TorchCamera(scenes.head_scene(P=8, res=res, sh_degree=1, seed=3, view=v, n_views=views).camera, gpu_device)
+            for v in range(views)]
+    bg = torch.from_numpy(truth.bg).to(gpu_device)
+    pc_true = FlatGaussians(truth.means3D, truth.shs, truth.opacities, truth.scales, truth.rotations, 1, gpu_device,
+                            fused_activations=True)
+    with torch.no_grad():
+        gts = [render(c, pc_true, bg)["render"].clone() for c in cams]
+    rng = np.random.default_rng(0)
+    shs0 = (truth.shs + 0.3 * rng.standard_normal(truth.shs.shape)).astype(np.float32)
+
+    def run(use_graph):
+        pc = FlatGaussians(truth.means3D, shs0, truth.opacities * 0.7, truth.scales, truth.rotations, 1, gpu_device,
+                           fused_activations=True)
+        cam = TorchCamera(scenes.head_scene(P=8, res=res, sh_degree=1, seed=3, view=0, n_views=views).camera, gpu_device)
+        ts = TrainStep(pc, cam, bg, use_graph=use_graph)
+        losses = []
+        for it in range(24):
+            losses.append(ts.step(cams[it % views], gts[it % views]).clone())
+        torch.cuda.synchronize()
+        ts.check()
+        return pc.flat.clone(), [float(x) for x in losses], ts
+
+    flat_e, loss_e, ts_e = run(False)
+    flat_g, loss_g, ts_g = run(True)
+    assert ts_g._graph is not None and ts_e._graph is None
+    assert np.mean(loss_e[-4:]) < 0.8 * np.mean(loss_e[:4]), loss_e
+    # same trajectory up to the summation order of the gradient atomics
+    assert np.allclose(loss_g, loss_e, rtol=2e-3), (loss_g, loss_e)
+    assert float((flat_g - flat_e).abs().max()) < 5e-3
+    assert torch.equal(ts_g.denom, ts_e.denom) and float(ts_e.denom.max()) == 24.0
+    assert torch.allclose(ts_g.xyz_gradient_accum, ts_e.xyz_gradient_accum, rtol=5e-2, atol=1e-7)

@@ -95,3 +95,13 @@ def test_head_scene_and_view_orbit():
     for s in (s0, s1):
         c = np.array([0.0, 1.47, 0.0, 1.0], np.float32) @ s.camera.full_proj_transform
         assert abs(c[0] / c[3]) < 0.3 and abs(c[1] / c[3]) < 0.3 and c[3] > 0.2
+
+
+def test_fused_adam_and_train_step_refuse_cpu_tensors():
+    """No CPU fallback for the fused optimizer either: host-side argument checks fail loudly."""
+    import pytest
+    import torch
+    from fateavatar_amd.optim import FusedAdam
+    p, g = torch.zeros(16), torch.zeros(16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FusedAdam(p, g, [(16, 1e-3)])
