@@ -289,9 +289,12 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     {
         const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
         if (tile < T) {
-            // the binning counters of this tile have been consumed (scan, emit): leave them zeroed for the next frame
-            if (lane == 0) *reinterpret_cast<uint2*>(v.tile_count + (size_t)tile * kCounterStride) = make_uint2(0u, 0u);
-            if (overflow) return;
+            if (overflow) {
+                // the emit pass did not run, so its count-down of the overflow counters did not happen: zero them here
+                // (the scan already zeroed tile_count) so that the next frame finds clean counters
+                if (lane < kXcds) v.tile_over[(size_t)lane * v.tpad + tile] = 0u;
+                return;
+            }
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_offset[tile + 1] - start;
             // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store

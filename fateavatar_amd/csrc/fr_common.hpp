@@ -13,7 +13,8 @@ constexpr int kWave = 64;
 constexpr int kTile = 8;    // 8x8 pixels = one wavefront
 constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): radii / num_rendered semantics
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
-constexpr int kCounterStride = 16; // u32 words between the atomic counters of neighbouring tiles: one 64-B line each
+constexpr int kXcds = 8;            // binning counters are privatised per XCD (indexed by HW_REG_XCC_ID & 7)
+constexpr int kSubWords = 16;       // per-tile sub-segment table: 8 starts of the per-XCD sub-segments + 8 starts of their overflow parts
                                    // (device-scope atomics serialise per cache line, ~11 ns apiece)
 constexpr int kInlineSlots = 8;    // instances per Gaussian whose segment position is remembered from the counting pass
 constexpr int kSortRegMax = 4096;   // longest list sorted in registers (4 waves x 16 keys per lane); longer ones: global-memory fallback
@@ -60,6 +61,7 @@ struct GeomView {
                             //     a dx^2 + 2 b dx dy + c dy^2 <= cull_tau2 (evaluation slack included; +inf = never cull)
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
     uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
+    uint32_t* block_xcc;        // [ceil(P/256)] XCD the preprocess workgroup ran on (whose counters it used)
     uint32_t* inline_slots;     // [P*kInlineSlots] position inside its tile's segment of each of a Gaussian's first
                                 // kInlineSlots instances (handed out by the counting atomic of the preprocess)
     static GeomView make(void* buf, size_t P)
@@ -76,6 +78,7 @@ struct GeomView {
         g.cull_tau2 = carve<float>(p, P);
         g.accum = carve<float>(p, P * kAccumStride);
         g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
+        g.block_xcc = carve<uint32_t>(p, (P + 255) / 256 + 1);
         g.inline_slots = carve<uint32_t>(p, P * kInlineSlots);
         return g;
     }
@@ -104,10 +107,16 @@ struct DeviceCounts {  // lives at the head of the image buffer
 struct ImageView {
     DeviceCounts* counts;
     // The per-tile counters do NOT live in the image buffer: they belong to the handle (fr_handle_impl::tile_counters),
-    // are zero between frames (k_tile_sort re-zeroes each tile's line once it is done with it) and so need no
-    // zeroing launch per frame.  launch_forward points these two members at them.
-    uint32_t* tile_count;    // [T*kCounterStride] per 8x8 tile: instances with a remembered position (one counter per 64-B line)
-    uint32_t* tile_over;     // [T*kCounterStride] per 8x8 tile: instances beyond kInlineSlots of their Gaussian
+    // are zero between frames (the scan re-zeroes tile_count after reading it, the emit pass counts tile_over back
+    // down) and so need no zeroing launch per frame.  launch_forward points these two members at them.
+    // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
+    // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
+    // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
+    uint32_t* tile_count;    // [kXcds][Tpad] instances with a remembered position, counted by XCD x
+    uint32_t* tile_over;     // [kXcds][Tpad] instances beyond kInlineSlots of their Gaussian, counted by XCD x
+    uint32_t* tile_sub;      // [T][kSubWords] starts (relative to tile_offset) of sub-segment x [0..7] and of its overflow part [8..15]
+    uint32_t tpad;           // row pitch of the two counter arrays
+    uint32_t* tile_total;    // [Tpad] instances per tile (sum over the XCD copies), written by k_tile_totals for the scan
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
     uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
@@ -125,6 +134,9 @@ struct ImageView {
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
         v.tile_count = v.tile_over = nullptr;
+        v.tpad = (uint32_t)((T + 15) & ~(size_t)15);
+        v.tile_sub = carve<uint32_t>(p, T * kSubWords);
+        v.tile_total = carve<uint32_t>(p, v.tpad);
         v.tile_offset = carve<uint32_t>(p, T + 1);
         v.large_list = carve<uint32_t>(p, T);
         v.medium_list = carve<uint32_t>(p, T);

@@ -34,6 +34,7 @@ struct PreArgs {
     GeomView g;
     uint32_t* tile_count;
     uint32_t* tile_over;
+    uint32_t tpad;          // row pitch of the per-XCD counter copies
     DeviceCounts* counts;
     int tiles_x, tiles_y;   // 8x8 tiles
     int ref_gx, ref_gy;     // 16x16 tiles (reference grid)
@@ -321,6 +322,8 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
         // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several)
         constexpr int kCountUnroll = 4;
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
+        if (threadIdx.x == 0) a.g.block_xcc[blockIdx.x] = xcc;
         for (uint32_t k0 = (uint32_t)lane; k0 < total; k0 += 64 * kCountUnroll) {
             uint32_t pos[kCountUnroll];
             size_t where[kCountUnroll];
@@ -340,8 +343,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 const uint32_t j = k - s_excl[wave][lo];
                 const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
                 const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
-                if (!footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;
-                const size_t t = (size_t)(ty * (uint32_t)a.tiles_x + tx) * kCounterStride;
+                // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
+                // reaches both ends of its bounding box); only wider ones can miss a corner tile
+                const uint32_t rh = (rr.y >> 16) - y0;
+                if (rw > 1 && rh > 1 && !footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;
+                const size_t t = (size_t)xcc * a.tpad + (size_t)(ty * (uint32_t)a.tiles_x + tx);
                 if (j < (uint32_t)kInlineSlots) {
                     pos[u] = atomicAdd(&a.tile_count[t], 1u);
                     where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
@@ -368,6 +374,43 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 // Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
 // (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
 // the unit -> tile table and builds the list of tiles too long for the in-register sort.
+// Per-tile work that needs no prefix: add up the eight per-XCD counter copies, write the tile's sub-segment table,
+// and leave tile_count zeroed for the next frame (the emit pass counts tile_over back down itself).  Wide and
+// coalesced (every thread four consecutive tiles, 16 B per load), so that the single-workgroup scan behind it only
+// touches one dense 4-byte-per-tile array.
+__global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
+{
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (i >= T) return;
+    uint32_t sub[4][kSubWords];
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int x = 0; x < kXcds; x++) {
+        uint4* p1 = reinterpret_cast<uint4*>(v.tile_count + (size_t)x * v.tpad + i);
+        const uint4 c1 = *p1;
+        const uint4 c2 = *reinterpret_cast<const uint4*>(v.tile_over + (size_t)x * v.tpad + i);
+        *p1 = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t a1[4] = {c1.x, c1.y, c1.z, c1.w}, a2[4] = {c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sub[q][x] = acc[q];                  // start of XCD x's sub-segment (remembered instances first)
+            sub[q][kXcds + x] = acc[q] + a1[q];  // start of its un-remembered part
+            acc[q] += a1[q] + a2[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (i + q >= T) break;
+        uint4* dst = reinterpret_cast<uint4*>(v.tile_sub + (size_t)(i + q) * kSubWords);
+#pragma unroll
+        for (int w4 = 0; w4 < kSubWords / 4; w4++)
+            dst[w4] = make_uint4(sub[q][4 * w4], sub[q][4 * w4 + 1], sub[q][4 * w4 + 2], sub[q][4 * w4 + 3]);
+    }
+    *reinterpret_cast<uint4*>(v.tile_total + i) = make_uint4(acc[0], acc[1], acc[2], acc[3]);  // (tiles >= T: zero)
+}
+
+// Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts, the lists of tiles the
+// multi-wave sorters take, and the frame counts.  One workgroup.
 __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity,
                                                      const uint32_t* block_ref_tiles, uint32_t n_blocks,
                                                      fr_counts* host_counts)
@@ -376,32 +419,32 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
     __shared__ uint32_t s_heads[3];
     if (threadIdx.x < 3) s_heads[threadIdx.x] = 0;
     __syncthreads();
-    __shared__ uint32_t s_sum[1024];
-    __shared__ uint32_t s_usum[1024];
+    __shared__ uint32_t s_sum[16];
+    __shared__ uint32_t s_usum[16];
     __shared__ uint32_t s_max[16];
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (T + 1023u) / 1024u;
+    // every thread owns `per` consecutive tiles, a multiple of 4 (16-byte loads)
+    const uint32_t per = (((T + 1023u) / 1024u) + 3u) & ~3u;
     const uint32_t b = min(T, tid * per), e = min(T, b + per);
     uint32_t sum = 0, usum = 0, mx = 0;
-    // (remembered, un-remembered) instance counts of this thread's tiles; cached in registers for the second pass
-    constexpr int kCache = 4;
-    uint2 cc[kCache];
+    constexpr int kCache = 2;  // quads of counts kept in registers for the second pass
+    uint4 cache[kCache];
+    for (uint32_t i = b, k = 0; i < e; i += 4, k++) {
+        const uint4 c = *reinterpret_cast<const uint4*>(v.tile_total + i);
+        if (k < (uint32_t)kCache) cache[k] = c;
+        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-    for (int q = 0; q < kCache; q++) {
-        const uint32_t i = b + q;
-        cc[q] = (i < e) ? *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride) : make_uint2(0u, 0u);
-    }
-    for (uint32_t i = b; i < e; i++) {
-        const uint2 c2 = (i - b < (uint32_t)kCache) ? cc[(i - b) & (kCache - 1)]
-                                                    : *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride);
-        const uint32_t c = c2.x + c2.y;
-        sum += c;
-        usum += (c + kUnit - 1) / kUnit;
-        mx = max(mx, c);
-        // single workgroup: the list heads live in LDS (a global same-address atomic costs ~11 ns apiece)
-        if (c > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&s_heads[0], 1u)] = i;
-        else if (c > (uint32_t)kSortGroupMax) v.big_list[atomicAdd(&s_heads[2], 1u)] = i;
-        else if (c > (uint32_t)kSortWaveMax) v.medium_list[atomicAdd(&s_heads[1], 1u)] = i;
+        for (int q = 0; q < 4; q++) {
+            if (i + q >= e) break;
+            const uint32_t n = cc[q];
+            sum += n;
+            usum += (n + kUnit - 1) / kUnit;
+            mx = max(mx, n);
+            // single workgroup: the list heads live in LDS (a global same-address atomic costs ~11 ns apiece)
+            if (n > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&s_heads[0], 1u)] = i + q;
+            else if (n > (uint32_t)kSortGroupMax) v.big_list[atomicAdd(&s_heads[2], 1u)] = i + q;
+            else if (n > (uint32_t)kSortWaveMax) v.medium_list[atomicAdd(&s_heads[1], 1u)] = i + q;
+        }
     }
     uint32_t ref = 0;
     for (uint32_t i = tid; i < n_blocks; i += 1024) ref += block_ref_tiles[i];
@@ -423,30 +466,31 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         if (w < wv) wbase += s_sum[w], uwbase += s_usum[w];
         tot += s_sum[w], utot += s_usum[w];
     }
-    __syncthreads();
-    s_sum[tid] = wbase + inc;     // inclusive prefix over the whole workgroup (as before)
-    s_usum[tid] = uwbase + uinc;
-    if (tid == 1023) s_sum[1023] = tot, s_usum[1023] = utot;
-    __syncthreads();
-    const uint32_t total = s_sum[1023];
+    const uint32_t total = tot;
     const bool overflow = (uint64_t)total > capacity;
-    uint32_t run = s_sum[tid] - sum, urun = s_usum[tid] - usum;  // exclusive prefixes of this thread's chunk
-    for (uint32_t i = b; i < e; i++) {
-        const uint2 c2 = (i - b < (uint32_t)kCache) ? cc[(i - b) & (kCache - 1)]
-                                                    : *reinterpret_cast<const uint2*>(v.tile_count + (size_t)i * kCounterStride);
-        // (the unit descriptors are written by k_tile_sort, one coalesced store per tile: scattered stores from
-        // this single workgroup were most of its run time)
-        const uint32_t c = c2.x + c2.y;
-        v.tile_offset[i] = run;
-        v.unit_offset[i] = urun;
-        run += c;
-        urun += (c + kUnit - 1) / kUnit;
+    uint32_t run = wbase + inc - sum, urun = uwbase + uinc - usum;  // exclusive prefixes of this thread's chunk
+    for (uint32_t i = b, k = 0; i < e; i += 4, k++) {
+        const uint4 c = (k < (uint32_t)kCache) ? cache[k < (uint32_t)kCache ? k : 0] : *reinterpret_cast<const uint4*>(v.tile_total + i);
+        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+        uint32_t o[4], uo[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            o[q] = run, uo[q] = urun;
+            run += cc[q];
+            urun += (cc[q] + kUnit - 1) / kUnit;
+        }
+        if (i + 4 <= e) {
+            *reinterpret_cast<uint4*>(v.tile_offset + i) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(v.unit_offset + i) = make_uint4(uo[0], uo[1], uo[2], uo[3]);
+        } else {
+            for (int q = 0; q < 4 && i + q < e; q++) v.tile_offset[i + q] = o[q], v.unit_offset[i + q] = uo[q];
+        }
     }
     if (tid == 1023) {
         uint32_t m = 0;
         for (int i = 0; i < 16; i++) m = max(m, s_max[i]);
         v.tile_offset[T] = total;
-        v.unit_offset[T] = s_usum[1023];
+        v.unit_offset[T] = utot;
         DeviceCounts* c = v.counts;
         uint32_t nr = 0;
         for (int i = 0; i < 16; i++) nr += s_ref[i];
@@ -457,7 +501,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         c->num_instances = total;
         c->max_tile_list = m;
         c->overflow = overflow ? 1u : 0u;
-        c->num_units = overflow ? 0u : s_usum[1023];
+        c->num_units = overflow ? 0u : utot;
         c->capacity = (uint32_t)capacity;
         host_counts->num_rendered = c->num_rendered;
         host_counts->num_instances = total;
@@ -479,6 +523,7 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
     if (v.counts->overflow) return;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t xcc = g.block_xcc[blockIdx.x];  // the XCD whose counters numbered this workgroup's instances
     uint2 r = make_uint2(0u, 0u);
     uint32_t n = 0;
     uint64_t key = 0;
@@ -518,14 +563,17 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
         const uint32_t j = k - s_excl[wave][lo];
         const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, w = (rr.y & 0xffff) - x0;
         const uint32_t ty = y0 + j / w, tx = x0 + (j - (j / w) * w);
-        if (!footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;  // same test as the count
+        const uint32_t h = (rr.y >> 16) - y0;
+        if (w > 1 && h > 1 && !footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;  // same test as the count
         const uint32_t tile = ty * (uint32_t)v.tiles_x + tx;
-        uint32_t slot;
+        // the instance lives in the sub-segment of the XCD that counted it
+        uint32_t slot = v.tile_offset[tile];
         if (j < (uint32_t)kInlineSlots)
-            slot = v.tile_offset[tile] + g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
+            slot += v.tile_sub[(size_t)tile * kSubWords + xcc] +
+                    g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
         else  // un-remembered instances go behind the remembered ones; the overflow counter counts back down to 0
-            slot = v.tile_offset[tile] + v.tile_count[(size_t)tile * kCounterStride] +
-                   (atomicSub(&v.tile_over[(size_t)tile * kCounterStride], 1u) - 1u);
+            slot += v.tile_sub[(size_t)tile * kSubWords + kXcds + xcc] +
+                    (atomicSub(&v.tile_over[(size_t)xcc * v.tpad + tile], 1u) - 1u);
         keys[slot] = s_key[wave][lo];
     }
 }
@@ -577,14 +625,15 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     if (T > h->tile_counter_tiles) {
         if (h->tile_counters) FR_HIP(hipFree(h->tile_counters));
         h->tile_counters = nullptr, h->tile_counter_tiles = 0;
-        FR_HIP(hipMalloc(&h->tile_counters, (size_t)T * kCounterStride * sizeof(uint32_t)));
+        FR_HIP(hipMalloc(&h->tile_counters, (size_t)2 * kXcds * v.tpad * sizeof(uint32_t)));
         h->tile_counter_tiles = T;
         h->counters_clean = false;
     }
     if (!h->counters_clean)
-        if ((rc = launch_zero(h->tile_counters, h->tile_counter_tiles * kCounterStride * sizeof(uint32_t), s))) return rc;
+        if ((rc = launch_zero(h->tile_counters, (size_t)2 * kXcds * ((h->tile_counter_tiles + 15) & ~(size_t)15) * sizeof(uint32_t), s)))
+            return rc;
     h->counters_clean = false;  // until every stage of this frame has been enqueued
-    v.tile_count = h->tile_counters, v.tile_over = h->tile_counters + 1;  // same 64-B line (the second is rarely touched)
+    v.tile_count = h->tile_counters, v.tile_over = h->tile_counters + (size_t)kXcds * v.tpad;
 
     PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
@@ -597,7 +646,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.visible = prm.aux ? prm.aux->visible : nullptr;
-    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.tile_over = v.tile_over, a.counts = v.counts;
+    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.tile_over = v.tile_over, a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
     if (P > 0) {
@@ -611,6 +660,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     {
         StageScope sc(h, ST_SCAN, s);
+        hipLaunchKernelGGL(k_tile_totals, dim3((T + 1023) / 1024), dim3(256), 0, s, v, T);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, g.block_ref_tiles,
                            (uint32_t)((P + 255) / 256), h->host_counts_dev);
     }

@@ -48,8 +48,11 @@ def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
     """In-place batch-mean of a flat gradient buffer across ranks (one collective)."""
     w = world_size()
     if w > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        flat_grad.div_(w)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective: no extra pass
+        else:  # gloo (CPU tests) has no AVG
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+            flat_grad.div_(w)
     return flat_grad
 
 
