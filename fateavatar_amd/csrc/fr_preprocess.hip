@@ -76,20 +76,34 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
 {
     const int total = rows * row_len;
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
-    for (int c = lane * 4; c < total; c += 64 * 4) {
-        float v[4];
-        if (c + 3 < total) {
-            const float4 q = *reinterpret_cast<const float4*>(src + c);
-            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
-        } else {
-            for (int k = 0; k < 4; k++) v[k] = (c + k < total) ? src[c + k] : 0.f;
+    // kStageBatch 16-byte loads per lane are issued before the first one is consumed: the copy costs one or two
+    // memory round trips per wave, not one per 1 KiB
+    constexpr int kStageBatch = 6;
+    for (int base = lane * 4; base < total; base += 64 * 4 * kStageBatch) {
+        float4 q[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; u++) {
+            const int c = base + u * 64 * 4;
+            if (c + 3 < total) {
+                q[u] = *reinterpret_cast<const float4*>(src + c);
+            } else {
+                q[u].x = (c < total) ? src[c] : 0.f;
+                q[u].y = (c + 1 < total) ? src[c + 1] : 0.f;
+                q[u].z = (c + 2 < total) ? src[c + 2] : 0.f;
+                q[u].w = 0.f;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = c + k;
-            if (e < total) {
-                const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
-                dst[r * stride + (e - r * row_len)] = v[k];
+        for (int u = 0; u < kStageBatch; u++) {
+            const int c = base + u * 64 * 4;
+            const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = c + k;
+                if (e < total) {
+                    const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
+                    dst[r * stride + (e - r * row_len)] = v[k];
+                }
             }
         }
     }
