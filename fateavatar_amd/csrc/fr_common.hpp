@@ -263,6 +263,31 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 // HW fp32 atomic add (global_atomic_add_f32), no return value needed.
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// The frame's camera (view 4x4, projection 4x4, position) as wave-uniform values: every lane fetches ONE of the 35
+// floats (one memory round trip, issued together with the kernel's other input loads) and v_readlane broadcasts
+// them to scalar registers.  Reading the matrices through their pointers instead cost the per-Gaussian kernels a
+// dependent global load (= a serialised round trip) at every use.
+struct CameraRegs {
+    float view[16], proj[16], campos[3];
+};
+__device__ __forceinline__ CameraRegs load_camera(const float* view, const float* proj, const float* campos, int lane)
+{
+    float x = 0.f;
+    if (lane < 16) x = view[lane];
+    else if (lane < 32) x = proj[lane - 16];
+    else if (lane < 35) x = campos[lane - 32];
+    const int xi = __float_as_int(x);
+    CameraRegs c;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        c.view[k] = __int_as_float(__builtin_amdgcn_readlane(xi, k));
+        c.proj[k] = __int_as_float(__builtin_amdgcn_readlane(xi, 16 + k));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) c.campos[k] = __int_as_float(__builtin_amdgcn_readlane(xi, 32 + k));
+    return c;
+}
+
 // reference auxiliary.h:58-77 — matrices are indexed column-major
 __device__ __forceinline__ float3 xform4x3(const float3 p, const float* m)
 {

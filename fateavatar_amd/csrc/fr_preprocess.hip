@@ -143,6 +143,18 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int M3 = a.M * 3, sh_stride = M3 | 1;
     const float* my_sh = nullptr;
+    // every input of this thread is requested up front (camera, mean, scale, rotation, opacity — and the SH block
+    // below), so that the kernel pays one memory round trip for its inputs instead of one per use
+    const CameraRegs cam = load_camera(a.view, a.proj, a.campos, lane);
+    const bool live = idx < a.P;
+    const int li = live ? idx : 0;
+    const float3 p_orig = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
+    float in_sc[3] = {0.f, 0.f, 0.f}, in_rot[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.scales) in_sc[0] = a.scales[3 * li], in_sc[1] = a.scales[3 * li + 1], in_sc[2] = a.scales[3 * li + 2];
+    if (a.rotations)
+        in_rot[0] = a.rotations[4 * li], in_rot[1] = a.rotations[4 * li + 1], in_rot[2] = a.rotations[4 * li + 2],
+        in_rot[3] = a.rotations[4 * li + 3];
+    const float in_opacity = a.opacities[li];
     if (a.shs && !a.colors_precomp) {
         float* w_sh = s_sh + (size_t)wave * 64 * sh_stride;
         const int wave_first = blockIdx.x * 256 + wave * 64;
@@ -162,12 +174,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         do {
-            const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
             // near cull only (auxiliary.h:154)
-            const float3 p_view = xform4x3(p_orig, a.view);
+            const float3 p_view = xform4x3(p_orig, cam.view);
             if (p_view.z <= 0.2f) break;
 
-            const float4 p_hom = xform4x4(p_orig, a.proj);
+            const float4 p_hom = xform4x4(p_orig, cam.proj);
             const float p_w = 1.0f / (p_hom.w + 0.0000001f);
             const float p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
 
@@ -176,9 +187,8 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             if (a.cov3D_precomp) {
                 for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                float sc0 = a.scales[3 * idx], sc1 = a.scales[3 * idx + 1], sc2 = a.scales[3 * idx + 2];
-                float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-                      z = a.rotations[4 * idx + 3];
+                float sc0 = in_sc[0], sc1 = in_sc[1], sc2 = in_sc[2];
+                float r = in_rot[0], x = in_rot[1], y = in_rot[2], z = in_rot[3];
                 if (a.raw) {
                     sc0 = act_exp(sc0), sc1 = act_exp(sc1), sc2 = act_exp(sc2);
                     const float inv = act_rot_inv_norm(r, x, y, z);
@@ -209,7 +219,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
             const float j00 = a.focal_x / t.z, j02 = -(a.focal_x * t.x) / (t.z * t.z);
             const float j11 = a.focal_y / t.z, j12 = -(a.focal_y * t.y) / (t.z * t.z);
-            const float* vm = a.view;
+            const float* vm = cam.view;
             // T = J * W (2x3): row 0 and row 1; the zero products are kept so the sums round identically
             float T0[3], T1[3];
             for (int w = 0; w < 3; w++) {
@@ -256,7 +266,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             if (a.colors_precomp) {
                 col[0] = a.colors_precomp[3 * idx], col[1] = a.colors_precomp[3 * idx + 1], col[2] = a.colors_precomp[3 * idx + 2];
             } else {
-                float dx = p_orig.x - a.campos[0], dy = p_orig.y - a.campos[1], dz = p_orig.z - a.campos[2];
+                float dx = p_orig.x - cam.campos[0], dy = p_orig.y - cam.campos[1], dz = p_orig.z - cam.campos[2];
                 const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                 dx = dx / len, dy = dy / len, dz = dz / len;
                 const float* sh = my_sh;
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 }
             }
 
-            const float opacity = a.raw ? act_sigmoid(a.opacities[idx]) : a.opacities[idx];
+            const float opacity = a.raw ? act_sigmoid(in_opacity) : in_opacity;
             radius_out = mr;
             a.g.depth[idx] = p_view.z;
             a.g.means2D[idx] = make_float2(pix_x, pix_y);

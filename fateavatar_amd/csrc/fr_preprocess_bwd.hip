@@ -42,11 +42,12 @@ __device__ __forceinline__ void store3(float* p, size_t i, float a, float b, flo
 
 // Everything for ONE Gaussian.  `row` (LDS, may be null) holds this Gaussian's SH coefficients on entry and
 // receives its dL_dsh row in place (the kernel stages both through LDS for coalesced HBM access).
-__device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const int idx, float* row)
+__device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const CameraRegs& cam, const int radius,
+                                                   const int idx, float* row)
 {
     const size_t i = (size_t)idx;
     const int Mc = a.M;
-    if (!(a.radii[idx] > 0)) {
+    if (!(radius > 0)) {
         if (row)
             for (int k = 0; k < Mc * 3; k++) row[k] = 0.f;
         store3(a.out.dL_dmeans2D, i, 0.f, 0.f, 0.f);
@@ -90,7 +91,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
     if (a.out.dL_dopacity) a.out.dL_dopacity[i] = a.raw ? dop * co.w * (1.0f - co.w) : dop;
 
     const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-    const float* vm = a.view;
+    const float* vm = cam.view;
     const float* c3 = a.cov3D_precomp ? a.cov3D_precomp + 6 * i : a.g.cov3D + 6 * i;
 
     // ---------------- conic -> Sigma2D -> Sigma3D and mean (backward.cu:144-274)
@@ -163,7 +164,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
 
     // ---------------- projection part of dL/dmean3D (backward.cu:370-387)
     {
-        const float* proj = a.proj;
+        const float* proj = cam.proj;
         const float4 m_hom = xform4x4(mean, proj);
         const float m_w = 1.0f / (m_hom.w + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
@@ -176,7 +177,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const in
 
     // ---------------- SH backward (backward.cu:20-139)
     if (a.shs) {
-        const float dox = mean.x - a.campos[0], doy = mean.y - a.campos[1], doz = mean.z - a.campos[2];
+        const float dox = mean.x - cam.campos[0], doy = mean.y - cam.campos[1], doz = mean.z - cam.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
         // `row` is read (SH) and overwritten (dL_dsh) in place: each channel pass loads its coefficients into
@@ -386,9 +387,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
     const int rows = min(64, a.P - wave_first);
     const bool staged = a.shs != nullptr && a.out.dL_dsh != nullptr;
     float* w_rows = s_rows + (size_t)wave * 64 * stride;
+    // camera and radius are requested before the SH block is staged: one round trip for all of them
+    const CameraRegs cam = load_camera(a.view, a.proj, a.campos, lane);
+    const int radius = idx < a.P ? a.radii[idx] : 0;
     if (staged && rows > 0) stage_rows(w_rows, stride, a.shs + (size_t)wave_first * M3, rows, M3, lane);
     __syncthreads();
-    if (idx < a.P) preprocess_bwd_one(a, idx, staged ? w_rows + lane * stride : nullptr);
+    if (idx < a.P) preprocess_bwd_one(a, cam, radius, idx, staged ? w_rows + lane * stride : nullptr);
     __syncthreads();
     if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane);
 }
