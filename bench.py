@@ -204,11 +204,14 @@ def main():
         if args.cpu_frames > 0 and world == 1:
             v, cores, sample = cpu_baseline(scene, args.cpu_frames)
             cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+        cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) else
+                    "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024)
+                    else "custom size (not the metric's configuration)")
         line = {
             "metric": "render+backward frames/sec at 512^2, 100k Gaussians", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {args.P} Gaussians on the head template, "
+            "config": {"workload": f"{cfg_name}: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
                        "frames_per_step_per_gpu": 1,

@@ -165,6 +165,22 @@ def test_long_tile_lists_take_the_multi_wave_and_fallback_sorts(P, lo, hi, gpu_d
     assert util.rel_l2(hb["dL_dopacity"], ob.dL_dopacity) < 2e-4
 
 
+def test_large_non_square_image(gpu_device):
+    """1536 x 1000 pixels = 192 x 125 tiles: the scan kernel's multi-quad-per-thread path, partial edge tiles in y,
+    and the XCD-private counter pitch for a tile count that is not a multiple of 16."""
+    s = scenes.random_scene(5000, 1000, 1536, sh_degree=1, seed=21, spread=0.28, scale_lo=0.004, scale_hi=0.03,
+                            opacity_lo=0.2, opacity_hi=0.9)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "large_image")
+    rng = np.random.default_rng(2)
+    dpix = (rng.uniform(-1, 1, (3, 1000, 1536)) / (1000 * 1536)).astype(np.float32)
+    from oracle import oracle
+    ob, hb = oracle.backward(o, dpix), h.backward(dpix)
+    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 2e-4
+    assert util.rel_l2(hb["dL_dsh"], ob.dL_dsh) < 2e-4
+
+
 def test_mark_visible(gpu_device):
     import torch
     from fateavatar_amd import rasterizer
