@@ -3,6 +3,7 @@
 // fr_preprocess_bwd.hip / fr_knn.hip.
 #include "fr_common.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -81,6 +82,8 @@ int fr_create(fr_handle** out)
     memset(h->host_counts, 0, 64);
     FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
+    const char* fb = getenv("FR_FUSED_BLEND");  // experimental one-launch k_unit_blend_fused (measured: no gain yet)
+    h->no_fused_blend = !(fb && fb[0] == '1');
     *out = reinterpret_cast<fr_handle*>(h);
     return FR_OK;
 }

@@ -267,7 +267,7 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
 constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
-                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap)
+                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg)
 {
     __shared__ SortXchgT<4> sx;
     const bool overflow = v.counts->overflow != 0;
@@ -301,6 +301,9 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
             for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
                 if (u0 + k < unit_cap) unit_tile[u0 + k] = make_uint4(tile, k, start, n);
+            // hand-off words of k_unit_blend_fused: a unit's per-pixel product is valid once it is non-zero
+            if (unit_tseg)
+                for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
                 if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
                 else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
@@ -511,6 +514,87 @@ __global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restri
             T = c ? test_T : T;
             last = c ? (ui.base + j + k + 1u) : last;
         }
+    }
+    float* o = unit_out + (size_t)u * 5 * kUnit + lane;
+    o[0] = Cr;
+    o[kUnit] = Cg;
+    o[2 * kUnit] = Cb;
+    o[3 * kUnit] = T;
+    o[4 * kUnit] = __uint_as_float(last | (term ? 0x80000000u : 0u));
+    }
+}
+
+// ---- passes A + B in one launch (EXPERIMENTAL, off by default: FR_FUSED_BLEND=1).  Measured at config 2 and on
+// the opaque stress scene: no faster than the two lean launches (128 VGPRs for the 64 stored alphas halve the
+// occupancy, which costs what the second alpha evaluation saved).  Kept for the next tuning round.  Every unit evaluates its 64 alphas ONCE (kept in registers), publishes the
+// per-pixel product of (1 - alpha) for the units behind it in the tile, picks up the products of the units in front
+// of it, and blends.  The hand-off follows MI355X_MICROARCH.md's data-tagged form: the 4-byte product itself is the
+// flag (zeroed by k_tile_sort, valid once non-zero; products are clamped to >= 1e-30, which still means "dead"),
+// written and polled with relaxed agent-scope accesses (sc1: L2 write-through / L1 bypass), no fences.  A unit only
+// ever waits for units with SMALLER indices; the grid is sized to be fully resident (launch_sort_and_blend), so the
+// unfinished unit with the smallest index always belongs to a running wave: no deadlock.  The spin is bounded
+// anyway (a wrong image is better than a hung device).
+__global__ void __launch_bounds__(256, 4) k_unit_blend_fused(const DeviceCounts* __restrict__ counts,
+                                                         const uint4* __restrict__ unit_tile,
+                                                         const float4* __restrict__ recs, int W, int H, int tiles_x,
+                                                         float* unit_tseg, float* __restrict__ unit_out)
+{
+    FR_UNIT_LOOP_BEGIN
+    const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
+    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+    const bool has_next = ui.base + kUnit < ui.n;
+
+    // ---- alphas of the unit (0 where the reference's tests reject the pair), and their running product
+    float al[kUnit];
+    float prod = 1.0f;
+#pragma unroll
+    for (int j = 0; j < kUnit; j++) {
+        const float4 q0 = s_rec[j * kRecQuads + 0];
+        const float2 q1 = *reinterpret_cast<const float2*>(&s_rec[j * kRecQuads + 1]);
+        const float dx = q0.x - fx, dy = q0.y - fy;
+        const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+        const float alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+        const bool ok = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        al[j] = ok ? alpha : 0.f;
+        prod *= 1.f - al[j];
+    }
+    if (has_next)
+        __hip_atomic_store(unit_tseg + (size_t)u * kUnit + lane, fmaxf(prod, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- transmittance entering the unit: products of the units in front (usually already published)
+    float T = 1.0f;
+    for (uint32_t p = u - ui.seg; p < u; p++) {
+        float v = __hip_atomic_load(unit_tseg + (size_t)p * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spins = 0; !__all(v != 0.f) && spins < (1u << 22); spins++) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(unit_tseg + (size_t)p * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        T *= v;
+    }
+
+    // ---- the reference's loop (forward.cu:330-361) over the stored alphas
+    bool dead = !ui.inside || (T < 0.0001f);
+    bool term = false;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f;
+    uint32_t last = 0;
+#pragma unroll
+    for (int j = 0; j < kUnit; j++) {
+        if ((j & (kGroup - 1)) == 0 && ((uint32_t)j >= ui.m || __all(dead))) break;
+        const float2 c01 = *reinterpret_cast<const float2*>(&s_rec[j * kRecQuads + 1].z);
+        const float c2 = s_rec[j * kRecQuads + 2].x;
+        bool c = !dead && (al[j] > 0.f);
+        const float test_T = T * (1.f - al[j]);
+        const bool fin = c && (test_T < 0.0001f);
+        term = term || fin;
+        dead = dead || fin;
+        c = c && !fin;
+        const float w = c ? al[j] * T : 0.f;
+        Cr += c01.x * w;
+        Cg += c01.y * w;
+        Cb += c2 * w;
+        T = c ? test_T : T;
+        last = c ? (ui.base + (uint32_t)j + 1u) : last;
     }
     float* o = unit_out + (size_t)u * 5 * kUnit + lane;
     o[0] = Cr;
@@ -761,20 +845,39 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     const uint32_t unit_wgs = (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG);
     const uint32_t unit_grid = unit_wgs < kUnitGrid ? unit_wgs : kUnitGrid;
     int rc;
+    // k_unit_blend_fused waits for other workgroups inside the launch: its grid must be fully resident.  One less
+    // per CU than the occupancy query says (the query can be one too high when a kernel uses > 80 SGPRs).
+    if (h->fused_grid == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        FR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_unit_blend_fused, 64 * kWavesPerWG, 0));
+        FR_HIP(hipGetDevice(&dev));
+        FR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        per_cu = per_cu > 8 ? 8 : per_cu;
+        h->fused_grid = (per_cu >= 3 && cus > 0) ? (uint32_t)((per_cu - 1) * cus) : 1u;  // 1 = do not use the fused kernel
+    }
+    const bool fused = h->fused_grid > 1 && !(h->no_fused_blend);
+    const uint32_t fgrid = unit_wgs < h->fused_grid ? unit_wgs : h->fused_grid;
     {
         StageScope sc(h, ST_SORT, s);
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
-                           (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap);  // small_blocks == Q
+                           (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
+                           fused ? b.unit_tseg : nullptr);  // small_blocks == Q
         hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
     {
         StageScope sc(h, ST_BLEND_FWD, s);
-        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, v.unit_offset,
-                           v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
-        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, v.unit_offset,
-                           v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        if (fused) {
+            hipLaunchKernelGGL(k_unit_blend_fused, dim3(fgrid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                               (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        } else {
+            hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                               v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
+            hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                               v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg,
+                               b.unit_out);
+        }
         hipLaunchKernelGGL(k_tile_combine, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s,
                            v.counts, v.unit_offset, T, prm.W, prm.H, v.tiles_x,
                            in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);

@@ -203,6 +203,9 @@ struct fr_handle_impl {
     uint32_t* tile_counters = nullptr;
     size_t tile_counter_tiles = 0;
     bool counters_clean = false;
+    uint32_t fused_grid = 0;     // resident-grid size of k_unit_blend_fused (0 = not queried yet, 1 = kernel not usable)
+    bool no_fused_blend = true;  // default; FR_FUSED_BLEND=1 in the environment selects the experimental one-launch
+                                 // k_unit_blend_fused instead of k_unit_tseg + k_unit_blend
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];
 };
