@@ -377,13 +377,18 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const floa
     }
 }
 
-__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a)
+#ifndef FR_PREBWD_WAVES
+#define FR_PREBWD_WAVES 4
+#endif
+constexpr int kPreBwdWaves = FR_PREBWD_WAVES;  // waves per workgroup of k_preprocess_bwd
+
+__global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd(PreBwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_rows[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int M3 = a.M * 3, stride = M3 | 1;
-    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_first = blockIdx.x * (64 * kPreBwdWaves) + wave * 64;
     const int rows = min(64, a.P - wave_first);
     const bool staged = a.shs != nullptr && a.out.dL_dsh != nullptr;
     float* w_rows = s_rows + (size_t)wave * 64 * stride;
@@ -426,8 +431,9 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     a.denom = prm.aux ? prm.aux->denom : nullptr;
     {
         StageScope sc(h, ST_PREPROCESS_BWD, s);
-        const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)4 * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), lds, s, a);
+        const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)kPreBwdWaves * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+        const int wg = 64 * kPreBwdWaves;
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + wg - 1) / wg), dim3(wg), lds, s, a);
     }
     FR_HIP(hipGetLastError());
     if (debug) FR_HIP(hipStreamSynchronize(s));

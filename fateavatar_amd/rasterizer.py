@@ -295,16 +295,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
                 geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug)
+        # gradients nobody can receive are not computed: dL_dcolors without colors_precomp, dL_dcov3D without
+        # cov3D_precomp, dL_dsh without sh (the reference fills them in and autograd drops them)
+        want = {"dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"}
+        if colors_precomp.numel():
+            want.add("dL_dcolors")
+        if cov3Ds_precomp.numel():
+            want.add("dL_dcov3D")
+        if sh.numel():
+            want.add("dL_dsh")
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw, _stats=ctx.stats)
+                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw, _stats=ctx.stats, _want=want)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw, _stats=ctx.stats)
+            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

@@ -6,7 +6,7 @@ name=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out -o p -- "$@" > $out/run.log 2>&1 || true
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out -o p -- "$@" > $out/run.log 2>&1 || true
 python $GRAFT_REPO_ROOT/tools/kstats.py $out/p_results.db > $out/kernels.txt 2>&1 || true
 cat $out/kernels.txt
 python $GRAFT_REPO_ROOT/tools/ktimeline.py $out/p_results.db > $out/timeline.txt 2>&1 || true
