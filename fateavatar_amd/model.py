@@ -24,28 +24,62 @@ class FlatGaussians(torch.nn.Module):
         self.P, self.M = P, M
         # True: render() passes the raw parameters and the rasterizer kernels apply the activations themselves
         self.fused_activations = bool(fused_activations)
-        sizes = [P * 3, P * M * 3, P, P * 3, P * 4]
-        shapes = [(P, 3), (P, M, 3), (P, 1), (P, 3), (P, 4)]
         # one flat value buffer and one flat gradient buffer; every parameter (and its .grad) is a VIEW into
         # them, so autograd accumulates in place and the data-parallel exchange is a single all-reduce
-        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros_like(self.flat)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
         op = t(opacities).reshape(-1).clamp(1e-6, 1 - 1e-6)
-        raw = [t(means3D), t(shs), torch.log(op / (1 - op)), torch.log(t(scales)), t(rotations)]
+        self._bind([t(means3D), t(shs), torch.log(op / (1 - op)).reshape(-1, 1), torch.log(t(scales)), t(rotations)])
+
+    def widths(self):
+        """Floats per Gaussian of each field, in flat-buffer order."""
+        return [3, self.M * 3, 1, 3, 4]
+
+    def _bind(self, raw):
+        """(Re)build the flat value / gradient buffers from one raw tensor per field ([P, ...] each) and make every
+        parameter, and its gradient slot, a view into them."""
+        P = raw[0].shape[0]
+        device = raw[0].device
+        self.P = P
+        sizes = [P * w for w in self.widths()]
+        shapes = [(P, 3), (P, self.M, 3), (P, 1), (P, 3), (P, 4)]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros_like(self.flat)
         self._grad_views = {}
         off = 0
         for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
-            self.flat[off:off + n].copy_(r.reshape(-1))
+            self.flat[off:off + n].copy_(r.detach().reshape(-1))
             p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
             gv = self.flat_grad[off:off + n].view(shp)
             self._grad_views[name] = gv
             if name in ("_xyz", "_features") or self.fused_activations:
-                # these two reach the rasterizer untouched: it writes their gradient straight into the flat
+                # these reach the rasterizer untouched: it writes their gradient straight into the flat
                 # buffer (rasterizer.py `_fr_grad_out`), no accumulation kernel, no zero-fill
                 p._fr_grad_out = gv
             setattr(self, name, p)
             off += n
+
+    @torch.no_grad()
+    def resize(self, keep_mask=None, new_rows=None):
+        """Prune and / or append Gaussians (reference: _prune_low_opacity_points / _uv_densify,
+        model/fateavatar.py:610-711): rows where `keep_mask` is False are dropped, then `new_rows` — one raw tensor
+        [n_new, ...] per field, in FIELDS order — are appended.  The flat buffers are rebuilt and every parameter is a
+        new nn.Parameter (as in the reference); returns the row map `old_index` (int64 [P_new], -1 for appended rows)
+        that optimizer state has to follow (FusedAdam.remap_rows)."""
+        dev = self.flat.device
+        P_old = self.P
+        keep = torch.ones(P_old, dtype=torch.bool, device=dev) if keep_mask is None else keep_mask.to(dev).bool().reshape(-1)
+        if keep.numel() != P_old:
+            raise ValueError("keep_mask must have one entry per Gaussian")
+        old_index = torch.nonzero(keep).reshape(-1)
+        raw = [getattr(self, name).detach()[old_index] for name, _ in self.FIELDS]
+        n_new = 0
+        if new_rows is not None:
+            n_new = int(new_rows[0].shape[0])
+            for i, (r, add) in enumerate(zip(raw, new_rows)):
+                add = add.to(dev, torch.float32).reshape((n_new,) + tuple(r.shape[1:]))
+                raw[i] = torch.cat([r, add], dim=0)
+        self._bind(raw)
+        return torch.cat([old_index, torch.full((n_new,), -1, dtype=torch.int64, device=dev)])
 
     def _p(self, name):
         return getattr(self, name)

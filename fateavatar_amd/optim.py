@@ -50,6 +50,37 @@ class FusedAdam:
         cfg.beta1, cfg.beta2, cfg.eps, cfg.grad_scale = float(betas[0]), float(betas[1]), float(eps), float(grad_scale)
         self.cfg = cfg
 
+    @torch.no_grad()
+    def remap_rows(self, flat_param: torch.Tensor, flat_grad: torch.Tensor, old_index: torch.Tensor,
+                   widths: Sequence[int], old_rows: int, zero_fields: Sequence[int] = ()) -> None:
+        """Optimizer-state surgery after a prune / densify of row-structured parameters (reference:
+        model/fateavatar.py:640-651,688-694): the buffer holds one [rows, width] block per field, `old_index[r]` is
+        the old row new row r came from, or -1 for an appended row, whose moments start at zero (`torch.zeros_like`
+        in the reference).  Rebinds the optimizer to the new flat buffers; the step count is kept, as the reference
+        keeps `state["step"]`.  Fields listed in `zero_fields` get zero moments everywhere (_reset_opacity,
+        model/fateavatar.py:713-731)."""
+        new_rows = int(old_index.numel())
+        if sum(widths) * new_rows != flat_param.numel() or flat_param.shape != flat_grad.shape:
+            raise RuntimeError("remap_rows: buffer size does not match rows x widths")
+        src = old_index.clamp(min=0)
+        fresh = (old_index < 0)
+        new_m, new_v = torch.zeros_like(flat_param), torch.zeros_like(flat_param)
+        o_old = o_new = 0
+        for f, w in enumerate(widths):
+            for old, new in ((self.exp_avg, new_m), (self.exp_avg_sq, new_v)):
+                blk = old[o_old:o_old + old_rows * w].view(old_rows, w)[src]
+                blk[fresh] = 0.0
+                if f in zero_fields:
+                    blk.zero_()
+                new[o_new:o_new + new_rows * w].view(new_rows, w).copy_(blk)
+            o_old += old_rows * w
+            o_new += new_rows * w
+        self.param, self.grad, self.exp_avg, self.exp_avg_sq = flat_param, flat_grad, new_m, new_v
+        end = 0
+        for i, w in enumerate(widths):
+            end += new_rows * w
+            self.cfg.segment_end[i] = end
+
     def set_grad_scale(self, s: float) -> None:
         self.cfg.grad_scale = float(s)
 

@@ -109,6 +109,59 @@ class TrainStep:
             self.adam.step()
         return self.loss
 
+    # -- Gaussian maintenance (reference: train/iteration.py:62-86 -> model/fateavatar.py:610-731), generic-3DGS flavour:
+    #    the FateAvatar versions additionally carry the mesh binding (face index, barycentrics) of every row
+    @torch.no_grad()
+    def _after_resize(self, old_index, old_rows, zero_fields=()):
+        pc = self.pc
+        self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), old_rows, zero_fields)
+        # statistics restart from zero after a change of the point set (model/fateavatar.py:667-672)
+        self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
+        self.denom = torch.zeros((pc.P, 1), device=self.dev)
+        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom)
+        self._graph, self._eager_steps = None, 0   # buffers moved: the captured step is stale
+        from . import rasterizer
+        rasterizer.set_no_wait(False)
+
+    @torch.no_grad()
+    def prune_low_opacity(self, min_opacity: float = 0.005) -> int:
+        """_prune_low_opacity_points (model/fateavatar.py:674-711).  Returns the number of Gaussians removed."""
+        pc = self.pc
+        keep = ~(torch.sigmoid(pc._opacity) < min_opacity).reshape(-1)
+        old_rows = pc.P
+        old_index = pc.resize(keep_mask=keep)
+        self._after_resize(old_index, old_rows)
+        return old_rows - pc.P
+
+    @torch.no_grad()
+    def densify_by_gradient(self, increase_num: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """The sampling and cloning rule of _uv_densify (model/fateavatar.py:610-672) without the mesh re-binding:
+        `increase_num` rows drawn with probability proportional to xyz_gradient_accum (multinomial, with
+        replacement), cloned with their scale multiplied by 0.75; appended rows start with zero Adam moments.
+        Data-parallel runs must pass identically seeded generators (or broadcast the returned indices).  Returns the
+        sampled row indices."""
+        pc = self.pc
+        w = self.xyz_gradient_accum.reshape(-1)
+        if float(w.sum()) <= 0:
+            raise RuntimeError("no densification statistics accumulated yet")
+        idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+        rows = [getattr(pc, name).detach()[idx].clone() for name, _ in pc.FIELDS]
+        rows[3] = torch.log(torch.exp(rows[3]) * 0.75)   # _scaling
+        old_rows = pc.P
+        old_index = pc.resize(new_rows=rows)
+        self._after_resize(old_index, old_rows)
+        return idx
+
+    @torch.no_grad()
+    def reset_opacity(self) -> None:
+        """_reset_opacity (model/fateavatar.py:713-731): opacity <- min(opacity, 0.01), its Adam moments <- 0."""
+        pc = self.pc
+        cur = torch.sigmoid(pc._opacity)
+        new = torch.minimum(cur, torch.full_like(cur, 0.01))
+        pc._opacity.data.copy_(torch.log(new / (1 - new)))
+        old_index = torch.arange(pc.P, device=self.dev)
+        self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), pc.P, zero_fields=(2,))
+
     def check(self) -> None:
         """After synchronising: raise if a captured (no-wait) frame overflowed its binning capacity."""
         from . import rasterizer

@@ -447,3 +447,77 @@ def test_train_step_graph_equals_eager_and_fits(gpu_device):
     assert float((flat_g - flat_e).abs().max()) < 5e-3
     assert torch.equal(ts_g.denom, ts_e.denom) and float(ts_e.denom.max()) == 24.0
     assert torch.allclose(ts_g.xyz_gradient_accum, ts_e.xyz_gradient_accum, rtol=5e-2, atol=1e-7)
+
+
+def test_prune_densify_reset_follow_reference_optimizer_surgery(gpu_device):
+    """TrainStep.prune_low_opacity / densify_by_gradient / reset_opacity: parameters AND Adam moments follow the row
+    surgery of model/fateavatar.py:610-731 (kept rows keep their moments, appended rows start at zero, the step count
+    is kept), and the (re-captured) step keeps training afterwards."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from fateavatar_amd.train import TrainStep
+    P, res = 3000, 96
+    truth = scenes.head_scene(P=P, res=res, sh_degree=1, seed=4, opacity=0.5)
+    cam = TorchCamera(truth.camera, gpu_device)
+    bg = torch.from_numpy(truth.bg).to(gpu_device)
+    pc_true = FlatGaussians(truth.means3D, truth.shs, truth.opacities, truth.scales, truth.rotations, 1, gpu_device,
+                            fused_activations=True)
+    with torch.no_grad():
+        gt = render(cam, pc_true, bg)["render"].clone()
+    op0 = truth.opacities.copy()
+    op0[::9] = 0.002  # below the pruning threshold
+    pc = FlatGaussians(truth.means3D, truth.shs * 0.5, op0, truth.scales, truth.rotations, 1, gpu_device,
+                       fused_activations=True)
+    ts = TrainStep(pc, TorchCamera(truth.camera, gpu_device), bg, lrs=dict(opacity=1e-4))
+    for _ in range(5):
+        ts.step(cam, gt)
+    torch.cuda.synchronize()
+    assert ts._graph is not None
+
+    def blocks(flat, rows):
+        out, o = [], 0
+        for w in pc.widths():
+            out.append(flat[o:o + rows * w].view(rows, w).clone())
+            o += rows * w
+        return out
+
+    # ---- prune
+    rows0 = pc.P
+    keep = ~(torch.sigmoid(pc._opacity) < 0.005).reshape(-1)
+    p0, m0, v0 = blocks(pc.flat, rows0), blocks(ts.adam.exp_avg, rows0), blocks(ts.adam.exp_avg_sq, rows0)
+    removed = ts.prune_low_opacity(0.005)
+    assert removed == int((~keep).sum()) and removed >= P // 9 - 1 and pc.P == rows0 - removed
+    for a, b in zip(blocks(pc.flat, pc.P) + blocks(ts.adam.exp_avg, pc.P) + blocks(ts.adam.exp_avg_sq, pc.P), p0 + m0 + v0):
+        assert torch.equal(a, b[keep])
+    assert ts.adam.step_count == 5 and ts._graph is None
+    for _ in range(4):
+        ts.step(cam, gt)
+    torch.cuda.synchronize()
+    assert ts._graph is not None and ts.adam.step_count == 9
+
+    # ---- densify
+    rows1 = pc.P
+    p1, m1 = blocks(pc.flat, rows1), blocks(ts.adam.exp_avg, rows1)
+    idx = ts.densify_by_gradient(200, generator=torch.Generator(device=gpu_device).manual_seed(0))
+    assert pc.P == rows1 + 200 and int(idx.max()) < rows1
+    p2, m2, v2 = blocks(pc.flat, pc.P), blocks(ts.adam.exp_avg, pc.P), blocks(ts.adam.exp_avg_sq, pc.P)
+    for f in range(5):
+        assert torch.equal(p2[f][:rows1], p1[f]) and torch.equal(m2[f][:rows1], m1[f])
+        assert float(m2[f][rows1:].abs().max()) == 0.0 and float(v2[f][rows1:].abs().max()) == 0.0
+        want = torch.log(torch.exp(p1[f][idx]) * 0.75) if f == 3 else p1[f][idx]
+        assert torch.equal(p2[f][rows1:], want)
+    assert float(ts.denom.abs().max()) == 0.0 and ts.denom.shape == (pc.P, 1)
+    l0 = float(ts.step(cam, gt))
+    for _ in range(6):
+        l1 = float(ts.step(cam, gt))
+    assert l1 < l0
+
+    # ---- opacity reset
+    ts.reset_opacity()
+    assert float(torch.sigmoid(pc._opacity.detach()).max()) <= 0.01 + 1e-6
+    mo = blocks(ts.adam.exp_avg, pc.P)
+    assert float(mo[2].abs().max()) == 0.0 and float(mo[0].abs().max()) > 0.0
+    ts.step(cam, gt)
+    torch.cuda.synchronize()
+    ts.check()

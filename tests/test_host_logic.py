@@ -105,3 +105,26 @@ def test_fused_adam_and_train_step_refuse_cpu_tensors():
     p, g = torch.zeros(16), torch.zeros(16)
     with pytest.raises(RuntimeError, match="no CPU path"):
         FusedAdam(p, g, [(16, 1e-3)])
+
+
+def test_flat_gaussians_resize_row_map():
+    """Prune + append on the flat parameter holder (model/fateavatar.py:610-711 semantics): surviving rows keep their
+    values and order, appended rows follow, and the returned row map is what optimizer state must follow."""
+    import numpy as np
+    import torch
+    from fateavatar_amd.model import FlatGaussians
+    P, M = 10, 4
+    rng = np.random.default_rng(0)
+    pc = FlatGaussians(rng.normal(size=(P, 3)).astype(np.float32), rng.normal(size=(P, M, 3)).astype(np.float32),
+                       rng.uniform(0.1, 0.9, (P, 1)).astype(np.float32), rng.uniform(0.1, 0.2, (P, 3)).astype(np.float32),
+                       rng.normal(size=(P, 4)).astype(np.float32), 1, torch.device("cpu"))
+    old = {n: getattr(pc, n).detach().clone() for n, _ in pc.FIELDS}
+    keep = torch.tensor([1, 0, 1, 1, 0, 1, 1, 1, 0, 1], dtype=torch.bool)
+    new_rows = [old[n][[2, 5]].clone() for n, _ in pc.FIELDS]
+    row_map = pc.resize(keep, new_rows)
+    assert pc.P == 9 and row_map.tolist() == [0, 2, 3, 5, 6, 7, 9, -1, -1]
+    assert pc.flat.numel() == sum(pc.widths()) * pc.P == pc.flat_grad.numel()
+    for n, _ in pc.FIELDS:
+        p = getattr(pc, n)
+        assert isinstance(p, torch.nn.Parameter) and p.data_ptr() >= pc.flat.data_ptr()
+        assert torch.equal(p[:7], old[n][keep]) and torch.equal(p[7:], old[n][[2, 5]])
