@@ -30,6 +30,31 @@ class FlatGaussians(torch.nn.Module):
         op = t(opacities).reshape(-1).clamp(1e-6, 1 - 1e-6)
         self._bind([t(means3D), t(shs), torch.log(op / (1 - op)).reshape(-1, 1), torch.log(t(scales)), t(rotations)])
 
+    @classmethod
+    def from_raw(cls, xyz, features, opacity, scaling, rotation, sh_degree: int, device, fused_activations=False):
+        """From RAW parameters (logit opacity, log scale, un-normalised quaternion), e.g. `ply.load_ply()`."""
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+        self.max_sh_degree, self.M = sh_degree, int(np.shape(features)[1])
+        self.fused_activations = bool(fused_activations)
+        self._bind([t(xyz), t(features), t(opacity).reshape(-1, 1), t(scaling), t(rotation)])
+        return self
+
+    def save_ply(self, path: str) -> None:
+        """GaussianModel.save_ply (gaussian_model.py:205-223)."""
+        from . import ply
+        g = lambda n: getattr(self, n).detach().cpu().numpy()  # noqa: E731
+        ply.save_ply(path, g("_xyz"), g("_features"), g("_opacity"), g("_scaling"), g("_rotation"))
+
+    @classmethod
+    def load_ply(cls, path: str, device, max_sh_degree=None, fused_activations=False):
+        """GaussianModel.load_ply (gaussian_model.py:230-269)."""
+        from . import ply
+        d = ply.load_ply(path, max_sh_degree)
+        return cls.from_raw(d["xyz"], d["features"], d["opacity"], d["scaling"], d["rotation"], d["sh_degree"], device,
+                            fused_activations)
+
     def widths(self):
         """Floats per Gaussian of each field, in flat-buffer order."""
         return [3, self.M * 3, 1, 3, 4]

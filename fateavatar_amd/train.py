@@ -162,6 +162,42 @@ class TrainStep:
         old_index = torch.arange(pc.P, device=self.dev)
         self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), pc.P, zero_fields=(2,))
 
+    # -- checkpoint / resume (reference layout: Trainer.save_checkpoint, train/trainer.py:396-435 — a dict with
+    #    'global_step' and 'model' = the Gaussian parameters under the GaussianModel names and shapes; the reference
+    #    does not save optimizer state, `optimizer` and `densification` here are additions a resume needs)
+    @torch.no_grad()
+    def state_dict(self) -> dict:
+        pc = self.pc
+        f = pc._features.detach()
+        model = {"_xyz": pc._xyz.detach().clone(), "_features_dc": f[:, :1, :].clone(), "_features_rest": f[:, 1:, :].clone(),
+                 "_opacity": pc._opacity.detach().clone(), "_scaling": pc._scaling.detach().clone(),
+                 "_rotation": pc._rotation.detach().clone()}
+        return {"global_step": self.adam.step_count, "model": model,
+                "optimizer": {"exp_avg": self.adam.exp_avg.clone(), "exp_avg_sq": self.adam.exp_avg_sq.clone(),
+                              "state": self.adam.state.clone()},
+                "densification": {"xyz_gradient_accum": self.xyz_gradient_accum.clone(), "denom": self.denom.clone()}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict) -> None:
+        pc, m = self.pc, sd["model"]
+        rows = [m["_xyz"], torch.cat([m["_features_dc"], m["_features_rest"]], dim=1), m["_opacity"], m["_scaling"],
+                m["_rotation"]]
+        if int(rows[1].shape[1]) != pc.M:
+            raise ValueError("checkpoint holds a different number of SH coefficients")
+        old_rows = pc.P
+        pc._bind([r.to(self.dev, torch.float32) for r in rows])
+        # rebind the optimizer to the new buffers (row map irrelevant: every moment is overwritten below)
+        self._after_resize(torch.full((pc.P,), -1, dtype=torch.int64, device=self.dev), old_rows)
+        opt = sd.get("optimizer")
+        if opt is not None:
+            self.adam.exp_avg.copy_(opt["exp_avg"])
+            self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            self.adam.state.copy_(opt["state"])
+        dens = sd.get("densification")
+        if dens is not None:
+            self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])
+            self.denom.copy_(dens["denom"])
+
     def check(self) -> None:
         """After synchronising: raise if a captured (no-wait) frame overflowed its binning capacity."""
         from . import rasterizer

@@ -521,3 +521,38 @@ def test_prune_densify_reset_follow_reference_optimizer_surgery(gpu_device):
     ts.step(cam, gt)
     torch.cuda.synchronize()
     ts.check()
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(gpu_device, tmp_path):
+    """TrainStep.state_dict -> torch.save -> a fresh TrainStep.load_state_dict: the resumed run follows the
+    uninterrupted one (up to the summation order of the gradient atomics); the saved `model` uses the GaussianModel
+    parameter names and shapes."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from fateavatar_amd.train import TrainStep
+    truth = scenes.head_scene(P=2500, res=80, sh_degree=1, seed=6, opacity=0.5)
+    cam = TorchCamera(truth.camera, gpu_device)
+    bg = torch.from_numpy(truth.bg).to(gpu_device)
+    mk = lambda shs: FlatGaussians(truth.means3D, shs, truth.opacities, truth.scales, truth.rotations, 1, gpu_device,  # noqa: E731
+                                   fused_activations=True)
+    with torch.no_grad():
+        gt = render(cam, mk(truth.shs), bg)["render"].clone()
+    a = TrainStep(mk(truth.shs * 0.3), TorchCamera(truth.camera, gpu_device), bg)
+    for _ in range(6):
+        a.step(cam, gt)
+    sd = a.state_dict()
+    assert sd["global_step"] == 6 and sd["model"]["_features_dc"].shape == (2500, 1, 3)
+    assert sd["model"]["_features_rest"].shape == (2500, 3, 3) and sd["model"]["_opacity"].shape == (2500, 1)
+    torch.save(sd, tmp_path / "ck.pth")
+    for _ in range(5):
+        a.step(cam, gt)
+    b = TrainStep(mk(truth.shs * 0.0), TorchCamera(truth.camera, gpu_device), bg)
+    b.load_state_dict(torch.load(tmp_path / "ck.pth", map_location=gpu_device))
+    assert b.adam.step_count == 6
+    for _ in range(5):
+        b.step(cam, gt)
+    torch.cuda.synchronize()
+    assert b.adam.step_count == a.adam.step_count == 11
+    assert float((a.pc.flat - b.pc.flat).abs().max()) < 2e-3
+    assert torch.equal(a.denom, b.denom)
