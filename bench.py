@@ -5,10 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` (activations in stock
-PyTorch + the HIP rasterizer through the reference's Python API) followed by `loss.backward()` down
-to the raw Gaussian parameters; at N > 1 each rank renders its own view of the replicated Gaussians
-and the step ends with ONE RCCL all-reduce(AVG) of the flat gradient buffer.
+A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` through the reference's Python
+API (activations inside the HIP preprocess kernels by default, `--torch-activations` for the reference's
+stock PyTorch ops) followed by the backward pass down to the raw Gaussian parameters; at N > 1 each rank
+renders its own view of the replicated Gaussians and the step ends with ONE RCCL all-reduce(AVG) of the flat
+gradient buffer.
 Workload (config.workload): BASELINE.json configs[1] — 100 000 Gaussians sampled on the head
 template, 512x512, SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident
 in HBM before the timed region.
@@ -16,8 +17,9 @@ in HBM before the timed region.
 The JSON line carries
   roofline     — the blend backward (the graded kernel): algorithmic bytes 76*R + 20*H*W + 8*T
                  (R = num_rendered and T = 16x16 tiles in reference semantics) divided by
-                 that kernel's mean launch duration, measured with HIP events on the launch stream
-                 during the timed steps, against the 8 TB/s HBM peak.
+                 that kernel's mean launch duration, measured with HIP events on the launch stream over
+                 eager launches of the same frame right after the timed region (events recorded inside a
+                 replayed graph cannot be read back), against the 8 TB/s HBM peak.
   cpu_baseline — the CPU oracle (oracle/fr_oracle.c, OpenMP, kind "port": the reference has no CPU
                  rasterizer) timed on the host cores on a bounded sample of the same frames.
 """
@@ -102,7 +104,7 @@ def main():
 
     def frame():
         pc.begin_step()                       # grads set to None: backward assigns (zero_grad(set_to_none=True))
-        out = render(cam, pc, bg)             # activations (stock PyTorch) + HIP rasterizer forward
+        out = render(cam, pc, bg)             # activations + HIP rasterizer forward
         torch.autograd.backward(out["render"], grad_tensors=dL_dpix)  # HIP rasterizer backward + activation backward
 
     def eager_step():

@@ -96,7 +96,7 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t max_tile_list;
     uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
-    uint32_t large_cursor;   // work-queue head for the large-tile sorter
+    uint32_t reserved0;
     uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
     uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
     uint32_t pad2[6];
