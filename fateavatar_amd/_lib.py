@@ -61,7 +61,7 @@ class fr_counts(C.Structure):
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_read_counts", "fr_backward", "fr_mark_visible", "fr_image_final_T",
-           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_adam_step"]
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step"]
 
 
 def build(force: bool = False) -> str:
@@ -126,6 +126,8 @@ def lib():
     L.fr_knn_workspace_bytes.restype = C.c_size_t
     L.fr_knn_mean_dist2.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
     L.fr_knn_mean_dist2.restype = C.c_int
+    L.fr_knn_nearest_dist2.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
+    L.fr_knn_nearest_dist2.restype = C.c_int
     L.fr_adam_step.argtypes = [C.POINTER(fr_adam_config), _fp, _fp, _fp, _fp, C.c_uint64, _fp, C.c_void_p]
     L.fr_adam_step.restype = C.c_int
     _lib = L

@@ -215,7 +215,13 @@ size_t fr_knn_workspace_bytes(int32_t P) { return knn_workspace_bytes(P); }
 int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (P < 0 || (P > 0 && (!points || !out || !workspace))) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
-    return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), 0);
+}
+
+int fr_knn_nearest_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (P < 0 || (P > 0 && (!points || !out || !workspace))) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
+    return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), 1);
 }
 
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

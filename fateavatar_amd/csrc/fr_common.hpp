@@ -241,7 +241,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
 int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
                     const void* image, const void* binning, const float* dL_dpix, const fr_grads& g, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
-int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s, int mode);
 size_t knn_workspace_bytes(int P);
 // zero `bytes` (multiple of 16, 16-byte aligned) with a plain kernel.  hipMemsetAsync is avoided on purpose: as a
 // memset NODE of a captured graph it stopped taking effect once an eager kernel had been launched between two

@@ -133,8 +133,10 @@ __device__ __forceinline__ void update3(float dist, float (&best)[3])
         }
 }
 
+// mode 0: mean of the three smallest squared distances (distCUDA2); mode 1: the smallest one (the nearest other
+// point: what pytorch3d's knn_points(p, p, K=6).dists[..., 1] is used for in model/fateavatar.py:597-608)
 __global__ void __launch_bounds__(256) k_knn_search(int P, const KnnHeader* h, int G, const uint32_t* __restrict__ offset,
-                                                    const float4* __restrict__ sorted, float* out)
+                                                    const float4* __restrict__ sorted, float* out, int mode)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P) return;
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(256) k_knn_search(int P, const KnnHeader* h, i
             }
         if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == G - 1 && y1 == G - 1 && z1 == G - 1) break;  // whole grid seen
     }
-    out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+    out[__float_as_uint(me.w)] = mode == 1 ? best[0] : (best[0] + best[1] + best[2]) / 3.0f;
 }
 
 static int knn_grid_size(int P)
@@ -198,7 +200,7 @@ size_t knn_workspace_bytes(int P)
            align_up((size_t)(P > 0 ? P : 1) * 16, 256);
 }
 
-int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s)
+int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s, int mode)
 {
     if (P <= 0) return FR_OK;
     if (ws_bytes < knn_workspace_bytes(P)) return fail_msg(FR_ERR_INVALID_ARGUMENT, "knn workspace too small");
@@ -219,7 +221,7 @@ int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes
     hipLaunchKernelGGL(k_knn_count, dim3(nb), dim3(256), 0, s, P, points, h, G, cell_count);
     hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, s, (uint32_t)cells, cell_count, cell_offset, cursor);
     hipLaunchKernelGGL(k_knn_scatter, dim3(nb), dim3(256), 0, s, P, points, h, G, cursor, sorted);
-    hipLaunchKernelGGL(k_knn_search, dim3(nb), dim3(256), 0, s, P, h, G, cell_offset, sorted, out);
+    hipLaunchKernelGGL(k_knn_search, dim3(nb), dim3(256), 0, s, P, h, G, cell_offset, sorted, out, mode);
     FR_HIP(hipGetLastError());
     return FR_OK;
 }

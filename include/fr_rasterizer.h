@@ -215,6 +215,11 @@ int fr_debug_selftest_reduce(const float* in, float* out, void* hip_stream);
 size_t fr_knn_workspace_bytes(int32_t P);
 int fr_knn_mean_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
                       void* hip_stream);
+/* out[i] = squared distance from points[i] to the nearest OTHER point (FLT_MAX if P == 1): the quantity
+ * FateAvatar.get_init_scale_by_knn takes from pytorch3d's knn_points(p, p, K=6).dists[..., 1]
+ * (model/fateavatar.py:597-608).  Same workspace as fr_knn_mean_dist2. */
+int fr_knn_nearest_dist2(int32_t P, const float* points, float* out, void* workspace, size_t workspace_bytes,
+                         void* hip_stream);
 
 #ifdef __cplusplus
 }

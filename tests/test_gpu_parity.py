@@ -227,6 +227,24 @@ def test_knn_bit_exact_vs_oracle(gpu_device):
         np.testing.assert_array_equal(got, ref)
 
 
+def test_nearest_neighbour_distance_and_init_scale(gpu_device):
+    """fr_knn_nearest_dist2 == brute-force nearest-neighbour distance; init_scale_by_knn reproduces the config-2 spacing
+    SURVEY.md §8d measured with the reference's pytorch3d path (6.085e-4 on 100 k template samples)."""
+    import torch
+    from scipy.spatial import cKDTree
+    from fateavatar_amd.knn import init_scale_by_knn, nearest_dist2
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(4000, 3)).astype(np.float32)
+    got = nearest_dist2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=2)
+    assert np.allclose(got, d[:, 1] ** 2, rtol=1e-4, atol=1e-12)
+    verts, faces, from_fixture = scenes.head_geometry()
+    mean_s, max_s, log_s = init_scale_by_knn(torch.from_numpy(scenes.sample_mesh(verts, faces, 100_000, seed=0)).to(gpu_device))
+    assert abs(float(max_s) - 10 * float(mean_s)) < 1e-9 and abs(float(log_s) - np.log(float(mean_s))) < 1e-5
+    if from_fixture == "head_template":
+        assert abs(float(mean_s) - 6.085e-4) < 0.05e-4, float(mean_s)
+
+
 def test_render_api_autograd_path(gpu_device):
     """render() + autograd down to the raw parameters == oracle grads chained through the activations."""
     import torch
