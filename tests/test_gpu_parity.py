@@ -59,16 +59,9 @@ def _check_forward(o, h, name):
     assert np.isfinite(col).all()
 
 
-@pytest.mark.parametrize("name", list(SCENES))
-def test_forward_backward_vs_oracle(name, gpu_device):
-    s = SCENES[name]
-    o = util.oracle_forward(s)
-    h = util.HipFrame(s, gpu_device)
-    _check_forward(o, h, name)
-    rng = np.random.default_rng(11)
-    H, W = s.camera.image_height, s.camera.image_width
-    dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
-    ob = oracle_backward = __import__("oracle.oracle", fromlist=["backward"]).backward(o, dpix)
+def _check_backward(o, h, dpix, name):
+    from oracle import oracle
+    ob = oracle.backward(o, dpix)
     hb = h.backward(dpix)
     for k in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
               "dL_drotations"]:
@@ -82,6 +75,18 @@ def test_forward_backward_vs_oracle(name, gpu_device):
         fr = util.frac_close(got, ref, 1e-4, 1e-6 * scale)
         rl = util.rel_l2(got, ref)
         assert fr >= 0.999 and rl <= 2e-4, (name, k, fr, rl)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_forward_backward_vs_oracle(name, gpu_device):
+    s = SCENES[name]
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, name)
+    rng = np.random.default_rng(11)
+    H, W = s.camera.image_height, s.camera.image_width
+    dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+    _check_backward(o, h, dpix, name)
 
 
 def test_colors_precomp_and_cov3d_precomp(gpu_device):

@@ -1,0 +1,38 @@
+"""One-off fuzz: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box."""
+import sys, os, traceback
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fateavatar_amd import scenes
+from tests import util
+from tests.test_gpu_parity import _check_forward, _check_backward
+from oracle import oracle
+
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+bad = 0
+for it in range(n):
+    big = len(sys.argv) > 3
+    P = int(rng.integers(1, 60000 if big else 6000))
+    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
+    deg = int(rng.integers(0, 4))
+    slo = float(10 ** rng.uniform(-3.5, -1.5)); shi = slo * float(rng.uniform(1, 20))
+    olo = float(rng.uniform(0.001, 0.5)); ohi = float(rng.uniform(olo, 1.0))
+    spread = float(rng.uniform(0.05, 1.5))
+    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
+              opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
+              bg=tuple(rng.uniform(0, 1, 3)))
+    name = f"fuzz{it}: P={P} {H}x{W} deg={deg} scale=[{slo:.4f},{shi:.4f}] op=[{olo:.3f},{ohi:.3f}] spread={spread:.2f}"
+    try:
+        s = scenes.random_scene(P, H, W, **kw)
+        o = util.oracle_forward(s)
+        h = util.HipFrame(s, dev)
+        _check_forward(o, h, name)
+        dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+        _check_backward(o, h, dpix, name)
+        print("ok  ", name, "inst", h.counts.num_instances, "maxlist", h.counts.max_tile_list, flush=True)
+    except Exception as e:
+        bad += 1
+        print("FAIL", name, repr(e)[:300], flush=True)
+        traceback.print_exc(limit=2)
+print("failures:", bad)
