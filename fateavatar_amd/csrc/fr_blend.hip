@@ -154,6 +154,41 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
     r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);
 }
 
+// Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
+// gathers of four slots are issued together and unconditionally (an out-of-range slot reads Gaussian 0 and is not
+// written): one memory round trip per four slots instead of one per slot.
+template <int K>
+__device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint32_t n, uint32_t base, const u64 (&v)[K],
+                                              int lane, const GeomView& g)
+{
+    constexpr int B = K < 4 ? K : 4;
+    constexpr float kLog2e = 1.4426950408889634f;
+#pragma unroll
+    for (int r0 = 0; r0 < K; r0 += B) {
+        float2 xy[B];
+        float4 co[B], c[B];
+        uint32_t id[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
+            id[u] = i < n ? (uint32_t)v[r0 + u] : 0u;
+            xy[u] = g.means2D[id[u]];
+            co[u] = g.conic_opacity[id[u]];
+            c[u] = g.rgba[id[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
+            if (i < n) {
+                float4* r = recs + (size_t)(start + i) * kRecQuads;
+                r[0] = make_float4(xy[u].x, xy[u].y, co[u].x * (-0.5f * kLog2e), co[u].y * (-kLog2e));
+                r[1] = make_float4(co[u].z * (-0.5f * kLog2e), co[u].w, c[u].x, c[u].y);
+                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), 0.f, 0.f);
+            }
+        }
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, uint32_t start, uint32_t n, int lane,
                                                const GeomView& g)
@@ -165,11 +200,7 @@ __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, ui
         v[r] = i < n ? keys[start + i] : ~0ull;
     }
     wave_sort<K>(v, lane);
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const uint32_t i = (uint32_t)(r * 64 + lane);
-        if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
-    }
+    write_records<K>(recs, start, n, 0u, v, lane, g);
 }
 
 // Four waves sort up to 4 * 64 * K keys together (K = 4: 1024, K = 16: 4096): each wave sorts its 64*K keys in
@@ -217,11 +248,7 @@ __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, u
     cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
     reg_cleaners_from<K, K / 2>(v);
     lane_cleaners_from_32<K>(v, lane);
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
-        if (i < n) write_record(recs, start + i, (uint32_t)v[r], g);
-    }
+    write_records<K>(recs, start, n, (uint32_t)(wave * KW), v, lane, g);
 }
 
 #undef SortXchg
