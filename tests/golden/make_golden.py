@@ -13,6 +13,7 @@ its rasterizer is CUDA and cannot be built in this image):
   golden_camera.npz  volume_rendering/camera_3dgs.py:22-72, tools/gs_utils/graphics_utils.py:51-84
                      world_view_transform / projection / full_proj_transform / camera_center
   golden_misc.npz    tools/gs_utils/general_utils.py:18-19 inverse_sigmoid
+  golden_binding.npz volume_rendering/mesh_compute.py:27-59 compute_face_orientation (+ scale) / compute_face_normals
   head_template_geom.npz  vertices + triangle indices of weights/head_template_mouth_close.obj
                      (input geometry of BASELINE.json configs 2 and 5; data, not code)
 """
@@ -123,7 +124,23 @@ def gen_head():
                         faces=np.asarray(faces, np.int32))
 
 
+def gen_binding():
+    """volume_rendering/mesh_compute.py:27-59: per-face frame (a0, a1, a2), face scale and unnormalised face normals —
+    the mesh part of FateAvatar's Gaussian binding (model/fateavatar.py:225-233)."""
+    from volume_rendering import mesh_compute
+    g = torch.Generator().manual_seed(77)
+    V, F = 60, 90
+    verts = torch.randn(2, V, 3, generator=g) * 0.1                      # [bs, V, 3], two frames
+    faces = torch.stack([torch.randperm(V, generator=g)[:3] for _ in range(F)]).int()
+    verts[:, faces[5, 2].long()] = verts[:, faces[5, 1].long()]           # a degenerate (zero-area) face: eps clamps
+    orien, scale = mesh_compute.compute_face_orientation(verts, faces, return_scale=True)
+    normals = mesh_compute.compute_face_normals(verts, faces)
+    np.savez_compressed(os.path.join(OUT, "golden_binding.npz"), verts=verts.numpy(), faces=faces.numpy(),
+                        orientation=orien.numpy(), scale=scale.numpy(), normals=normals.numpy())
+
+
 if __name__ == "__main__":
+    gen_binding()
     gen_sh()
     gen_cov3d()
     gen_camera()
