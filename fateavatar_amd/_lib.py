@@ -44,6 +44,13 @@ class fr_adam_config(C.Structure):
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("grad_scale", C.c_float)]
 
 
+class fr_binding(C.Structure):
+    _fields_ = [("N", C.c_int32), ("V", C.c_int32), ("F", C.c_int32), ("verts", C.c_void_p), ("faces", C.c_void_p),
+                ("face_index", C.c_void_p), ("bary", C.c_void_p), ("face_scale_canonical", C.c_void_p),
+                ("shell_len", C.c_float), ("resize_scale", C.c_int32), ("offset", C.c_void_p), ("rotation", C.c_void_p),
+                ("scaling", C.c_void_p)]
+
+
 class fr_inputs(C.Structure):
     _fields_ = [(n, _fp) for n in ("background", "means3D", "shs", "colors_precomp", "opacities", "scales",
                                    "rotations", "cov3D_precomp", "viewmatrix", "projmatrix", "campos")]
@@ -61,7 +68,8 @@ class fr_counts(C.Structure):
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_read_counts", "fr_backward", "fr_mark_visible", "fr_image_final_T",
-           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step"]
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_face_scale",
+           "fr_bind_forward", "fr_bind_backward"]
 
 
 def build(force: bool = False) -> str:
@@ -128,6 +136,12 @@ def lib():
     L.fr_knn_mean_dist2.restype = C.c_int
     L.fr_knn_nearest_dist2.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
     L.fr_knn_nearest_dist2.restype = C.c_int
+    L.fr_face_scale.argtypes = [C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_void_p]
+    L.fr_face_scale.restype = C.c_int
+    L.fr_bind_forward.argtypes = [C.POINTER(fr_binding), _fp, _fp, _fp, C.c_void_p]
+    L.fr_bind_forward.restype = C.c_int
+    L.fr_bind_backward.argtypes = [C.POINTER(fr_binding), _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]
+    L.fr_bind_backward.restype = C.c_int
     L.fr_adam_step.argtypes = [C.POINTER(fr_adam_config), _fp, _fp, _fp, _fp, C.c_uint64, _fp, C.c_void_p]
     L.fr_adam_step.restype = C.c_int
     _lib = L

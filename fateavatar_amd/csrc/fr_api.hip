@@ -224,6 +224,38 @@ int fr_knn_nearest_dist2(int32_t P, const float* points, float* out, void* works
     return launch_knn(P, points, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), 1);
 }
 
+static int check_binding(const fr_binding* b)
+{
+    if (!b || b->N < 0 || b->V < 0 || b->F < 0) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_binding: null or negative sizes");
+    if (b->N > 0 && (!b->verts || !b->faces || !b->face_index || !b->bary || !b->offset || !b->rotation || !b->scaling ||
+                     (b->resize_scale && !b->face_scale_canonical)))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_binding: missing array");
+    return FR_OK;
+}
+
+int fr_face_scale(int32_t V, int32_t F, const float* verts, const int32_t* faces, float* out_scale, void* stream)
+{
+    if (V < 0 || F < 0 || (F > 0 && (!verts || !faces || !out_scale))) return fail_msg(FR_ERR_INVALID_ARGUMENT, "bad argument");
+    return launch_face_scale(F, verts, faces, out_scale, static_cast<hipStream_t>(stream));
+}
+
+int fr_bind_forward(const fr_binding* b, float* xyz, float* rotation_out, float* scaling_out, void* stream)
+{
+    int rc = check_binding(b);
+    if (rc) return rc;
+    if (b->N > 0 && (!xyz || !rotation_out || !scaling_out)) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_bind_forward: null output");
+    return launch_bind_forward(*b, xyz, rotation_out, scaling_out, static_cast<hipStream_t>(stream));
+}
+
+int fr_bind_backward(const fr_binding* b, const float* g_xyz, const float* g_rotation, const float* g_scaling,
+                     float* d_verts, float* d_offset, float* d_rotation, float* d_scaling, void* stream)
+{
+    int rc = check_binding(b);
+    if (rc) return rc;
+    return launch_bind_backward(*b, g_xyz, g_rotation, g_scaling, d_verts, d_offset, d_rotation, d_scaling,
+                                static_cast<hipStream_t>(stream));
+}
+
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  uint64_t n, float* state, void* stream)
 {

@@ -247,6 +247,10 @@ size_t knn_workspace_bytes(int P);
 // memset NODE of a captured graph it stopped taking effect once an eager kernel had been launched between two
 // replays (ROCm 7.0 runtime shipped with PyTorch 2.10; reproduced with tools/dbg_graph.py).
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
+int launch_bind_forward(const fr_binding& b, float* xyz, float* rot, float* scale, hipStream_t s);
+int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g_rot, const float* g_scale, float* d_verts,
+                         float* d_offset, float* d_rotation, float* d_scaling, hipStream_t s);
+int launch_face_scale(int F, const float* verts, const int* faces, float* out, hipStream_t s);
 int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                 unsigned long long n, float* state, hipStream_t s);
 int launch_selftest_reduce(const float* in, float* out, hipStream_t s);

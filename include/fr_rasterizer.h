@@ -16,6 +16,7 @@
  *   fr_mark_visible   replaces CudaRasterizer::Rasterizer::markVisible
  *                     (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153),
  *                     called from markVisible (rasterize_points.cu:198-217)
+ *   fr_bind_forward / fr_bind_backward replace the ~40 PyTorch kernels of the mesh binding (model/fateavatar.py:225-258)
  *   fr_adam_step      replaces torch.optim.Adam.step() over the Gaussian groups (train/optim.py:11-37)
  *   fr_knn_mean_dist2 replaces SimpleKNN::knn (simple_knn.h, simple_knn.cu:186-222),
  *                     called from distCUDA2 (spatial.cu:14-25)
@@ -192,6 +193,33 @@ typedef struct fr_adam_config {
 } fr_adam_config;
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  uint64_t n, float* state, void* hip_stream);
+
+/* ---- FateAvatar's mesh binding (reference model/fateavatar.py:225-258 with
+ * volume_rendering/mesh_compute.py:27-59 and pytorch3d's matrix_to_quaternion / quaternion_multiply): from the posed
+ * mesh and each Gaussian's binding (face index, barycentrics) and raw parameters to what the reference assigns to
+ * gaussian._xyz / _rotation / _scaling before render():
+ *   xyz = sum_k bary_k v_k + (e1 x e2) * shell_len * tanh(offset);  rotation = standardize(q_face (x) rotation);
+ *   scaling = scaling + log(face_scale / face_scale_canonical)   (resize_scale != 0; unchanged otherwise).
+ * All pointers are device pointers; one frame per call. */
+typedef struct fr_binding {
+    int32_t N, V, F;
+    const float* verts;                 /* [V,3] posed vertices */
+    const int32_t* faces;               /* [F,3] */
+    const int32_t* face_index;          /* [N]   face every Gaussian is bound to */
+    const float* bary;                  /* [N,3] barycentric coordinates */
+    const float* face_scale_canonical;  /* [F]   fr_face_scale of the canonical mesh */
+    float shell_len;                    /* cfg_model.normal_offset */
+    int32_t resize_scale;
+    const float* offset;                /* [N]   raw: tanh is applied here */
+    const float* rotation;              /* [N,4] raw quaternion (r,x,y,z) */
+    const float* scaling;               /* [N,3] raw log-scale */
+} fr_binding;
+int fr_face_scale(int32_t V, int32_t F, const float* verts, const int32_t* faces, float* out_scale, void* hip_stream);
+int fr_bind_forward(const fr_binding* b, float* xyz, float* rotation_out, float* scaling_out, void* hip_stream);
+/* Gradients of the three outputs in, gradients of offset / rotation / scaling out (fully written), and dL/dverts
+ * ADDED into d_verts [V,3] with float atomics (the caller zeroes it).  Any of the seven arrays may be NULL. */
+int fr_bind_backward(const fr_binding* b, const float* g_xyz, const float* g_rotation, const float* g_scaling,
+                     float* d_verts, float* d_offset, float* d_rotation, float* d_scaling, void* hip_stream);
 
 /* present[i] = view-space z of means3D[i] > 0.2 (auxiliary.h:154). */
 int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

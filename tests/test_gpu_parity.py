@@ -579,3 +579,81 @@ def test_checkpoint_resume_continues_the_same_trajectory(gpu_device, tmp_path):
     assert b.adam.step_count == a.adam.step_count == 11
     assert float((a.pc.flat - b.pc.flat).abs().max()) < 2e-3
     assert torch.equal(a.denom, b.denom)
+
+
+def _binding_case(device, N=20000, seed=0, dtype=None):
+    import torch
+    verts, faces, _ = scenes.head_geometry()
+    g = torch.Generator().manual_seed(seed)
+    V, F = verts.shape[0], faces.shape[0]
+    canon = torch.from_numpy(verts)
+    posed = canon * (1.0 + 0.05 * torch.randn(V, 1, generator=g)) + 0.002 * torch.randn(V, 3, generator=g)
+    fi = torch.randint(0, F, (N,), generator=g, dtype=torch.int32)
+    uvw = torch.rand(N, 3, generator=g)
+    bary = uvw / uvw.sum(-1, keepdim=True)
+    offset = torch.randn(N, 1, generator=g)
+    rot = torch.randn(N, 4, generator=g)
+    scl = torch.randn(N, 3, generator=g) - 6.0
+    t = lambda x: x.to(device) if dtype is None or not x.is_floating_point() else x.to(device, dtype)  # noqa: E731
+    return dict(canon=t(canon), posed=t(posed), faces=t(torch.from_numpy(faces)), fi=t(fi), bary=t(bary), offset=t(offset),
+                rot=t(rot), scl=t(scl))
+
+
+def test_mesh_binding_forward_and_backward_vs_oracle(gpu_device):
+    """fr_bind_forward / fr_bind_backward (one kernel each) == the oracle's restatement of model/fateavatar.py:225-258:
+    forward against the same formulas in fp32, gradients against float64 autograd of them."""
+    import torch
+    from fateavatar_amd.binding import bind_gaussians, face_scale
+    from oracle import binding as B
+    c = _binding_case(gpu_device)
+    shell = 0.01
+    canon_scale = face_scale(c["canon"], c["faces"])
+    ref_scale = B.face_orientation(c["canon"].cpu(), c["faces"].cpu())[1]
+    assert torch.allclose(canon_scale.cpu(), ref_scale, rtol=2e-6, atol=0)
+    leaves = [c[k].clone().requires_grad_(True) for k in ("posed", "offset", "rot", "scl")]
+    xyz, rot, scl = bind_gaussians(leaves[0], c["faces"], c["fi"], c["bary"], canon_scale, leaves[1], leaves[2], leaves[3], shell)
+    # ---- forward vs fp32 oracle
+    o32 = B.bind(c["posed"].cpu(), c["faces"].cpu(), c["fi"].cpu(), c["bary"].cpu(), ref_scale, c["offset"].cpu(),
+                 c["rot"].cpu(), c["scl"].cpu(), shell)
+    for got, want, name in zip((xyz, rot, scl), o32, ("xyz", "rotation", "scaling")):
+        assert torch.allclose(got.detach().cpu(), want, rtol=2e-5, atol=2e-6), (name, float((got.detach().cpu() - want).abs().max()))
+    assert bool((rot[:, 0] >= 0).all())
+    # ---- backward vs float64 autograd of the oracle
+    g = torch.Generator().manual_seed(9)
+    w = [torch.randn(x.shape, generator=g) for x in (xyz, rot, scl)]
+    torch.autograd.backward([xyz, rot, scl], [x.to(gpu_device) for x in w])
+    d = lambda k: c[k].cpu().double()  # noqa: E731
+    l64 = [d("posed").requires_grad_(True), d("offset").requires_grad_(True), d("rot").requires_grad_(True),
+           d("scl").requires_grad_(True)]
+    o64 = B.bind(l64[0], c["faces"].cpu(), c["fi"].cpu(), d("bary"), ref_scale.double(), l64[1], l64[2], l64[3], shell)
+    torch.autograd.backward(list(o64), [x.double() for x in w])
+    for got, want, name in zip(leaves, l64, ("d_verts", "d_offset", "d_rotation", "d_scaling")):
+        ref = want.grad.float()
+        err = float((got.grad.cpu() - ref).norm() / ref.norm())
+        assert err < 2e-5, (name, err)
+        assert got.grad.shape == got.shape
+
+
+def test_mesh_binding_options_and_degenerate_face(gpu_device):
+    """resize_scale off leaves the scaling untouched; a zero-area face goes through the eps clamps without NaN/inf;
+    only the requested gradients are produced."""
+    import torch
+    from fateavatar_amd.binding import bind_gaussians, face_scale
+    from oracle import binding as B
+    c = _binding_case(gpu_device, N=3000, seed=3)
+    f0 = c["faces"][7].long()
+    c["posed"][f0[2]] = c["posed"][f0[1]]              # degenerate face 7
+    c["fi"][:50] = 7
+    canon_scale = face_scale(c["canon"], c["faces"])
+    off = c["offset"].clone().requires_grad_(True)
+    xyz, rot, scl = bind_gaussians(c["posed"], c["faces"], c["fi"], c["bary"], None, off, c["rot"], c["scl"], 0.02,
+                                   resize_scale=False)
+    assert torch.equal(scl, c["scl"]) and torch.isfinite(xyz).all() and torch.isfinite(rot).all()
+    xyz.sum().backward()
+    assert off.grad is not None and torch.isfinite(off.grad).all()
+    o = B.bind(c["posed"].cpu(), c["faces"].cpu(), c["fi"].cpu(), c["bary"].cpu(), canon_scale.cpu(), c["offset"].cpu(),
+               c["rot"].cpu(), c["scl"].cpu(), 0.02, resize_scale=False)
+    assert torch.allclose(xyz.detach().cpu(), o[0], rtol=2e-5, atol=2e-6)
+    ok = torch.ones(3000, dtype=torch.bool)
+    ok[:50] = False                                     # the quaternion of a degenerate frame is not well defined
+    assert torch.allclose(rot.detach().cpu()[ok], o[1][ok], rtol=2e-5, atol=2e-6)

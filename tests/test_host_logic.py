@@ -128,3 +128,13 @@ def test_flat_gaussians_resize_row_map():
         p = getattr(pc, n)
         assert isinstance(p, torch.nn.Parameter) and p.data_ptr() >= pc.flat.data_ptr()
         assert torch.equal(p[:7], old[n][keep]) and torch.equal(p[7:], old[n][[2, 5]])
+
+
+def test_mesh_binding_refuses_cpu_tensors():
+    import pytest
+    import torch
+    from fateavatar_amd.binding import bind_gaussians
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bind_gaussians(z(4, 3), z(2, 3, dtype=torch.int32), z(5, dtype=torch.int32), z(5, 3), z(2, 1), z(5, 1), z(5, 4),
+                       z(5, 3), 0.01)
