@@ -13,4 +13,6 @@ $R/tools/pmc.sh ${tag}_fetch "FETCH_SIZE" python $R/tools/probe.py --iters 10 > 
 $R/tools/pmc.sh ${tag}_write "WRITE_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
+python $R/tools/probe_coherent.py > $O/${tag}_coherent_order.txt 2>/dev/null
+python $R/tools/probe_binding.py > $O/${tag}_binding.txt 2>/dev/null
 ls $O | grep $tag
