@@ -348,41 +348,70 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         constexpr int kCountUnroll = 4;
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
         if (threadIdx.x == 0) a.g.block_xcc[blockIdx.x] = xcc;
-        for (uint32_t k0 = (uint32_t)lane; k0 < total; k0 += 64 * kCountUnroll) {
-            uint32_t pos[kCountUnroll];
+        // Wave-level aggregation: lanes of one pass that count into the SAME counter (Gaussians stored in a spatially
+        // coherent order, e.g. the reference's UV-raster initialisation, hit a handful of tiles per wave) are grouped
+        // through a 64-slot table in LDS keyed by the counter index: the group's first lane issues ONE global atomic
+        // for the whole group.  Lanes whose slot is taken by another counter fall back to their own atomic, so with
+        // random orders (all counters distinct) nothing is lost but a few LDS operations.
+        __shared__ volatile uint32_t s_gkey[4][kCountUnroll][64], s_gbase[4][kCountUnroll][64];  // volatile: lanes talk through them
+        __shared__ uint32_t s_gcnt[4][kCountUnroll][64];
+        for (uint32_t b0 = 0; b0 < total; b0 += 64 * kCountUnroll) {   // wave-uniform trip count
+            uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll];
             size_t where[kCountUnroll];
-            bool remember[kCountUnroll];
+            bool valid[kCountUnroll], grouped[kCountUnroll], remember[kCountUnroll];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
-                const uint32_t k = k0 + 64u * (uint32_t)u;
-                remember[u] = false;
-                pos[u] = 0, where[u] = 0;
-                if (k >= total) continue;
-                int lo = 0, hi = 63;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
+                valid[u] = false, remember[u] = false, grouped[u] = false;
+                rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, where[u] = 0;
+                s_gcnt[wave][u][lane] = 0u;
+                if (k < total) {
+                    int lo = 0, hi = 63;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                    }
+                    const uint2 rr = s_rect[wave][lo];
+                    const uint32_t j = k - s_excl[wave][lo];
+                    const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
+                    const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
+                    // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
+                    // reaches both ends of its bounding box); only wider ones can miss a corner tile
+                    const uint32_t rh = (rr.y >> 16) - y0;
+                    if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) {
+                        valid[u] = true;
+                        remember[u] = j < (uint32_t)kInlineSlots;
+                        // counter index in the concatenation [tile_count | tile_over] (tile_over = tile_count + 8 * tpad)
+                        key[u] = (remember[u] ? 0u : (uint32_t)kXcds * a.tpad) + xcc * a.tpad + ty * (uint32_t)a.tiles_x + tx;
+                        where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
+                        slot[u] = (key[u] * 2654435761u) >> 26;
+                        s_gkey[wave][u][slot[u]] = key[u];   // several lanes may write: one of them wins the slot
+                    }
                 }
-                const uint2 rr = s_rect[wave][lo];
-                const uint32_t j = k - s_excl[wave][lo];
-                const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
-                const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
-                // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
-                // reaches both ends of its bounding box); only wider ones can miss a corner tile
-                const uint32_t rh = (rr.y >> 16) - y0;
-                if (rw > 1 && rh > 1 && !footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;
-                const size_t t = (size_t)xcc * a.tpad + (size_t)(ty * (uint32_t)a.tiles_x + tx);
-                if (j < (uint32_t)kInlineSlots) {
-                    pos[u] = atomicAdd(&a.tile_count[t], 1u);
-                    where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
-                    remember[u] = true;
-                } else {
-                    atomicAdd(&a.tile_over[t], 1u);
+            }
+#pragma unroll
+            for (int u = 0; u < kCountUnroll; u++) {
+                grouped[u] = valid[u] && s_gkey[wave][u][slot[u]] == key[u];
+                if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[wave][u][slot[u]], 1u);
+            }
+            uint32_t got[kCountUnroll];
+#pragma unroll
+            for (int u = 0; u < kCountUnroll; u++) {
+                got[u] = 0;
+                if (valid[u] && (!grouped[u] || rank[u] == 0)) {
+                    const uint32_t n_add = grouped[u] ? s_gcnt[wave][u][slot[u]] : 1u;
+                    got[u] = atomicAdd(&a.tile_count[key[u]], n_add);   // (indexes tile_over too, see `key`)
                 }
             }
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++)
-                if (remember[u]) a.g.inline_slots[where[u]] = pos[u];
+                if (grouped[u] && rank[u] == 0) s_gbase[wave][u][slot[u]] = got[u];
+#pragma unroll
+            for (int u = 0; u < kCountUnroll; u++) {
+                if (!remember[u]) continue;
+                const uint32_t base = grouped[u] ? s_gbase[wave][u][slot[u]] : got[u];
+                a.g.inline_slots[where[u]] = base + rank[u];
+            }
         }
     }
     // num_rendered in reference semantics: per-workgroup partial sums, added up by the scan kernel (a single
