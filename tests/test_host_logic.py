@@ -138,3 +138,29 @@ def test_mesh_binding_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU path"):
         bind_gaussians(z(4, 3), z(2, 3, dtype=torch.int32), z(5, dtype=torch.int32), z(5, 3), z(2, 1), z(5, 1), z(5, 4),
                        z(5, 3), 0.01)
+
+
+def test_reference_render_runs_against_the_alias_packages_up_to_the_device_boundary():
+    """The reference's OWN volume_rendering/render_3dgs.py (imported from the read-only checkout, present only in the
+    build container) must import against the alias package and drive it with its keyword arguments; on CPU tensors the
+    call has to get as far as the C-ABI boundary and stop there with the no-CPU-path error (nothing earlier may fail)."""
+    import importlib
+    import os
+    import sys
+    import pytest
+    import torch
+    if not os.path.exists("/root/reference/volume_rendering/render_3dgs.py"):
+        pytest.skip("the reference checkout is only present in the build container")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    try:
+        ref = importlib.import_module("volume_rendering.render_3dgs")
+    finally:
+        sys.path.remove("/root/reference")
+    from fateavatar_amd import scenes
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    s = scenes.random_scene(50, 32, 32, sh_degree=1, seed=0)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 1, torch.device("cpu"))
+    cam = TorchCamera(s.camera, torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="HIP device|no CPU"):
+        ref.render(cam, pc, torch.from_numpy(s.bg), device="cpu")
