@@ -13,13 +13,13 @@ constexpr int kWave = 64;
 constexpr int kTile = 8;    // 8x8 pixels = one wavefront
 constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): radii / num_rendered semantics
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
-constexpr int kXcds = 8;            // binning counters are privatised per XCD (indexed by HW_REG_XCC_ID & 7)
-constexpr int kSubWords = 16;       // per-tile sub-segment table: 8 starts of the per-XCD sub-segments + 8 starts of their overflow parts
-                                   // (device-scope atomics serialise per cache line, ~11 ns apiece)
-constexpr int kInlineSlots = 8;    // instances per Gaussian whose segment position is remembered from the counting pass
-constexpr int kSortRegMax = 4096;   // longest list sorted in registers (4 waves x 16 keys per lane); longer ones: global-memory fallback
-constexpr int kSortGroupMax = 1024; // longest list the main sort kernel handles (4 waves x 4 keys per lane)
-constexpr int kSortWaveMax = 256;  // longest list one wave sorts alone // longest tile list the in-register wave sort handles
+constexpr int kXcds = 8;          // binning counters are privatised per XCD (indexed by HW_REG_XCC_ID & 7)
+constexpr int kSubWords = 16;     // per-tile sub-segment table: starts of the 8 per-XCD sub-segments + of their overflow parts
+constexpr int kInlineSlots = 8;   // instances per Gaussian whose segment position is remembered from the counting pass
+constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
+constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)
+constexpr int kSortRegMax = 4096;    // longest list k_tile_sort_big sorts in registers (4 waves x 16 keys per lane);
+                                     // longer ones take its global-memory fallback
 
 // accumulator slots (blend backward -> preprocess backward).  With q = dL/dG * G of a (pixel, Gaussian) pair
 // and d = splat centre - pixel, the slots hold the sums over pixels of:
@@ -96,7 +96,7 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t max_tile_list;
     uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
-    uint32_t reserved0;
+    uint32_t reserved0;      // (unused)
     uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
     uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
     uint32_t pad2[6];
