@@ -11,6 +11,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .rasterizer import GradOut
+
 
 class FlatGaussians(torch.nn.Module):
     FIELDS = (("_xyz", 3), ("_features", None), ("_opacity", 1), ("_scaling", 3), ("_rotation", 4))
@@ -79,7 +81,7 @@ class FlatGaussians(torch.nn.Module):
             if name in ("_xyz", "_features") or self.fused_activations:
                 # these reach the rasterizer untouched: it writes their gradient straight into the flat
                 # buffer (rasterizer.py `_fr_grad_out`), no accumulation kernel, no zero-fill
-                p._fr_grad_out = gv
+                p._fr_grad_out = GradOut(gv)
             setattr(self, name, p)
             off += n
 

@@ -236,6 +236,34 @@ def cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
 
 
+class GradOut:
+    """A gradient slot a parameter tensor can carry as `tensor._fr_grad_out`: the rasterizer's backward writes the
+    parameter's gradient straight into `buf` instead of allocating a tensor that autograd then copies or adds.
+    That is only valid for ONE backward per accumulation: the kernel overwrites.  The slot is therefore claimed by the
+    first backward after the parameter's .grad was cleared and refused to every later one until it is cleared again
+    (forward() re-arms it when it sees `.grad is None`), so multi-frame batches — several renders from the same
+    parameters, one summed loss, as model/fateavatar.py:251-276 does — accumulate correctly."""
+
+    def __init__(self, buf: torch.Tensor):
+        self.buf = buf
+        self.claimed = False
+
+    @staticmethod
+    def of(t):
+        slot = getattr(t, "_fr_grad_out", None)
+        if slot is None:
+            return None
+        if t.is_leaf and t.grad is None:
+            slot.claimed = False   # gradients were cleared (zero_grad(set_to_none=True)): a new accumulation starts
+        return slot
+
+    def claim(self):
+        if self.claimed:
+            return None
+        self.claimed = True
+        return self.buf
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """diff_gaussian_rasterization/__init__.py:44-155."""
 
@@ -271,14 +299,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.stats = getattr(means2D, "_fr_densification_stats", None)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
-        # optional extension: an input tensor may carry `_fr_grad_out`, a preallocated buffer that receives its
-        # gradient (zero-copy into e.g. a flat data-parallel gradient buffer)
-        ctx.grad_out = {"dL_dmeans3D": getattr(means3D, "_fr_grad_out", None),
-                        "dL_dsh": getattr(sh, "_fr_grad_out", None) if sh.numel() else None}
+        # optional extension: an input tensor may carry `_fr_grad_out`, a GradOut slot whose preallocated buffer
+        # receives its gradient (zero-copy into e.g. a flat data-parallel gradient buffer)
+        ctx.grad_slots = {"dL_dmeans3D": GradOut.of(means3D), "dL_dsh": GradOut.of(sh) if sh.numel() else None}
         if ctx.raw:  # raw parameters reach the kernels directly: their gradients can be written in place too
-            ctx.grad_out.update(dL_dopacity=getattr(opacities, "_fr_grad_out", None),
-                                dL_dscales=getattr(scales, "_fr_grad_out", None),
-                                dL_drotations=getattr(rotations, "_fr_grad_out", None))
+            ctx.grad_slots.update(dL_dopacity=GradOut.of(opacities), dL_dscales=GradOut.of(scales),
+                                  dL_drotations=GradOut.of(rotations))
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -313,7 +339,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads = rasterize_gaussians_backward(*args, _out=ctx.grad_out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
+            # the FIRST backward of a step may write a gradient straight into its slot's buffer; any further backward
+            # of the same step (several frames rendered from the same parameters) gets a fresh tensor, which autograd
+            # then adds to the first
+            out = {k: slot.claim() for k, slot in ctx.grad_slots.items() if slot is not None}
+            grads = rasterize_gaussians_backward(*args, _out=out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

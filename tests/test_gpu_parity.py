@@ -657,3 +657,49 @@ def test_mesh_binding_options_and_degenerate_face(gpu_device):
     ok = torch.ones(3000, dtype=torch.bool)
     ok[:50] = False                                     # the quaternion of a degenerate frame is not well defined
     assert torch.allclose(rot.detach().cpu()[ok], o[1][ok], rtol=2e-5, atol=2e-6)
+
+
+def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
+    """model/fateavatar.py:251-276 renders every frame of the batch first and back-propagates one summed loss
+    afterwards: two forwards in flight, then both backwards.  Gradients must equal the sum of the per-frame ones."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    P, res = 5000, 112
+    sa = scenes.head_scene(P=P, res=res, sh_degree=2, seed=8, view=0, n_views=3, opacity=0.4)
+    sb = scenes.head_scene(P=P, res=res, sh_degree=2, seed=8, view=1, n_views=3, opacity=0.4)
+    bg = torch.from_numpy(sa.bg).to(gpu_device)
+    cams = [TorchCamera(sa.camera, gpu_device), TorchCamera(sb.camera, gpu_device)]
+    rng = np.random.default_rng(3)
+    ws = [torch.from_numpy((rng.uniform(-1, 1, (3, res, res)) / res ** 2).astype(np.float32)).to(gpu_device) for _ in range(2)]
+
+    def grads(order):
+        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device)
+        if order == "batched":
+            outs = [render(c, pc, bg) for c in cams]                      # both forwards first
+            (sum((o["render"] * w).sum() for o, w in zip(outs, ws))).backward()
+            vs = [o["viewspace_points"].grad.clone() for o in outs]
+        else:
+            vs = []
+            for c, w in zip(cams, ws):                                    # one frame at a time, gradients accumulate
+                o = render(c, pc, bg)
+                (o["render"] * w).sum().backward()
+                vs.append(o["viewspace_points"].grad.clone())
+        return {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}, vs
+
+    ga, va = grads("batched")
+    gb, vb = grads("sequential")
+    # the truth: each frame alone, from its own copy of the parameters, added up
+    want = None
+    for c, w in zip(cams, ws):
+        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device)
+        (render(c, pc, bg)["render"] * w).sum().backward()
+        g1 = {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}
+        want = g1 if want is None else {n: want[n] + g1[n] for n in want}
+    for n in ga:
+        assert util.rel_l2(ga[n].cpu().numpy(), want[n].cpu().numpy()) < 1e-5, ("batched", n)
+        assert util.rel_l2(gb[n].cpu().numpy(), want[n].cpu().numpy()) < 1e-5, ("sequential", n)
+    assert float(ga["_xyz"].abs().max()) > 0 and float(ga["_features"].abs().max()) > 0
+    for x, y in zip(va, vb):
+        assert util.rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-5
+    assert not torch.equal(va[0], va[1])
