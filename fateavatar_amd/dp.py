@@ -44,13 +44,33 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+_avg_supported = None
+
+
+def _collective_avg_ok(like: torch.Tensor) -> bool:
+    """Does this backend average inside the collective?  RCCL does (ncclAvg); gloo does not.  Probed once with a
+    one-element all-reduce so that an older RCCL without AVG degrades to SUM + divide instead of failing the step."""
+    global _avg_supported
+    if _avg_supported is None:
+        ok = False
+        if dist.get_backend() == "nccl":
+            try:
+                probe = torch.ones(1, dtype=like.dtype, device=like.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                ok = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:
+                ok = False
+        _avg_supported = ok
+    return _avg_supported
+
+
 def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
     """In-place batch-mean of a flat gradient buffer across ranks (one collective)."""
     w = world_size()
     if w > 1:
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective: no extra pass
-        else:  # gloo (CPU tests) has no AVG
+        if _collective_avg_ok(flat_grad):
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG)  # averaged inside the collective: no extra pass
+        else:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
             flat_grad.div_(w)
     return flat_grad
