@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
 // Lists longer than kSortGroupMax (dense / zoomed-in scenes): 4 waves x 16 keys per lane up to 4096, the
 // global-memory network beyond.  A separate kernel so that its register budget (16 keys per lane) does not
 // lower the occupancy of the common path.
-constexpr uint32_t kBigSorters = 128;
+constexpr uint32_t kBigSorters = 512;
 
 __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, float4* recs, GeomView g)
 {
