@@ -136,6 +136,9 @@ __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, 
     return qmin <= t2;
 }
 
+constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
+constexpr int kCountLdsBytes = 2304 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
+
 __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
@@ -155,8 +158,13 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         in_rot[0] = a.rotations[4 * li], in_rot[1] = a.rotations[4 * li + 1], in_rot[2] = a.rotations[4 * li + 2],
         in_rot[3] = a.rotations[4 * li + 3];
     const float in_opacity = a.opacities[li];
-    if (a.shs && !a.colors_precomp) {
-        float* w_sh = s_sh + (size_t)wave * 64 * sh_stride;
+    // one LDS region per wave: first the wave's staged SH rows, later (the rows are dead by then) the tables of its
+    // counting pass — nothing in it is shared between waves, so the kernel needs no workgroup barrier for it
+    const bool sh_staged = a.shs && !a.colors_precomp;
+    const int wave_floats = max(sh_staged ? 64 * sh_stride : 0, kCountLdsBytes / 4);   // launch_forward sizes it the same way
+    float* const wave_lds = s_sh + (size_t)wave * wave_floats;
+    if (sh_staged) {
+        float* w_sh = wave_lds;
         const int wave_first = blockIdx.x * 256 + wave * 64;
         if (wave_first < a.P)
             stage_wave_rows(w_sh, sh_stride, a.shs + (size_t)wave_first * M3, min(64, a.P - wave_first), M3, lane);
@@ -325,12 +333,18 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     // that the emit pass needs no second atomic.  The wave spreads its instances over its lanes: one returning
     // atomic round trip per 64 instances instead of one per tile of the widest rectangle.
     {
-        __shared__ uint32_t s_excl[4][64];
-        __shared__ uint2 s_rect[4][64];
-        __shared__ float4 s_cull[4][64];
-        __shared__ float2 s_ctr[4][64];
-        s_cull[wave][lane] = cull;
-        s_ctr[wave][lane] = ctr;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the SH rows have been read: reuse their space
+        __builtin_amdgcn_wave_barrier();
+        char* cl = reinterpret_cast<char*>(wave_lds);
+        float4* s_cull = reinterpret_cast<float4*>(cl);                                  // [64]   1024 B
+        uint2* s_rect = reinterpret_cast<uint2*>(cl + 1024);                              // [64]    512 B
+        float2* s_ctr = reinterpret_cast<float2*>(cl + 1536);                             // [64]    512 B
+        uint32_t* s_excl = reinterpret_cast<uint32_t*>(cl + 2048);                        // [64]    256 B
+        volatile uint32_t* s_gkey = reinterpret_cast<volatile uint32_t*>(cl + 2304);      // [4][64] 1024 B (lanes talk through it)
+        volatile uint32_t* s_gbase = reinterpret_cast<volatile uint32_t*>(cl + 3328);     // [4][64] 1024 B
+        uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 4352);                        // [4][64] 1024 B  -> kCountLdsBytes
+        s_cull[lane] = cull;
+        s_ctr[lane] = ctr;
         const int w = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), h = (int)(rect.y >> 16) - (int)(rect.x >> 16);
         const uint32_t n = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
         uint32_t incl = n;
@@ -339,13 +353,13 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             if (lane >= off) incl += t;
         }
         const uint32_t total = __shfl(incl, 63);
-        s_excl[wave][lane] = incl - n;
-        s_rect[wave][lane] = rect;
-        __syncthreads();
+        s_excl[lane] = incl - n;
+        s_rect[lane] = rect;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int wave_first = blockIdx.x * 256 + wave * 64;
         // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
         // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several)
-        constexpr int kCountUnroll = 4;
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
         if (threadIdx.x == 0) a.g.block_xcc[blockIdx.x] = xcc;
         // Wave-level aggregation: lanes of one pass that count into the SAME counter (Gaussians stored in a spatially
@@ -353,8 +367,6 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         // through a 64-slot table in LDS keyed by the counter index: the group's first lane issues ONE global atomic
         // for the whole group.  Lanes whose slot is taken by another counter fall back to their own atomic, so with
         // random orders (all counters distinct) nothing is lost but a few LDS operations.
-        __shared__ volatile uint32_t s_gkey[4][kCountUnroll][64], s_gbase[4][kCountUnroll][64];  // volatile: lanes talk through them
-        __shared__ uint32_t s_gcnt[4][kCountUnroll][64];
         for (uint32_t b0 = 0; b0 < total; b0 += 64 * kCountUnroll) {   // wave-uniform trip count
             uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll];
             size_t where[kCountUnroll];
@@ -364,52 +376,52 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
                 valid[u] = false, remember[u] = false, grouped[u] = false;
                 rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, where[u] = 0;
-                s_gcnt[wave][u][lane] = 0u;
+                s_gcnt[u * 64 + lane] = 0u;
                 if (k < total) {
                     int lo = 0, hi = 63;
                     while (lo < hi) {
                         const int mid = (lo + hi + 1) >> 1;
-                        if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
+                        if (s_excl[mid] <= k) lo = mid; else hi = mid - 1;
                     }
-                    const uint2 rr = s_rect[wave][lo];
-                    const uint32_t j = k - s_excl[wave][lo];
+                    const uint2 rr = s_rect[lo];
+                    const uint32_t j = k - s_excl[lo];
                     const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
                     const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
                     // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
                     // reaches both ends of its bounding box); only wider ones can miss a corner tile
                     const uint32_t rh = (rr.y >> 16) - y0;
-                    if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) {
+                    if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[lo], s_ctr[lo], tx, ty)) {
                         valid[u] = true;
                         remember[u] = j < (uint32_t)kInlineSlots;
                         // counter index in the concatenation [tile_count | tile_over] (tile_over = tile_count + 8 * tpad)
                         key[u] = (remember[u] ? 0u : (uint32_t)kXcds * a.tpad) + xcc * a.tpad + ty * (uint32_t)a.tiles_x + tx;
                         where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
                         slot[u] = (key[u] * 2654435761u) >> 26;
-                        s_gkey[wave][u][slot[u]] = key[u];   // several lanes may write: one of them wins the slot
+                        s_gkey[u * 64 + slot[u]] = key[u];   // several lanes may write: one of them wins the slot
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
-                grouped[u] = valid[u] && s_gkey[wave][u][slot[u]] == key[u];
-                if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[wave][u][slot[u]], 1u);
+                grouped[u] = valid[u] && s_gkey[u * 64 + slot[u]] == key[u];
+                if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[u * 64 + slot[u]], 1u);
             }
             uint32_t got[kCountUnroll];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
                 got[u] = 0;
                 if (valid[u] && (!grouped[u] || rank[u] == 0)) {
-                    const uint32_t n_add = grouped[u] ? s_gcnt[wave][u][slot[u]] : 1u;
+                    const uint32_t n_add = grouped[u] ? s_gcnt[u * 64 + slot[u]] : 1u;
                     got[u] = atomicAdd(&a.tile_count[key[u]], n_add);   // (indexes tile_over too, see `key`)
                 }
             }
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++)
-                if (grouped[u] && rank[u] == 0) s_gbase[wave][u][slot[u]] = got[u];
+                if (grouped[u] && rank[u] == 0) s_gbase[u * 64 + slot[u]] = got[u];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
                 if (!remember[u]) continue;
-                const uint32_t base = grouped[u] ? s_gbase[wave][u][slot[u]] : got[u];
+                const uint32_t base = grouped[u] ? s_gbase[u * 64 + slot[u]] : got[u];
                 a.g.inline_slots[where[u]] = base + rank[u];
             }
         }
@@ -705,7 +717,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     if (P > 0) {
         {
             StageScope sc(h, ST_PREPROCESS_FWD, s);
-            const size_t lds = (in.shs && !in.colors_precomp) ? (size_t)4 * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+            const size_t sh_bytes = (in.shs && !in.colors_precomp) ? (size_t)64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+            const size_t lds = 4 * (sh_bytes > (size_t)kCountLdsBytes ? sh_bytes : (size_t)kCountLdsBytes);
             hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), lds, s, a);
         }
         FR_HIP(hipGetLastError());
