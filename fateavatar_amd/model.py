@@ -159,15 +159,17 @@ class TorchCamera:
     def __init__(self, cam, device):
         self.image_height, self.image_width = cam.image_height, cam.image_width
         self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
-        self.world_view_transform = torch.from_numpy(cam.world_view_transform).to(device)
-        self.full_proj_transform = torch.from_numpy(cam.full_proj_transform).to(device)
-        self.camera_center = torch.from_numpy(cam.camera_center).to(device)
+        # the three tensors are views into ONE 35-float buffer, so that copy_from is a single device copy
+        self._packed = torch.from_numpy(np.concatenate([
+            np.asarray(cam.world_view_transform, np.float32).reshape(-1), np.asarray(cam.full_proj_transform, np.float32).reshape(-1),
+            np.asarray(cam.camera_center, np.float32).reshape(-1)])).to(device)
+        self.world_view_transform = self._packed[0:16].view(4, 4)
+        self.full_proj_transform = self._packed[16:32].view(4, 4)
+        self.camera_center = self._packed[32:35]
 
     def copy_from(self, other: "TorchCamera") -> None:
         """Overwrite the matrices in place (same intrinsics): lets a captured HIP graph render a new view."""
         if (other.image_height, other.image_width, other.FoVx, other.FoVy) != \
                 (self.image_height, self.image_width, self.FoVx, self.FoVy):
             raise ValueError("copy_from needs a camera with the same image size and field of view")
-        self.world_view_transform.copy_(other.world_view_transform, non_blocking=True)
-        self.full_proj_transform.copy_(other.full_proj_transform, non_blocking=True)
-        self.camera_center.copy_(other.camera_center, non_blocking=True)
+        self._packed.copy_(other._packed, non_blocking=True)
