@@ -20,7 +20,11 @@ int main()
     const unsigned n = 2u << 20, T = 16384;
     std::vector<unsigned> h(n);
     srand(1);
+#ifdef CLUSTERED
+    for (unsigned i = 0; i < n; i += 64) { const unsigned b = (rand() % (T / 64)) * 64; for (unsigned l = 0; l < 64; l++) h[i + l] = b + l; }
+#else
     for (auto& x : h) x = rand() % T;
+#endif
     unsigned *idx, *ctr, *out;
     hipMalloc(&idx, n * 4); hipMalloc(&ctr, (size_t)8 * T * 16 * 4); hipMalloc(&out, 2048 * 256 * 4);
     hipMemcpy(idx, h.data(), n * 4, hipMemcpyHostToDevice);
