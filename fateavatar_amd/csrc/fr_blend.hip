@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             if (overflow) {
                 // the emit pass did not run, so its count-down of the overflow counters did not happen: zero them here
                 // (the scan already zeroed tile_count) so that the next frame finds clean counters
-                if (lane < kXcds) v.tile_over[(size_t)lane * v.tpad + tile] = 0u;
+                if (lane < kXcds)
+                    v.tile_over[(size_t)lane * v.tpad + v.counter_index(tile % (uint32_t)v.tiles_x, tile / (uint32_t)v.tiles_x)] = 0u;
                 return;
             }
             const uint32_t start = v.tile_offset[tile];

@@ -112,11 +112,11 @@ struct ImageView {
     // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
     // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
     // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
-    uint32_t* tile_count;    // [kXcds][Tpad] instances with a remembered position, counted by XCD x
-    uint32_t* tile_over;     // [kXcds][Tpad] instances beyond kInlineSlots of their Gaussian, counted by XCD x
+    uint32_t* tile_count;    // [kXcds][tpad] instances with a remembered position, counted by XCD x (block-major, counter_index)
+    uint32_t* tile_over;     // [kXcds][tpad] instances beyond kInlineSlots of their Gaussian, counted by XCD x
     uint32_t* tile_sub;      // [T][kSubWords] starts (relative to tile_offset) of sub-segment x [0..7] and of its overflow part [8..15]
     uint32_t tpad;           // row pitch of the two counter arrays
-    uint32_t* tile_total;    // [Tpad] instances per tile (sum over the XCD copies), written by k_tile_totals for the scan
+    uint32_t* tile_total;    // [T rounded up to 16] instances per tile (sum over the XCD copies), written by k_tile_totals for the scan
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
     uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
@@ -125,6 +125,12 @@ struct ImageView {
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
     int tiles_x, tiles_y;
+    // position of tile (tx, ty)'s counter inside one XCD copy: block-major, 4x4 tiles per 64-byte line
+    __host__ __device__ uint32_t counter_index(uint32_t tx, uint32_t ty) const
+    {
+        const uint32_t bx = (uint32_t)(tiles_x + 3) / 4;
+        return ((ty >> 2) * bx + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
+    }
     static ImageView make(void* buf, int W, int H)
     {
         char* p = static_cast<char*>(buf);
@@ -134,9 +140,12 @@ struct ImageView {
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
         v.tile_count = v.tile_over = nullptr;
-        v.tpad = (uint32_t)((T + 15) & ~(size_t)15);
+        // counters are stored in 4x4-tile blocks (one 64-byte line per block): lanes of one atomic instruction that
+        // fall into the same line are merged into ONE request (27 requests/ns vs 250 lane-atomics/ns,
+        // tools/micro_atomics.hip), and the tiles of one Gaussian's rectangle are 2-D neighbours
+        v.tpad = (uint32_t)(((size_t)((v.tiles_x + 3) / 4) * ((v.tiles_y + 3) / 4)) * 16);
         v.tile_sub = carve<uint32_t>(p, T * kSubWords);
-        v.tile_total = carve<uint32_t>(p, v.tpad);
+        v.tile_total = carve<uint32_t>(p, (T + 15) & ~(size_t)15);
         v.tile_offset = carve<uint32_t>(p, T + 1);
         v.large_list = carve<uint32_t>(p, T);
         v.medium_list = carve<uint32_t>(p, T);

@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                         valid[u] = true;
                         remember[u] = j < (uint32_t)kInlineSlots;
                         // counter index in the concatenation [tile_count | tile_over] (tile_over = tile_count + 8 * tpad)
-                        key[u] = (remember[u] ? 0u : (uint32_t)kXcds * a.tpad) + xcc * a.tpad + ty * (uint32_t)a.tiles_x + tx;
+                        const uint32_t bx4 = (uint32_t)(a.tiles_x + 3) / 4;   // ImageView::counter_index
+                        key[u] = (remember[u] ? 0u : (uint32_t)kXcds * a.tpad) + xcc * a.tpad +
+                                 ((ty >> 2) * bx4 + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
                         where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
                         slot[u] = (key[u] * 2654435761u) >> 26;
                         s_gkey[u * 64 + slot[u]] = key[u];   // several lanes may write: one of them wins the slot
@@ -445,8 +447,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 // touches one dense 4-byte-per-tile array.
 __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
 {
+    // every thread: four consecutive counters = one row of a 4x4-tile block
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (i >= T) return;
+    if (i >= v.tpad) return;
     uint32_t sub[4][kSubWords];
     uint32_t acc[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -463,15 +466,20 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
             acc[q] += a1[q] + a2[q];
         }
     }
+    const uint32_t bx = (uint32_t)(v.tiles_x + 3) / 4, blk = i >> 4, row = (i >> 2) & 3u;
+    const uint32_t ty = (blk / bx) * 4 + row, tx0 = (blk % bx) * 4;
+    if (ty >= (uint32_t)v.tiles_y) return;   // padding rows of the block grid: never counted into, already zero
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        if (i + q >= T) break;
-        uint4* dst = reinterpret_cast<uint4*>(v.tile_sub + (size_t)(i + q) * kSubWords);
+        if (tx0 + q >= (uint32_t)v.tiles_x) break;
+        const uint32_t tile = ty * (uint32_t)v.tiles_x + tx0 + q;
+        uint4* dst = reinterpret_cast<uint4*>(v.tile_sub + (size_t)tile * kSubWords);
 #pragma unroll
         for (int w4 = 0; w4 < kSubWords / 4; w4++)
             dst[w4] = make_uint4(sub[q][4 * w4], sub[q][4 * w4 + 1], sub[q][4 * w4 + 2], sub[q][4 * w4 + 3]);
+        v.tile_total[tile] = acc[q];
     }
-    *reinterpret_cast<uint4*>(v.tile_total + i) = make_uint4(acc[0], acc[1], acc[2], acc[3]);  // (tiles >= T: zero)
+    (void)T;
 }
 
 // Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts, the lists of tiles the
@@ -638,7 +646,7 @@ __global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, Image
                     g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
         else  // un-remembered instances go behind the remembered ones; the overflow counter counts back down to 0
             slot += v.tile_sub[(size_t)tile * kSubWords + kXcds + xcc] +
-                    (atomicSub(&v.tile_over[(size_t)xcc * v.tpad + tile], 1u) - 1u);
+                    (atomicSub(&v.tile_over[(size_t)xcc * v.tpad + v.counter_index(tx, ty)], 1u) - 1u);
         keys[slot] = s_key[wave][lo];
     }
 }
@@ -687,15 +695,15 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
-    if (T > h->tile_counter_tiles) {
+    if (v.tpad > h->tile_counter_tiles) {   // (tile_counter_tiles holds the largest pitch allocated so far)
         if (h->tile_counters) FR_HIP(hipFree(h->tile_counters));
         h->tile_counters = nullptr, h->tile_counter_tiles = 0;
         FR_HIP(hipMalloc(&h->tile_counters, (size_t)2 * kXcds * v.tpad * sizeof(uint32_t)));
-        h->tile_counter_tiles = T;
+        h->tile_counter_tiles = v.tpad;
         h->counters_clean = false;
     }
     if (!h->counters_clean)
-        if ((rc = launch_zero(h->tile_counters, (size_t)2 * kXcds * ((h->tile_counter_tiles + 15) & ~(size_t)15) * sizeof(uint32_t), s)))
+        if ((rc = launch_zero(h->tile_counters, (size_t)2 * kXcds * h->tile_counter_tiles * sizeof(uint32_t), s)))
             return rc;
     h->counters_clean = false;  // until every stage of this frame has been enqueued
     v.tile_count = h->tile_counters, v.tile_over = h->tile_counters + (size_t)kXcds * v.tpad;
@@ -726,7 +734,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     {
         StageScope sc(h, ST_SCAN, s);
-        hipLaunchKernelGGL(k_tile_totals, dim3((T + 1023) / 1024), dim3(256), 0, s, v, T);
+        hipLaunchKernelGGL(k_tile_totals, dim3((v.tpad + 1023) / 1024), dim3(256), 0, s, v, T);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, g.block_ref_tiles,
                            (uint32_t)((P + 255) / 256), h->host_counts_dev);
     }
