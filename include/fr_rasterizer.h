@@ -16,16 +16,20 @@
  *   fr_mark_visible   replaces CudaRasterizer::Rasterizer::markVisible
  *                     (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153),
  *                     called from markVisible (rasterize_points.cu:198-217)
- *   fr_bind_forward / fr_bind_backward replace the ~40 PyTorch kernels of the mesh binding (model/fateavatar.py:225-258)
+ *   fr_bind_forward / fr_bind_backward / fr_face_scale replace the ~40 PyTorch kernels of the mesh
+ *                     binding (model/fateavatar.py:225-258, volume_rendering/mesh_compute.py:27-59)
  *   fr_adam_step      replaces torch.optim.Adam.step() over the Gaussian groups (train/optim.py:11-37)
  *   fr_knn_mean_dist2 replaces SimpleKNN::knn (simple_knn.h, simple_knn.cu:186-222),
  *                     called from distCUDA2 (spatial.cu:14-25)
+ *   fr_knn_nearest_dist2 replaces pytorch3d knn_points(p, p, K=6).dists[..., 1] in get_init_scale_by_knn
+ *                     (model/fateavatar.py:597-608)
  *
  * Differences from the reference interface, all deliberate:
  *   - Scratch is three caller-owned byte buffers sized by fr_*_bytes() instead of
  *     std::function<char*(size_t)> resize callbacks: the caller's allocator stays in
- *     charge (torch caching allocator in the Python host) and nothing is allocated
- *     inside a call.
+ *     charge (torch caching allocator in the Python host).  The only device memory the
+ *     library owns is a few hundred KB of per-tile counters inside the fr_handle,
+ *     allocated when an image size is first seen.
  *   - The binning buffer has a CAPACITY.  fr_forward never blocks the GPU on the
  *     instance count (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:281):
  *     it enqueues the whole frame, then reads the counts the scan kernel wrote to pinned
@@ -55,9 +59,9 @@ extern "C" {
 #define FR_ERR_UNSUPPORTED 4
 
 /* Per-device context: pinned count slot, event, and the per-tile binning counters (device memory, kept zero
- * between frames so that a frame needs no zeroing launch).  Calls on one handle must be issued by one host thread
- * and be ordered on the stream(s) they are enqueued on: two fr_forward calls of the same handle must not run
- * concurrently.  The counters grow with the tile grid (hipMalloc — not while the stream is being captured into a
+ * between frames so that a frame needs no zeroing launch).  Calls on one handle must not overlap: neither on the host
+ * (one thread at a time) nor on the device (two fr_forward calls of the same handle must be ordered by the stream(s)
+ * they are enqueued on).  The counters grow with the tile grid (hipMalloc — not while the stream is being captured into a
  * hipGraph: run one eager frame of that image size first). */
 typedef struct fr_handle fr_handle;
 
