@@ -703,3 +703,26 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
     for x, y in zip(va, vb):
         assert util.rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-5
     assert not torch.equal(va[0], va[1])
+
+
+def test_experimental_fused_blend_kernel_stays_correct(gpu_device):
+    """FR_FUSED_BLEND=1 (one-launch k_unit_blend_fused with the in-launch look-back) is off by default; it must keep
+    matching the oracle for as long as it stays in the tree.  Run in a subprocess: the switch is read at handle creation."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from fateavatar_amd import scenes\n"
+        "from tests import util\n"
+        "from tests.test_gpu_parity import _check_forward\n"
+        "dev = torch.device('cuda:0')\n"
+        "for s in (scenes.head_scene(P=20000, res=256, sh_degree=1, seed=0, opacity=0.5),\n"
+        "          scenes.random_scene(4000, 64, 64, sh_degree=0, seed=5, opacity_lo=0.6, opacity_hi=0.99, scale_lo=0.02, scale_hi=0.08)):\n"
+        "    o = util.oracle_forward(s); h = util.HipFrame(s, dev); _check_forward(o, h, 'fused')\n"
+        "    assert h.counts.max_tile_list > 64\n"
+        "print('fused-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, FR_FUSED_BLEND="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "fused-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
