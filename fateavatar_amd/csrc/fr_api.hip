@@ -82,6 +82,7 @@ int fr_create(fr_handle** out)
     memset(h->host_counts, 0, 64);
     FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
     const char* fb = getenv("FR_FUSED_BLEND");  // experimental one-launch k_unit_blend_fused (measured: no gain yet)
     h->no_fused_blend = !(fb && fb[0] == '1');
     *out = reinterpret_cast<fr_handle*>(h);
@@ -93,6 +94,7 @@ int fr_destroy(fr_handle* hh)
     fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
     if (!h) return FR_OK;
     (void)hipEventDestroy(h->counts_ready);
+    if (h->frame_done) (void)hipEventDestroy(h->frame_done);
     for (int st = 0; st < ST_COUNT; st++)
         for (size_t i = 0; i < h->ev[st].start.size(); i++) {
             (void)hipEventDestroy(h->ev[st].start[i]);

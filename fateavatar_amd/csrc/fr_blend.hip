@@ -678,7 +678,11 @@ __global__ void __launch_bounds__(256) k_tile_combine(const DeviceCounts* __rest
     for (uint32_t u = u1; u-- > u0;) {
         const float* o = unit_out + (size_t)u * 5 * kUnit + lane;
         const float To = o[3 * kUnit];
-        const float inv = __builtin_amdgcn_rcpf(To);
+        // A pixel that was already dead when it entered unit u carries To = the plain product of the earlier units'
+        // (1 - alpha) products, which is below 1e-4 and may have underflowed to 0 or a denormal: its state is
+        // (0, 0, 0, To) — nothing behind it contributes — not 0 * rcp(0) = NaN.  A pixel that was alive at the
+        // unit's entry has To >= 1e-4 (T only ever takes values that passed the reference's T test).
+        const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
         unit_state[(size_t)u * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
         Sr += o[0];
         Sg += o[kUnit];
@@ -782,9 +786,12 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
     // The reference's accum_rec (colour blended behind the current Gaussian, backward.cu:515) only ever enters
     // through its dot product with dL/dpixel, and its recurrence is linear: carry that scalar instead of three
     // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
-    float A = (st.x * dpr + st.y * dpg) + st.z * dpb;
     const int m = (int)ui.m;
     const int lim = (int)last - (int)ui.base;  // records of this unit at or behind the pixel's last contributor do nothing
+    // a lane with nothing to do in this unit (pixel terminated earlier, or outside the image) must carry FINITE
+    // state: its alpha is forced to 0 below, and 0 * NaN would still poison the wave reduction
+    float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;
+    if (lim <= 0) T = 0.f;
 
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
         float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup];

@@ -212,6 +212,13 @@ struct fr_handle_impl {
     uint32_t* tile_counters = nullptr;
     size_t tile_counter_tiles = 0;
     bool counters_clean = false;
+    // Frames of one handle share those counters, so they must not overlap on the device.  Frames enqueued on ONE
+    // stream are ordered by it; when the stream changes, the new frame first waits for `frame_done`, recorded
+    // behind the last kernel that touches the counters of the previous frame (not while a stream is being captured:
+    // a capture is ordered by its own stream, and replays of the graph are ordered by whoever launches them).
+    hipEvent_t frame_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     uint32_t fused_grid = 0;     // resident-grid size of k_unit_blend_fused (0 = not queried yet, 1 = kernel not usable)
     bool no_fused_blend = true;  // default; FR_FUSED_BLEND=1 in the environment selects the experimental one-launch
                                  // k_unit_blend_fused instead of k_unit_tseg + k_unit_blend

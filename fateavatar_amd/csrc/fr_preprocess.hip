@@ -692,6 +692,13 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     const bool debug = prm.debug != 0;
     int rc;
 
+    // frames of one handle share the per-tile counters: order this frame behind the previous one if that was
+    // enqueued on a different stream (fr_common.hpp, fr_handle_impl::frame_done)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    if (!capturing && h->have_last && h->last_stream != s) FR_HIP(hipStreamWaitEvent(s, h->frame_done, 0));
+
     // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
@@ -752,6 +759,10 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
     h->counters_clean = true;
+    if (!capturing) {
+        FR_HIP(hipEventRecord(h->frame_done, s));
+        h->last_stream = s, h->have_last = true;
+    }
 
     if (no_wait) return FR_OK;
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).

@@ -81,6 +81,17 @@ class FusedAdam:
             end += new_rows * w
             self.cfg.segment_end[i] = end
 
+    @torch.no_grad()
+    def zero_field_moments(self, widths: Sequence[int], rows: int, fields: Sequence[int]) -> None:
+        """Zero the moments of whole fields IN PLACE (_reset_opacity, model/fateavatar.py:713-731): the buffers keep
+        their addresses, so a HIP graph that captured fr_adam_step stays valid."""
+        off = 0
+        for f, w in enumerate(widths):
+            if f in fields:
+                self.exp_avg[off:off + rows * w].zero_()
+                self.exp_avg_sq[off:off + rows * w].zero_()
+            off += rows * w
+
     def set_grad_scale(self, s: float) -> None:
         self.cfg.grad_scale = float(s)
 

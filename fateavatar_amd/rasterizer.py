@@ -55,9 +55,26 @@ _no_wait = False
 
 
 def set_no_wait(on: bool) -> None:
-    """Capture mode: make rasterize_gaussians free of host synchronisation (see FR_FLAG_NO_WAIT)."""
+    """Capture mode: make rasterize_gaussians free of host synchronisation (see FR_FLAG_NO_WAIT).  Process-wide:
+    prefer the scoped form `with no_wait(): ...` around a graph capture, so that renders outside the capture (a
+    validation view, a second model) keep their overflow check and capacity regrow."""
     global _no_wait
     _no_wait = bool(on)
+
+
+class no_wait:
+    """`with rasterizer.no_wait():` — FR_FLAG_NO_WAIT for the forwards issued inside the block only."""
+
+    def __enter__(self):
+        global _no_wait
+        self._prev = _no_wait
+        _no_wait = True
+        return self
+
+    def __exit__(self, *exc):
+        global _no_wait
+        _no_wait = self._prev
+        return False
 
 
 def read_counts(device_index: int = 0):

@@ -55,6 +55,7 @@ class TrainStep:
         self.use_graph = bool(use_graph)
         self._graph = None       # render .. backward (.. Adam when world == 1)
         self._eager_steps = 0
+        self.overflows = 0       # replayed frames that overflowed the captured binning capacity (see _poll_overflow)
 
     # -- the step body: everything between zero_grad and the gradient exchange
     def _forward_backward(self):
@@ -74,22 +75,24 @@ class TrainStep:
 
     def _capture(self):
         from . import rasterizer
-        rasterizer.set_no_wait(True)  # nothing in the captured frame may wait on the host
-        # one frame on a side stream warms the allocator pools of the capture path; it is not a step (no Adam), so
-        # the statistics it accumulated are put back
-        acc, den = self.xyz_gradient_accum.clone(), self.denom.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._forward_backward()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.xyz_gradient_accum.copy_(acc)
-        self.denom.copy_(den)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # thread_local: an RCCL watchdog thread may exist
-            self._body()
-        torch.cuda.synchronize()
+        # nothing in the captured frame may wait on the host: FR_FLAG_NO_WAIT, scoped to the capture (a replay does not
+        # go through rasterize_gaussians at all), so that other renders of the process keep their overflow handling
+        with rasterizer.no_wait():
+            # one frame on a side stream warms the allocator pools of the capture path; it is not a step (no Adam), so
+            # the statistics it accumulated are put back
+            acc, den = self.xyz_gradient_accum.clone(), self.denom.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._forward_backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.xyz_gradient_accum.copy_(acc)
+            self.denom.copy_(den)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # thread_local: an RCCL watchdog thread may exist
+                self._body()
+            torch.cuda.synchronize()
         self._graph = g
 
     def step(self, camera: TorchCamera, gt_image: torch.Tensor) -> torch.Tensor:
@@ -100,6 +103,8 @@ class TrainStep:
         if self.use_graph and self._graph is None and self._eager_steps >= 2:
             self._capture()
         if self._graph is not None:
+            self._poll_overflow()     # may drop the graph
+        if self._graph is not None:
             self._graph.replay()
         else:
             self._body()              # eager: first steps size the binning capacity (high-water mark)
@@ -108,6 +113,16 @@ class TrainStep:
             dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
             self.adam.step()
         return self.loss
+
+    def _poll_overflow(self):
+        """The scan kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
+        needs no synchronisation (they belong to the most recent frame that has got that far).  A replayed frame that
+        overflowed the capacity the graph was captured with produced no image and no gradients: raise the capacity,
+        drop the graph (the next steps run eagerly with the overflow check, then re-capture) and count the event."""
+        from . import rasterizer
+        if rasterizer.check_async_overflow(self.dev.index or 0):
+            self.overflows += 1
+            self._graph, self._eager_steps = None, 0
 
     # -- Gaussian maintenance (reference: train/iteration.py:62-86 -> model/fateavatar.py:610-731), generic-3DGS flavour:
     #    the FateAvatar versions additionally carry the mesh binding (face index, barycentrics) of every row
@@ -120,8 +135,6 @@ class TrainStep:
         self.denom = torch.zeros((pc.P, 1), device=self.dev)
         pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom)
         self._graph, self._eager_steps = None, 0   # buffers moved: the captured step is stale
-        from . import rasterizer
-        rasterizer.set_no_wait(False)
 
     @torch.no_grad()
     def prune_low_opacity(self, min_opacity: float = 0.005) -> int:
@@ -159,8 +172,8 @@ class TrainStep:
         cur = torch.sigmoid(pc._opacity)
         new = torch.minimum(cur, torch.full_like(cur, 0.01))
         pc._opacity.data.copy_(torch.log(new / (1 - new)))
-        old_index = torch.arange(pc.P, device=self.dev)
-        self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), pc.P, zero_fields=(2,))
+        # in place: the captured graph keeps pointing at the same parameter and moment buffers
+        self.adam.zero_field_moments(pc.widths(), pc.P, fields=(2,))
 
     # -- checkpoint / resume (reference layout: Trainer.save_checkpoint, train/trainer.py:396-435 — a dict with
     #    'global_step' and 'model' = the Gaussian parameters under the GaussianModel names and shapes; the reference

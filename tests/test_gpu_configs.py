@@ -1,0 +1,217 @@
+"""-m gpu: every BASELINE.json configuration at FULL size, HIP (through the C ABI) against the CPU oracle.
+
+  configs[0]  10 k random Gaussians, 256x256, SH degree 0, forward
+  configs[1]  100 k Gaussians on the head template, 512x512, SH degree 3, forward + backward  (the metric's config)
+  configs[2]  per-frame optimiser loop at 100 k / 512x512 (graph replay == eager, loss falls)
+  configs[4]  500 k Gaussians, 1024x1024, SH degree 3 — initial state and the tile-overflow / sort stress variant
+(configs[3], the 8-GPU data-parallel batch, cannot run on a 1-GPU box: tests/test_dp_gloo.py + tests/test_bench_dp.py.)
+Workload statistics are the ones SURVEY.md Appendix B measured on the reference; tolerances as in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from fateavatar_amd import scenes
+from tests import util
+from tests.test_gpu_parity import _check_backward, _check_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_tile_lists(radii, means2D, W, H):
+    """Per-16x16-tile list lengths in reference semantics (auxiliary.h:46-56) from per-Gaussian outputs."""
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r = radii.astype(np.int64)
+    vis = r > 0
+    px, py = means2D[vis, 0], means2D[vis, 1]
+    rr = r[vis].astype(np.float32)
+    x0 = np.clip(((px - rr) / np.float32(16)).astype(np.int32), 0, gx)
+    y0 = np.clip(((py - rr) / np.float32(16)).astype(np.int32), 0, gy)
+    x1 = np.clip(((px + rr + np.float32(15)) / np.float32(16)).astype(np.int32), 0, gx)
+    y1 = np.clip(((py + rr + np.float32(15)) / np.float32(16)).astype(np.int32), 0, gy)
+    cnt = np.zeros((gy + 1, gx + 1), np.int64)  # 2-D difference array
+    np.add.at(cnt, (y0, x0), 1)
+    np.add.at(cnt, (y0, x1), -1)
+    np.add.at(cnt, (y1, x0), -1)
+    np.add.at(cnt, (y1, x1), 1)
+    return cnt.cumsum(0).cumsum(1)[:gy, :gx]
+
+
+def _dpix(H, W, seed=11):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+
+
+def test_config1_random_10k_256(gpu_device):
+    s = scenes.random_scene(10_000, 256, 256, sh_degree=0, seed=0)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "config1")
+    _check_backward(o, h, _dpix(256, 256), "config1")
+
+
+def test_config2_head_100k_512_forward_backward(gpu_device):
+    s = scenes.head_scene()  # P = 100 000, 512 x 512, SH degree 3
+    assert s.P == 100_000 and s.camera.image_width == 512 and s.shs.shape[1] == 16
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "config2")
+    # SURVEY.md Appendix B (reference through a host shim): R = 208 596, 351 non-empty tiles, max list 1570 — derived
+    # here from the HIP path's own per-Gaussian outputs
+    assert h.counts.num_rendered == o.num_rendered and abs(int(h.counts.num_rendered) - 208_596) <= 8
+    ll = _ref_tile_lists(h.radii.cpu().numpy(), h.geometry(0, 2), 512, 512)
+    assert int((ll > 0).sum()) == 351 and int(ll.max()) == 1570 and int(ll.sum()) == h.counts.num_rendered
+    assert 256 < h.counts.max_tile_list <= 1024  # the 4-wave medium sorter is the tier this configuration exercises
+    _check_backward(o, h, _dpix(512, 512), "config2")
+
+
+@pytest.mark.parametrize("variant", ["init", "stress"])
+def test_config5_head_500k_1024(variant, gpu_device):
+    if variant == "init":   # measured nearest-neighbour spacing 2.750e-4, opacity 0.1
+        s = scenes.head_scene(P=500_000, res=1024, sh_degree=3, scale=2.750e-4)
+        want_R, want_max = 1_036_972, 2743
+    else:                   # stress variant: config-2 scale, opacity 0.5 -> long lists, opaque, early termination
+        s = scenes.head_scene(P=500_000, res=1024, sh_degree=3, scale=6.085e-4, opacity=0.5)
+        want_R, want_max = 1_377_268, 3502
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "config5-" + variant)
+    assert h.counts.num_rendered == o.num_rendered and abs(int(h.counts.num_rendered) - want_R) <= 40
+    ll = _ref_tile_lists(h.radii.cpu().numpy(), h.geometry(0, 2), 1024, 1024)
+    assert int(ll.max()) == want_max and int(ll.sum()) == h.counts.num_rendered
+    _check_backward(o, h, _dpix(1024, 1024), "config5-" + variant)
+
+
+FUZZ = [(seed, big) for seed in range(10) for big in (False,)] + [(100 + seed, True) for seed in range(4)]
+
+
+@pytest.mark.parametrize("seed,big", FUZZ)
+def test_fuzz_random_configurations(seed, big, gpu_device):
+    """Seeded random scene configurations (size, image shape, SH degree / stored coefficients, scale and opacity ranges,
+    spread, Gaussians behind the camera, background): forward state, image and every gradient against the oracle."""
+    rng = np.random.default_rng(seed)
+    P = int(rng.integers(1, 60000 if big else 6000))
+    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
+    deg = int(rng.integers(0, 4))
+    slo = float(10 ** rng.uniform(-3.5, -1.5))
+    shi = slo * float(rng.uniform(1, 20))
+    olo = float(rng.uniform(0.001, 0.5))
+    ohi = float(rng.uniform(olo, 1.0))
+    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=float(rng.uniform(0.05, 1.5)), scale_lo=slo,
+              scale_hi=shi, opacity_lo=olo, opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])),
+              M=int(rng.choice([(deg + 1) ** 2, 16])), bg=tuple(rng.uniform(0, 1, 3)))
+    name = f"fuzz{seed}: P={P} {H}x{W} {kw}"
+    s = scenes.random_scene(P, H, W, **kw)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, name)
+    _check_backward(o, h, _dpix(H, W, seed), name)
+
+
+def test_dead_pixel_next_to_live_pixels_gives_finite_gradients(gpu_device):
+    """One pixel of a tile sits under ~150 nearly opaque small splats (its transmittance product underflows to 0 in
+    the units behind), while its neighbours stay alive through several hundred translucent splats behind them: the
+    backward state of the dead pixel must be finite zeros, not 0 * rcp(0) = NaN spread over the whole unit."""
+    rng = np.random.default_rng(7)
+    H = W = 32
+    n_op, n_bg = 150, 400
+    P = n_op + n_bg
+    means = np.zeros((P, 3), np.float32)
+    tan = 0.2
+    # pixel (12, 12): ndc = (2 * (p + 0.5) / W - 1), view x = ndc * tan * z
+    z_op = np.linspace(1.0, 1.2, n_op).astype(np.float32)
+    ndc = 2 * 12.5 / W - 1
+    means[:n_op, 0] = ndc * tan * z_op
+    means[:n_op, 1] = ndc * tan * z_op
+    means[:n_op, 2] = z_op
+    z_bg = np.linspace(1.5, 2.5, n_bg).astype(np.float32)
+    means[n_op:, 0] = rng.uniform(-0.08, 0.02, n_bg).astype(np.float32) * z_bg
+    means[n_op:, 1] = rng.uniform(-0.08, 0.02, n_bg).astype(np.float32) * z_bg
+    means[n_op:, 2] = z_bg
+    scales = np.concatenate([np.full((n_op, 3), 1e-4, np.float32), rng.uniform(0.02, 0.05, (n_bg, 3)).astype(np.float32)])
+    rots = np.zeros((P, 4), np.float32)
+    rots[:, 0] = 1
+    op = np.concatenate([np.full((n_op, 1), 0.8, np.float32), rng.uniform(0.02, 0.08, (n_bg, 1)).astype(np.float32)])
+    shs = rng.uniform(-0.5, 0.5, (P, 1, 3)).astype(np.float32)
+    import math
+    cam = scenes.make_camera(np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 2 * math.atan(tan), 2 * math.atan(tan), H, W)
+    s = scenes.GaussianScene(means, scales, rots, op, shs, 0, np.asarray([0.1, 0.2, 0.3], np.float32), cam)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    assert h.counts.max_tile_list > 3 * 64          # several units per tile
+    assert int(o.n_contrib[12, 12]) < 10 and int(o.n_contrib[8, 8]) > 300   # dead after a few splats, next to pixels alive to the end
+    _check_forward(o, h, "dead_pixel")
+    _check_backward(o, h, _dpix(H, W), "dead_pixel")
+
+
+def test_config3_optimiser_loop_100k_512(gpu_device):
+    """BASELINE.json configs[2] at full size: 100 k Gaussians, 512x512, 60 steps of zero_grad -> render -> L1 ->
+    backward -> statistics -> Adam over 4 orbiting views of a hidden ground-truth set.  The HIP-graph replay of the
+    step must follow the eager step, the loss must fall, and no replayed frame may overflow its binning capacity."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from fateavatar_amd.train import TrainStep
+    P, res, views, steps = 100_000, 512, 4, 60
+    truth = scenes.head_scene(P=P, res=res, sh_degree=1, seed=3, opacity=0.6)
+    cams = [TorchCamera(scenes.head_scene(P=8, res=res, sh_degree=1, seed=3, view=v, n_views=views).camera, gpu_device)
+            for v in range(views)]
+    bg = torch.from_numpy(truth.bg).to(gpu_device)
+    pc_true = FlatGaussians(truth.means3D, truth.shs, truth.opacities, truth.scales, truth.rotations, 1, gpu_device,
+                            fused_activations=True)
+    with torch.no_grad():
+        gts = [render(c, pc_true, bg)["render"].clone() for c in cams]
+    rng = np.random.default_rng(0)
+    shs0 = (truth.shs + 0.3 * rng.standard_normal(truth.shs.shape)).astype(np.float32)
+
+    def run(use_graph):
+        pc = FlatGaussians(truth.means3D, shs0, truth.opacities * 0.7, truth.scales, truth.rotations, 1, gpu_device,
+                           fused_activations=True)
+        cam = TorchCamera(scenes.head_scene(P=8, res=res, sh_degree=1, seed=3, view=0, n_views=views).camera, gpu_device)
+        ts = TrainStep(pc, cam, bg, use_graph=use_graph)
+        losses = [ts.step(cams[it % views], gts[it % views]).clone() for it in range(steps)]
+        torch.cuda.synchronize()
+        ts.check()
+        return pc.flat.clone(), [float(x) for x in losses], ts
+
+    flat_e, loss_e, ts_e = run(False)
+    flat_g, loss_g, ts_g = run(True)
+    assert ts_g._graph is not None and ts_e._graph is None and ts_g.overflows == 0
+    assert np.mean(loss_e[-8:]) < 0.8 * np.mean(loss_e[:8]), loss_e
+    assert np.allclose(loss_g, loss_e, rtol=5e-3), (loss_g[-4:], loss_e[-4:])
+    assert torch.equal(ts_g.denom, ts_e.denom) and float(ts_e.denom.max()) == float(steps)
+    assert ts_g.adam.step_count == steps
+
+
+def test_opacity_reset_keeps_the_captured_step_valid(gpu_device):
+    """reset_opacity() zeroes the opacity moments IN PLACE: the graph captured before the reset keeps updating the live
+    moment buffers, and the step after the reset equals the eager step after the same reset."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    from fateavatar_amd.train import TrainStep
+    truth = scenes.head_scene(P=3000, res=96, sh_degree=1, seed=4, opacity=0.5)
+    cam = TorchCamera(truth.camera, gpu_device)
+    bg = torch.from_numpy(truth.bg).to(gpu_device)
+    mk = lambda: FlatGaussians(truth.means3D, truth.shs * 0.5, truth.opacities, truth.scales, truth.rotations, 1,  # noqa: E731
+                               gpu_device, fused_activations=True)
+    with torch.no_grad():
+        gt = render(cam, FlatGaussians(truth.means3D, truth.shs, truth.opacities, truth.scales, truth.rotations, 1,
+                                       gpu_device, fused_activations=True), bg)["render"].clone()
+    res = {}
+    for use_graph in (False, True):
+        ts = TrainStep(mk(), TorchCamera(truth.camera, gpu_device), bg, use_graph=use_graph)
+        for _ in range(5):
+            ts.step(cam, gt)
+        m_ptr = ts.adam.exp_avg.data_ptr()
+        graph_before = ts._graph
+        ts.reset_opacity()
+        assert ts.adam.exp_avg.data_ptr() == m_ptr and ts._graph is graph_before
+        for _ in range(3):
+            ts.step(cam, gt)
+        torch.cuda.synchronize()
+        o0, o1 = ts.pc.P * (3 + ts.pc.M * 3), ts.pc.P * (3 + ts.pc.M * 3 + 1)
+        res[use_graph] = (ts.pc.flat.clone(), ts.adam.exp_avg[o0:o1].clone())
+        assert float(ts.adam.exp_avg[o0:o1].abs().max()) > 0   # the live buffer is the one being updated
+    assert (ts._graph is not None)
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-3
+    assert torch.allclose(res[True][1], res[False][1], rtol=2e-2, atol=1e-9)

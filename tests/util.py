@@ -77,3 +77,60 @@ def rel_l2(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     d = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a - b))
+
+
+def explain_pixel(o, x: int, y: int):
+    """Why may the pixel (x, y) legitimately differ between two fp32 implementations of the reference's blend loop
+    (forward.cu:330-361)?  Walks the pixel's 16x16-tile list in the ORACLE and returns the smallest normalised margin by
+    which any of the three discrete tests was decided:
+        power > 0            margin |power| / 1e-5                               (absolute: power is O(1))
+        alpha < 1/255        margin |alpha - 1/255| / (1/255) / 2e-5
+        T (1 - alpha) < 1e-4 margin |T (1 - alpha) - 1e-4| / 1e-4 / (2e-5 + 2.4e-7 n)
+    (n = entries blended so far: T is a product of n factors, and the two implementations associate it differently).
+    A value <= 1 means some splat sits on a threshold within rounding: the pixel is a threshold flip."""
+    i = o._inputs
+    W = i["W"]
+    gx = (W + 15) // 16
+    t = (y // 16) * gx + (x // 16)
+    lo, hi = int(o.ranges[t, 0]), int(o.ranges[t, 1])
+    ids = o.point_list[lo:hi].astype(np.int64)
+    if ids.size == 0:
+        return np.inf
+    f32 = np.float32
+    xy = o.means2D[ids]
+    co = o.conic_opacity[ids]
+    dx = (xy[:, 0] - f32(x)).astype(f32)
+    dy = (xy[:, 1] - f32(y)).astype(f32)
+    power = (f32(-0.5) * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy).astype(f32)
+    alpha = np.minimum(f32(0.99), co[:, 3] * np.exp(np.minimum(power, f32(0)))).astype(f32)
+    best = float(np.min(np.abs(power.astype(np.float64)) / 1e-5))
+    T = 1.0
+    n = 0
+    for k in range(ids.size):
+        if power[k] > 0:
+            continue
+        a = float(alpha[k])
+        best = min(best, abs(a - 1.0 / 255.0) * 255.0 / 2e-5)
+        if a < 1.0 / 255.0:
+            continue
+        tt = T * (1.0 - a)
+        best = min(best, abs(tt - 1e-4) / 1e-4 / (2e-5 + 2.4e-7 * n))
+        if tt < 1e-4:
+            break
+        T = tt
+        n += 1
+    return best
+
+
+def unexplained_outliers(o, got_color, got_T, rtol=1e-4, atol=1e-5, limit=2000):
+    """Pixels where the image or the final transmittance is outside tolerance and NO splat of the pixel's list sits
+    on one of the reference's thresholds (explain_pixel > 1).  Returns (n_outliers, [(x, y, margin), ...])."""
+    bad = (np.abs(got_color - o.color) > atol + rtol * np.abs(o.color)).any(0) | \
+          (np.abs(got_T - o.final_T) > atol + rtol * np.abs(o.final_T))
+    ys, xs = np.nonzero(bad)
+    out = []
+    for x, y in list(zip(xs.tolist(), ys.tolist()))[:limit]:
+        m = explain_pixel(o, x, y)
+        if not (m <= 1.0):
+            out.append((x, y, m))
+    return int(bad.sum()), out
