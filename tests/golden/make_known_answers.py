@@ -1,0 +1,367 @@
+"""Known-answer vectors for the rasterizer proper that NEITHER oracle/fr_oracle.c NOR the HIP kernels produced.
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_known_answers.py        (build container only)
+
+The reference ships no test or fixture for its rasterizer, and its CUDA sources cannot be built in this image, so the
+blend / binning / backward arithmetic has no reference-held pin.  This script is the substitute VERDICT r1 asked for:
+
+  * forward: a float64 numpy evaluation of the rasterizer's mathematics for tiny analytic scenes, written from the
+    formulas the reference cites (EWA splatting projection, forward.cu:74-113; Sigma = R S S R^T, forward.cu:118-152;
+    near cull / 1e-7 homogeneous guard, auxiliary.h:139-164; ndc2Pix and getRect, auxiliary.h:41-56; conic / radius,
+    forward.cu:216-232; the per-pixel loop and its three tests, forward.cu:330-361; output, forward.cu:367-373).  The
+    SH colour comes from the REFERENCE's own `eval_sh` (tools/gs_utils/sh_utils.py, imported here), the camera
+    matrices from the reference's `getWorld2View2` / `getProjectionMatrix` (tools/gs_utils/graphics_utils.py).
+  * gradients: CENTRAL FINITE DIFFERENCES of that float64 forward (loss = sum(out * dL_dpix)), i.e. no restatement
+    of backward.cu at all.  Two places where the reference's backward is deliberately NOT the derivative of its forward
+    are modelled in the forward that is differentiated:
+      - guard-band clamp (backward.cu:168-176,262-264): the clamped t.x / t.y are constants (stop-gradient);
+      - dL_dmeans2D is the derivative w.r.t. the NDC-scaled pixel centre in the blend only (backward.cu:460-461,545-546):
+        obtained by perturbing the 2D centres with everything else fixed, times 0.5 W / 0.5 H.
+    (The third, the 0.99 alpha clamp whose gradient the reference passes straight through, backward.cu:499-534, is kept
+    out of the gradient scenes — opacities <= 0.98 — and covered by a forward-only scene.)
+
+Every scene is checked to sit far from the discrete decisions (power > 0, alpha < 1/255, T < 1e-4, radius ceil, tile
+rectangle, depth order), so that an fp32 implementation takes the same ones.  Output: tests/golden/known_answers.npz
+(inputs + expected outputs; data only).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+from tools.gs_utils import sh_utils  # noqa: E402
+from tools.gs_utils.graphics_utils import getProjectionMatrix, getWorld2View2  # noqa: E402
+
+TILE = 16  # config.h:16-17
+
+
+def camera(R, T, fovx, fovy):
+    """camera_3dgs.py:53-72 with the reference's own helpers."""
+    wvt = torch.tensor(getWorld2View2(np.asarray(R, np.float64), np.asarray(T, np.float64))).float().transpose(0, 1)
+    proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+    center = wvt.inverse()[3, :3]
+    return wvt.numpy().astype(np.float32), full.numpy().astype(np.float32), center.numpy().astype(np.float32)
+
+
+def sh_colour(D, sh, direction):
+    """max(eval_sh + 0.5, 0) (forward.cu:63-70) through the reference's eval_sh, float64."""
+    s = torch.from_numpy(np.ascontiguousarray(sh.T))[None]          # [1, 3, M]
+    d = torch.from_numpy(direction)[None]
+    v = sh_utils.eval_sh(D, s, d)[0].numpy() + 0.5
+    return np.maximum(v, 0.0)
+
+
+def per_gaussian(sc, frozen=None, margins=None):
+    """Float64 preprocess.  Returns a dict of per-Gaussian arrays; `frozen` = (flag_x, tx, flag_y, ty) of the baseline."""
+    f64 = np.float64
+    P = sc["means3D"].shape[0]
+    W, H = sc["W"], sc["H"]
+    view, proj, campos = sc["viewmatrix"].astype(f64), sc["projmatrix"].astype(f64), sc["campos"].astype(f64)
+    fx, fy = W / (2.0 * sc["tanfovx"]), H / (2.0 * sc["tanfovy"])
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    out = dict(radii=np.zeros(P, np.int32), xy=np.zeros((P, 2)), depth=np.zeros(P), conic=np.zeros((P, 3)),
+               rgb=np.zeros((P, 3)), rect=np.zeros((P, 4), np.int64), clampx=np.zeros(P, bool), clampy=np.zeros(P, bool),
+               tx=np.zeros(P), ty=np.zeros(P))
+    for i in range(P):
+        p = sc["means3D"][i].astype(f64)
+        pv = np.append(p, 1.0) @ view
+        if pv[2] <= 0.2:
+            continue
+        ph = np.append(p, 1.0) @ proj
+        pw = 1.0 / (ph[3] + 0.0000001)
+        ndc = ph[:2] * pw
+        if sc.get("cov3D_precomp") is not None:
+            c6 = sc["cov3D_precomp"][i].astype(f64)
+            Sig = np.array([[c6[0], c6[1], c6[2]], [c6[1], c6[3], c6[4]], [c6[2], c6[4], c6[5]]])
+        else:
+            r, x, y, z = sc["rotations"][i].astype(f64)
+            Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                           [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                           [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+            Mm = Rm @ np.diag(sc["scale_modifier"] * sc["scales"][i].astype(f64))
+            Sig = Mm @ Mm.T
+        limx, limy = 1.3 * sc["tanfovx"], 1.3 * sc["tanfovy"]
+        tz = pv[2]
+        cx, cy = abs(pv[0] / tz) > limx, abs(pv[1] / tz) > limy
+        tx = min(limx, max(-limx, pv[0] / tz)) * tz
+        ty = min(limy, max(-limy, pv[1] / tz)) * tz
+        if frozen is not None:                       # stop-gradient of the clamped values (backward.cu:168-176)
+            if frozen[0][i]:
+                tx = frozen[1][i]
+            if frozen[2][i]:
+                ty = frozen[3][i]
+        out["clampx"][i], out["clampy"][i], out["tx"][i], out["ty"][i] = cx, cy, tx, ty
+        J = np.array([[fx / tz, 0.0, -fx * tx / (tz * tz)], [0.0, fy / tz, -fy * ty / (tz * tz)]])
+        Wm = view[:3, :3].T                          # world -> view rotation
+        cov = J @ Wm @ Sig @ Wm.T @ J.T
+        a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+        det = a * c - b * b
+        if det == 0.0:
+            continue
+        mid = 0.5 * (a + c)
+        lam = mid + math.sqrt(max(0.1, mid * mid - det))
+        lam2 = mid - math.sqrt(max(0.1, mid * mid - det))
+        rr = 3.0 * math.sqrt(max(lam, lam2))
+        radius = int(math.ceil(rr))
+        px, py = ((ndc[0] + 1.0) * W - 1.0) * 0.5, ((ndc[1] + 1.0) * H - 1.0) * 0.5
+        e = [(px - radius) / TILE, (py - radius) / TILE, (px + radius + TILE - 1) / TILE, (py + radius + TILE - 1) / TILE]
+        x0, y0 = min(gx, max(0, int(e[0]))), min(gy, max(0, int(e[1])))     # int(): C truncation
+        x1, y1 = min(gx, max(0, int(e[2]))), min(gy, max(0, int(e[3])))
+        if margins is not None:
+            margins.append(("radius", abs(rr - round(rr))))
+            margins.extend(("rect", abs(v - round(v))) for v in e if -0.5 < v < max(gx, gy) + 0.5)
+        if (x1 - x0) * (y1 - y0) == 0:
+            continue
+        if sc.get("colors_precomp") is not None:
+            rgb = sc["colors_precomp"][i].astype(f64)
+        else:
+            d = p - campos
+            rgb = sh_colour(sc["D"], sc["shs"][i].astype(f64), d / np.linalg.norm(d))
+        out["radii"][i], out["xy"][i], out["depth"][i] = radius, (px, py), pv[2]
+        out["conic"][i], out["rgb"][i], out["rect"][i] = (c / det, -b / det, a / det), rgb, (x0, y0, x1, y1)
+    return out
+
+
+def forward64(sc, frozen=None, d_xy=None, order=None, margins=None):
+    g = per_gaussian(sc, frozen, margins)
+    W, H = sc["W"], sc["H"]
+    P = sc["means3D"].shape[0]
+    xy = g["xy"] + (d_xy if d_xy is not None else 0.0)
+    op = sc["opacities"].astype(np.float64).reshape(-1)
+    bg = sc["bg"].astype(np.float64)
+    vis = np.nonzero(g["radii"] > 0)[0]
+    if order is None:   # sort on the float32 depth bits, stable in the Gaussian index (rasterizer_impl.cu:88-108,300-308)
+        order = sorted(vis.tolist(), key=lambda i: (np.float32(g["depth"][i]), i))
+    color = np.zeros((3, H, W))
+    final_T = np.ones((H, W))
+    n_contrib = np.zeros((H, W), np.int64)
+    decisions = []
+    for y in range(H):
+        for x in range(W):
+            tx_, ty_ = x // TILE, y // TILE
+            T, C, contributor, last = 1.0, np.zeros(3), 0, 0
+            taken = 0   # bit k set: list entry k was blended (the discrete decisions of this pixel)
+            for i in order:
+                x0, y0, x1, y1 = g["rect"][i]
+                if not (x0 <= tx_ < x1 and y0 <= ty_ < y1):
+                    continue
+                contributor += 1
+                dx, dy = xy[i, 0] - x, xy[i, 1] - y
+                A, B, Cc = g["conic"][i]
+                power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+                if margins is not None and A * Cc - B * B <= 0:   # a positive-definite conic cannot give power > 0
+                    margins.append(("power", abs(power)))
+                if power > 0.0:
+                    continue
+                alpha = min(0.99, op[i] * math.exp(power))
+                if margins is not None:
+                    margins.append(("alpha", abs(alpha * 255.0 - 1.0)))
+                if alpha < 1.0 / 255.0:
+                    continue
+                test_T = T * (1.0 - alpha)
+                if margins is not None:
+                    margins.append(("T", abs(test_T / 1e-4 - 1.0)))
+                if test_T < 0.0001:
+                    break
+                C += g["rgb"][i] * alpha * T
+                T = test_T
+                last = contributor
+                taken |= 1 << contributor
+            decisions.append(taken)
+            final_T[y, x], n_contrib[y, x] = T, last
+            color[:, y, x] = C + T * bg
+    sig = (tuple(decisions), g["radii"].tobytes(), g["rect"].tobytes(), (g["rgb"] > 0).tobytes())
+    return dict(color=color, final_T=final_T, n_contrib=n_contrib, radii=g["radii"], order=order, g=g, sig=sig)
+
+
+def known_answer(sc, grads=True):
+    margins = []
+    base = forward64(sc, margins=margins)
+    worst = {}
+    for k, v in margins:
+        worst[k] = min(worst.get(k, np.inf), v)
+    need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
+    for k, v in worst.items():
+        assert v > need[k], (sc["name"], "scene sits on a discrete decision", k, v)
+    # depth order must not hinge on fp32 rounding: distinct depths differ by > 1e-5, or are exactly equal
+    dep = [base["g"]["depth"][i] for i in base["order"]]
+    for a, b in zip(dep, dep[1:]):
+        assert a == b or b - a > 1e-5, (sc["name"], "depths too close", a, b)
+    res = dict(color=base["color"], final_T=base["final_T"], n_contrib=base["n_contrib"].astype(np.int32), radii=base["radii"])
+    if not grads:
+        return res
+    g0 = base["g"]
+    frozen = (g0["clampx"], g0["tx"], g0["clampy"], g0["ty"])
+    G = sc["dL_dpix"].astype(np.float64)
+    order = base["order"]
+
+    def loss(scene, d_xy=None):
+        f = forward64(scene, frozen, d_xy, order)
+        return float((f["color"] * G).sum()), f["sig"]
+
+    def central(make, scale):
+        """Central difference whose two evaluations take the SAME discrete decisions as the base point (blended
+        entries per pixel, radii, rectangles, SH clamps): the step shrinks until they do."""
+        for h in (1e-6 * scale, 1e-7 * scale, 1e-8 * scale, 1e-9 * scale):
+            (lp, sp), (lm, sm) = loss(*make(+h)), loss(*make(-h))
+            if sp == base["sig"] and sm == base["sig"]:
+                return (lp - lm) / (2 * h)
+        raise AssertionError((sc["name"], "no step keeps the discrete decisions"))
+
+    def fd(key):
+        arr = sc[key].astype(np.float64)
+        out = np.zeros_like(arr)
+        it = np.nditer(arr, flags=["multi_index"])
+        for v in it:
+            idx = it.multi_index
+
+            def make(h, idx=idx):
+                a = arr.copy()
+                a[idx] += h
+                return (dict(sc, **{key: a}),)
+            out[idx] = central(make, max(1.0, abs(float(v))))
+        return out
+
+    P = sc["means3D"].shape[0]
+    res["dL_dmeans3D"] = fd("means3D")
+    res["dL_dopacity"] = fd("opacities").reshape(P, 1)
+    if sc.get("colors_precomp") is not None:
+        res["dL_dcolors"] = fd("colors_precomp")
+    else:
+        res["dL_dsh"] = fd("shs")
+    if sc.get("cov3D_precomp") is not None:
+        res["dL_dcov3D"] = fd("cov3D_precomp")   # NB: the 6 stored floats; off-diagonals enter the matrix twice
+    else:
+        res["dL_dscales"] = fd("scales")
+        res["dL_drotations"] = fd("rotations")
+    d2 = np.zeros((P, 3))
+    for i in range(P):
+        for k, half in ((0, 0.5 * sc["W"]), (1, 0.5 * sc["H"])):
+            def make(h, i=i, k=k):
+                d = np.zeros((P, 2))
+                d[i, k] = h
+                return sc, d
+            d2[i, k] = central(make, 1.0) * half
+    res["dL_dmeans2D"] = d2
+    return res
+
+
+def quat(axis, deg):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    h = math.radians(deg) / 2
+    return np.concatenate([[math.cos(h)], math.sin(h) * a]).astype(np.float32)
+
+
+def scenes():
+    rng = np.random.default_rng(20260928)
+    f32 = np.float32
+    out = []
+
+    def base(name, W, H, tan, R=np.eye(3), T=(0, 0, 0), bg=(0.2, 0.5, 0.9)):
+        fov = 2 * math.atan(tan)
+        fovy = 2 * math.atan(tan * H / W)
+        wvt, full, ctr = camera(R, T, fov, fovy)
+        return dict(name=name, W=W, H=H, tanfovx=math.tan(fov / 2), tanfovy=math.tan(fovy / 2), viewmatrix=wvt, projmatrix=full,
+                    campos=ctr, bg=np.asarray(bg, f32), scale_modifier=1.0,
+                    dL_dpix=(rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32))
+
+    def sh(P, D, M):
+        s = np.zeros((P, M, 3), f32)
+        s[:, :(D + 1) ** 2] = rng.uniform(-0.6, 0.9, (P, (D + 1) ** 2, 3))
+        return s
+
+    # A: one isotropic Gaussian whose centre projects onto a pixel centre (10, 7) of a 32 x 32 image
+    s = base("single_centred", 32, 32, 0.25)
+    z = 2.0
+    ndc = lambda p, S: (2 * p + 1) / S - 1  # noqa: E731
+    # (3e-3 px off the exact centre, so that no implementation can round the centre pixel's power to +0)
+    s.update(means3D=np.asarray([[ndc(10.003, 32) * s["tanfovx"] * z, ndc(6.998, 32) * s["tanfovy"] * z, z]], f32),
+             scales=np.full((1, 3), 0.035, f32), rotations=quat((0, 0, 1), 0)[None], opacities=np.asarray([0.6], f32),
+             shs=sh(1, 0, 1), D=0)
+    out.append(s)
+
+    # B: two anisotropic Gaussians at EXACTLY the same depth (order = index), a third behind them, one behind the camera
+    #    (culled), one far off screen (empty rectangle); rotated camera; 40 x 24 image = partial edge tiles; SH degree 1
+    #    (unrotated camera: view z = z + T_z is then computed identically for both, an exact tie in any precision)
+    s = base("depth_tie", 40, 24, 0.3, T=(0.02, -0.01, 0.1), bg=(0.0, 0.0, 0.0))
+    m = np.asarray([[0.03, 0.02, 1.5], [-0.05, 0.03, 1.5], [0.0, 0.0, 1.9], [0.0, 0.0, -1.0], [5.0, 0.1, 1.5]], np.float64)
+    s.update(means3D=m.astype(f32),
+             scales=np.asarray([[0.05, 0.02, 0.03], [0.02, 0.06, 0.02], [0.12, 0.1, 0.05], [0.05, 0.05, 0.05], [0.05, 0.05, 0.05]], f32),
+             rotations=np.stack([quat((1, 2, 3), 40), quat((3, -1, 1), 75), quat((0, 1, 0), 20), quat((1, 0, 0), 0), quat((1, 0, 0), 0)]),
+             opacities=np.asarray([0.5, 0.7, 0.9, 0.5, 0.5], f32), shs=sh(5, 1, 4), D=1)
+    out.append(s)
+
+    # C: a large Gaussian whose centre lies OUTSIDE the 1.3 tan(fov) guard band (clamped Jacobian, stop-gradient quirk)
+    #    but whose footprint reaches into the image, plus an ordinary one; SH degree 2
+    s = base("guard_band", 32, 32, 0.3, bg=(1.0, 1.0, 1.0))
+    s.update(means3D=np.asarray([[0.62, 0.05, 1.4], [-0.02, 0.49, 1.2], [0.05, -0.04, 1.0]], f32),
+             scales=np.asarray([[0.16, 0.09, 0.1], [0.07, 0.15, 0.08], [0.04, 0.03, 0.05]], f32),
+             rotations=np.stack([quat((0, 0, 1), 25), quat((1, 1, 0), 50), quat((1, 0, 1), 10)]),
+             opacities=np.asarray([0.8, 0.6, 0.4], f32), shs=sh(3, 2, 9), D=2)
+    out.append(s)
+
+    # D: colors_precomp + cov3D_precomp; the second covariance is INDEFINITE, so the conic is too and part of its
+    #    pixels have power > 0 (skipped, forward.cu:336-337)
+    s = base("indefinite_precomp", 32, 32, 0.25)
+    s.update(means3D=np.asarray([[0.03, 0.0, 1.3], [-0.04, 0.02, 1.6]], f32),
+             cov3D_precomp=np.asarray([[0.004, 0.001, 0.0, 0.006, 0.0005, 0.003],
+                                       [0.004, 0.009, 0.0, -0.002, 0.0, 0.003]], f32),
+             colors_precomp=np.asarray([[0.9, 0.2, 0.1], [0.1, 0.6, 0.8]], f32), opacities=np.asarray([0.7, 0.9], f32),
+             scales=None, rotations=None, shs=None, D=0)
+    out.append(s)
+
+    # E: eight almost coincident, fairly opaque Gaussians: pixels near the centre TERMINATE (T < 1e-4) part-way through the
+    #    list, pixels further out blend all of them; SH degree 3
+    ang = math.radians(7)
+    Rb = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    s = base("terminates", 32, 32, 0.25, R=Rb, T=(0.15, 0.01, 0.05), bg=(0.3, 0.1, 0.7))
+    n = 8
+    m = np.zeros((n, 3), np.float64)
+    m[:, 0] = 0.01 + 0.004 * rng.standard_normal(n)
+    m[:, 1] = -0.02 + 0.004 * rng.standard_normal(n)
+    m[:, 2] = 1.2 + 0.05 * np.arange(n)
+    s.update(means3D=m.astype(f32), scales=rng.uniform(0.03, 0.06, (n, 3)).astype(f32),
+             rotations=np.stack([quat(rng.standard_normal(3), float(rng.uniform(0, 180))) for _ in range(n)]),
+             opacities=np.full(n, 0.85, f32), shs=sh(n, 3, 16), D=3)
+    out.append(s)
+
+    # F (forward only): opacity 1 -> alpha is clamped at 0.99 near the centre (forward.cu:343)
+    s = base("alpha_clamp_forward_only", 32, 32, 0.25)
+    s.update(means3D=np.asarray([[0.0, 0.0, 1.5], [0.02, 0.01, 2.0]], f32), scales=np.asarray([[0.06] * 3, [0.1] * 3], f32),
+             rotations=np.stack([quat((0, 0, 1), 0)] * 2), opacities=np.asarray([1.0, 0.9], f32), shs=sh(2, 0, 1), D=0,
+             forward_only=True)
+    out.append(s)
+    return out
+
+
+def main():
+    blob = {}
+    names = []
+    for sc in scenes():
+        ka = known_answer(sc, grads=not sc.get("forward_only", False))
+        n = sc["name"]
+        names.append(n)
+        for k, v in sc.items():
+            if k in ("name", "forward_only") or v is None:
+                continue
+            blob[f"{n}/in/{k}"] = np.asarray(v)
+        for k, v in ka.items():
+            blob[f"{n}/out/{k}"] = np.asarray(v)
+        print(n, "radii", ka["radii"], "min final_T", float(ka["final_T"].min()), "max n_contrib", int(ka["n_contrib"].max()),
+              "terminated px", int(((ka["final_T"] < 1e-3)).sum()))
+    blob["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **blob)
+
+
+if __name__ == "__main__":
+    main()

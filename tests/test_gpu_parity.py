@@ -63,10 +63,29 @@ def _check_forward(o, h, name):
     assert np.abs(col - o.color).max() < 0.05, name
 
 
+def _flip_affected_gaussians(o, h):
+    """Gaussians whose gradient a threshold flip can legitimately change: everything in the 16x16-tile list of a pixel
+    whose forward value is outside the tolerance (such pixels are checked to BE threshold flips by _check_forward).  A
+    flip changes the transmittance of every later entry of that pixel, hence the gradients of all of them."""
+    col, fT = h.color.cpu().numpy(), h.final_T.cpu().numpy()
+    bad = (np.abs(col - o.color) > 1e-5 + 1e-4 * np.abs(o.color)).any(0) | (np.abs(fT - o.final_T) > 1e-5 + 1e-4 * np.abs(o.final_T))
+    mask = np.zeros(o.radii.shape[0], bool)
+    if bad.any():
+        H, W = bad.shape
+        gx = (W + 15) // 16
+        ys, xs = np.nonzero(bad)
+        for t in np.unique((ys // 16) * gx + xs // 16):
+            mask[o.point_list[int(o.ranges[t, 0]):int(o.ranges[t, 1])]] = True
+    return mask, int(bad.sum())
+
+
 def _check_backward(o, h, dpix, name):
     from oracle import oracle
     ob = oracle.backward(o, dpix)
     hb = h.backward(dpix)
+    skip, n_flips = _flip_affected_gaussians(o, h)
+    assert n_flips <= max(1, int(1e-4 * dpix.shape[1] * dpix.shape[2])), (name, n_flips)
+    keep = ~skip
     for k in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
               "dL_drotations"]:
         ref, got = getattr(ob, k), hb[k]
@@ -76,9 +95,12 @@ def _check_backward(o, h, dpix, name):
         if scale == 0:
             assert np.abs(got).max() == 0, (name, k)
             continue
-        fr = util.frac_close(got, ref, 1e-4, 1e-6 * scale)
-        rl = util.rel_l2(got, ref)
-        assert fr >= 0.999 and rl <= 2e-4, (name, k, fr, rl)
+        fr = util.frac_close(got[keep], ref[keep], 1e-4, 1e-6 * scale)
+        rl = util.rel_l2(got[keep], ref[keep])
+        assert fr >= 0.999 and rl <= 2e-4, (name, k, fr, rl, n_flips, int(skip.sum()))
+        # Gaussians that share a pixel with a threshold flip: same sign and size, not garbage
+        if skip.any():
+            assert util.rel_l2(got[skip], ref[skip]) <= 0.2, (name, k, "flip-affected rows")
 
 
 @pytest.mark.parametrize("name", list(SCENES))
