@@ -2,32 +2,44 @@
 """bench.py — render+backward frames/s of the MI355X rasterizer on BASELINE.json's metric config.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
 
-A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` through the reference's Python
-API (activations inside the HIP preprocess kernels by default, `--torch-activations` for the reference's
-stock PyTorch ops) followed by the backward pass down to the raw Gaussian parameters; at N > 1 each rank
-renders its own view of the replicated Gaussians and the step ends with ONE RCCL all-reduce(AVG) of the flat
-gradient buffer.
-Workload (config.workload): BASELINE.json configs[1] — 100 000 Gaussians sampled on the head
-template, 512x512, SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident
-in HBM before the timed region.
+With N > 1 and no torchrun environment the script re-executes itself through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one rank per GPU, RCCL); launched by torchrun directly it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
+A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` through the reference's Python API
+(activations inside the HIP preprocess kernels by default, `--torch-activations` for the reference's stock PyTorch ops)
+followed by the backward pass down to the raw Gaussian parameters, replayed as one HIP graph.  At N > 1 each rank
+renders its own view of the replicated Gaussians and every step ends with ONE RCCL all-reduce(AVG) of the flat gradient
+buffer.  The collective runs on RCCL's stream on a copy of the gradient and overlaps the next frame's
+kernels; step k+2 waits for the collective of step k (two buffers), and the timed region ends when the last one has
+finished — no all-reduce is skipped or left outside the clock.
+Workload (config.workload): BASELINE.json configs[1] — 100 000 Gaussians sampled on the head template, 512x512,
+SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident in HBM before the timed region.
 
 The JSON line carries
-  roofline     — the blend backward (the graded kernel): algorithmic bytes 76*R + 20*H*W + 8*T
-                 (R = num_rendered and T = 16x16 tiles in reference semantics) divided by
-                 that kernel's mean launch duration, measured with HIP events on the launch stream over
-                 eager launches of the same frame right after the timed region (events recorded inside a
-                 replayed graph cannot be read back), against the 8 TB/s HBM peak.
-  cpu_baseline — the CPU oracle (oracle/fr_oracle.c, OpenMP, kind "port": the reference has no CPU
-                 rasterizer) timed on the host cores on a bounded sample of the same frames.
+  roofline     — the blend backward (the graded kernel): algorithmic bytes 76*R + 20*H*W + 8*T (SURVEY.md §8d;
+                 R = num_rendered, T = 16x16 tiles, reference semantics) / that kernel's mean launch duration, measured
+                 with HIP events on the launch stream over eager launches of the same frame right after the timed
+                 region (events inside a replayed graph cannot be read back), against the 8 TB/s HBM peak.  `traffic`
+                 and `valu_frac` are NOT measured by this run: they come from the committed counter profile named in
+                 `counters_source` (rocprofv3 --pmc passes, tools/pmc.sh), or are null when no profile matches.
+  stage_frac   — every stage's algorithmic bytes / its measured time / 8 TB/s (formulas: STAGE_BYTES below).
+  cpu_baseline — the CPU oracle (oracle/fr_oracle.c, OpenMP, kind "port": the reference has no CPU rasterizer) on a
+                 bounded sample of the same frames: best thread count of a quick sweep, and one thread.
+  dp           — N > 1: ranks seen, backend, RCCL version, per-rank num_rendered, all-reduce payload and its
+                 un-overlapped duration.
+
+FR_BENCH_STUB=1 replaces the rasterizer by a deterministic CPU gradient generator so that the N > 1 control flow can
+be exercised without GPUs (tests/test_bench_dp.py); such a line says "data": "stub" and is not a measurement.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,16 +49,23 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fateavatar_amd import _lib, dp, scenes  # noqa: E402
-from fateavatar_amd.model import FlatGaussians, TorchCamera  # noqa: E402
-from fateavatar_amd.render import render  # noqa: E402
-from fateavatar_amd import rasterizer  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
+STUB = os.environ.get("FR_BENCH_STUB") == "1"
 
 
-def cpu_baseline(scene, n_frames: int):
-    """Oracle forward+backward on the host, all cores.  Returns (frames/s, threads, sample text)."""
+def stage_bytes(P: int, M: int, R: int, H: int, W: int) -> dict:
+    """Algorithmic (compulsory) bytes of each stage; binning + sort counted with ONE read + write of
+    the 12-byte key/value pairs (the reference's radix sort makes ~6)."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {"preprocess_fwd": P * (44 + 12 * M) + P * 75,
+            "binning_sort": P * 24 + R * 12 * 3 + R * 8 + T * 8,   # stages scan + emit + tile_sort together
+            "blend_fwd": 40 * R + 20 * H * W + 8 * T,
+            "blend_bwd": 76 * R + 20 * H * W + 8 * T,
+            "preprocess_bwd": P * (111 + 12 * M) + P * (64 + 12 * M)}
+
+
+def cpu_baseline(scene, budget_s: float = 20.0):
+    """Oracle forward+backward on the host: a quick sweep over thread counts picks the best; one thread beside it."""
     from oracle import oracle
     c = scene.camera
     H, W = c.image_height, c.image_width
@@ -54,14 +73,179 @@ def cpu_baseline(scene, n_frames: int):
     kw = dict(bg=scene.bg, means3D=scene.means3D, opacities=scene.opacities, viewmatrix=c.world_view_transform,
               projmatrix=c.full_proj_transform, campos=c.camera_center, tanfovx=c.tanfovx, tanfovy=c.tanfovy, H=H,
               W=W, shs=scene.shs, sh_degree=scene.sh_degree, scales=scene.scales, rotations=scene.rotations)
-    f = oracle.forward(**kw)  # warm-up (page-in, thread pool)
-    oracle.backward(f, dpix)
-    t0 = time.perf_counter()
-    for _ in range(n_frames):
-        f = oracle.forward(**kw)
-        oracle.backward(f, dpix)
-    dt = time.perf_counter() - t0
-    return n_frames / dt, oracle.num_threads(), f"{n_frames} frames fwd+bwd of the same workload ({dt:.1f} s)"
+
+    def run(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            oracle.backward(oracle.forward(**kw), dpix)
+        return time.perf_counter() - t0
+
+    ncpu = oracle.num_threads()
+    run(1)  # page-in, thread pool
+    sweep = {}
+    for t in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        oracle.set_num_threads(t)
+        run(1)
+        sweep[t] = run(2) / 2
+    best = min(sweep, key=sweep.get)
+    oracle.set_num_threads(best)
+    n = int(max(4, min(64, (budget_s * 0.5) / sweep[best])))
+    dt = run(n)
+    oracle.set_num_threads(1)
+    n1 = int(max(1, min(8, (budget_s * 0.3) / max(run(1), 1e-3))))
+    dt1 = run(n1)
+    oracle.set_num_threads(ncpu)
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"{n} frames fwd+bwd of the same workload at {best} threads ({dt:.1f} s); thread sweep "
+                      + ", ".join(f"{k}: {1 / v:.2f}" for k, v in sorted(sweep.items())) + " frames/s",
+            "value_1thread": round(n1 / dt1, 3), "host_threads": ncpu}
+
+
+# ---------------------------------------------------------------- engines: what a "frame" is
+class HipEngine:
+    """The product path: FlatGaussians + render() + autograd backward on one MI355X, replayed as a HIP graph."""
+
+    def __init__(self, args, rank, world, local):
+        from fateavatar_amd import rasterizer, scenes
+        from fateavatar_amd.model import FlatGaussians, TorchCamera
+        from fateavatar_amd.render import render
+        self.rasterizer, self.local, self.args = rasterizer, local, args
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        # replicated Gaussians (same seed on every rank), one view per rank
+        self.scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1))
+        s = self.scene
+        self.pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, s.sh_degree, self.dev,
+                                fused_activations=args.fused_activations)
+        self.cam = TorchCamera(s.camera, self.dev)
+        self.bg = torch.from_numpy(s.bg).to(self.dev)
+        H = W = args.res
+        # upstream gradient of the image: d(L1-mean against a fixed random target)/d(pixel) has magnitude 1/(3HW) and
+        # a random sign (SURVEY.md §8d config 2); it is fixed, so the step is exactly render + backward
+        g = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)) < 0.5).float() * 2 - 1)
+        self.dL_dpix = (g / (3 * H * W)).to(self.dev)
+        self._render = render
+        self.graph = None
+
+    def frame(self):
+        self.pc.begin_step()                       # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        out = self._render(self.cam, self.pc, self.bg)             # activations + HIP rasterizer forward
+        torch.autograd.backward(out["render"], grad_tensors=self.dL_dpix)  # HIP rasterizer backward (+ activations)
+
+    def prepare(self):
+        """Eager warm-up (sizes the binning capacity, fills the allocator pools), then capture ONE frame."""
+        for _ in range(max(3, self.args.warmup // 2)):
+            self.frame()
+        torch.cuda.synchronize()
+        if self.args.graph:
+            # the per-frame work is launch-bound on the host (~40 small launches): capture one frame and replay it; the
+            # rasterizer runs in no-wait mode inside the capture (no host synchronisation at all); overflow of the
+            # binning capacity is checked after the timed region
+            with self.rasterizer.no_wait():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        self.frame()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.frame()
+            torch.cuda.synchronize()
+
+    def enqueue_frame(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.frame()
+
+    def flat_grad(self):
+        return self.pc.collect_grads()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def finish(self):
+        """After the timed region: overflow check of the captured frames, per-kernel durations, counts."""
+        from fateavatar_amd import _lib
+        if self.graph is not None and self.rasterizer.check_async_overflow(self.local):
+            c = self.rasterizer.last_counts[self.local]
+            raise SystemExit(f"binning capacity overflowed inside the captured graph (instances {c.num_instances}, "
+                             f"num_rendered {c.num_rendered}, max list {c.max_tile_list}); rerun (capacity hint was raised)")
+        # HIP events around every stage launch, on the launch stream, over eager frames (event records inside a
+        # replayed graph cannot be read back)
+        _lib.profile_enable(self.local, True)
+        for _ in range(min(self.args.steps, 50)):
+            self.frame()
+        torch.cuda.synchronize()
+        prof = _lib.profile_read(self.local)
+        _lib.profile_enable(self.local, False)
+        c = self.rasterizer.last_counts[self.local]
+        return prof, dict(num_rendered=int(c.num_rendered), num_instances=int(c.num_instances), max_tile_list=int(c.max_tile_list))
+
+
+class StubEngine:
+    """FR_BENCH_STUB=1: a deterministic gradient per (rank, step) on the CPU instead of the rasterizer, so that the
+    launch / exchange / timing control flow of this file runs without a GPU.  Not a measurement."""
+
+    def __init__(self, args, rank, world, local):
+        self.dev = torch.device("cpu")
+        self.rank, self.k = rank, 0
+        self.grad = torch.zeros(1 << 12)
+        self.scene = None
+
+    def prepare(self):
+        pass
+
+    def enqueue_frame(self):
+        self.grad.copy_(torch.arange(self.grad.numel(), dtype=torch.float32) * 1e-3 + (self.rank + 1) * (self.k + 1))
+        self.k += 1
+
+    def flat_grad(self):
+        return self.grad
+
+    def sync(self):
+        pass
+
+    def finish(self):
+        return {}, dict(num_rendered=1000 + self.rank, num_instances=0, max_tile_list=0)
+
+
+class GradExchange:
+    """All-reduce(AVG) of the flat gradient of every step, overlapped with the following frame: the gradient is copied
+    (on the compute stream, behind the backward) into one of two exchange buffers and reduced there asynchronously;
+    a buffer is reused two steps later, after waiting for its collective."""
+
+    def __init__(self, like: torch.Tensor):
+        self.bufs = [torch.empty_like(like), torch.empty_like(like)]
+        self.works = [None, None]
+        self.k = 0
+
+    def submit(self, flat_grad: torch.Tensor):
+        from fateavatar_amd import dp
+        i = self.k & 1
+        if self.works[i] is not None:
+            self.works[i].wait()
+        self.bufs[i].copy_(flat_grad, non_blocking=True)
+        self.works[i] = dp.allreduce_mean_async(self.bufs[i])
+        self.k += 1
+
+    def drain(self):
+        for i in (0, 1):
+            if self.works[i] is not None:
+                self.works[i].wait()
+                self.works[i] = None
+
+    def latest(self) -> torch.Tensor:
+        return self.bufs[(self.k - 1) & 1]
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -72,157 +256,153 @@ def main():
     ap.add_argument("--P", type=int, default=100_000)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
+                    help="N > 1: wait for every all-reduce before the next frame starts")
     ap.add_argument("--fused-activations", dest="fused_activations", action="store_true", default=True,
                     help="sigmoid/exp/normalize inside the HIP kernels (SURVEY.md §8f row 1)")
     ap.add_argument("--torch-activations", dest="fused_activations", action="store_false",
                     help="reference behaviour: activations as stock PyTorch ops")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher (one rank per GPU of this node)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    from fateavatar_amd import dp
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not STUB and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
-    # replicated Gaussians (same seed on every rank), one view per rank
-    scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1))
-    pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree, dev,
-                       fused_activations=args.fused_activations)
-    cam = TorchCamera(scene.camera, dev)
-    bg = torch.from_numpy(scene.bg).to(dev)
-    H = W = args.res
-    # upstream gradient of the image: d(L1-mean against a fixed random target)/d(pixel) has magnitude 1/(3HW) and
-    # a random sign; it is fixed, so the step is exactly render + backward
-    dL_dpix = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)) < 0.5).float() * 2 - 1)
-    dL_dpix = (dL_dpix / (3 * H * W)).to(dev)
-
-    def frame():
-        pc.begin_step()                       # grads set to None: backward assigns (zero_grad(set_to_none=True))
-        out = render(cam, pc, bg)             # activations + HIP rasterizer forward
-        torch.autograd.backward(out["render"], grad_tensors=dL_dpix)  # HIP rasterizer backward + activation backward
-
-    def eager_step():
-        frame()
-        if world > 1:
-            dp.allreduce_mean_(pc.collect_grads())
-
-    # eager warm-up: sizes the binning capacity (high-water mark) and fills the allocator pools
-    for _ in range(max(3, args.warmup // 2)):
-        eager_step()
-    torch.cuda.synchronize()
-    counts = rasterizer.last_counts[local]
-
-    graph = None
-    if args.graph:
-        # The per-frame work is launch-bound on the host (~40 small launches): capture ONE frame (activations,
-        # rasterizer forward, loss, backward) into a HIP graph and replay it.  The rasterizer runs in no-wait
-        # mode inside the graph (no host synchronisation at all); overflow of the binning capacity is checked
-        # after the timed region.
-        rasterizer.set_no_wait(True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                frame()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            frame()
-        torch.cuda.synchronize()
+    eng = (StubEngine if STUB else HipEngine)(args, rank, world, local)
+    eng.prepare()
+    xchg = GradExchange(eng.flat_grad()) if world > 1 else None
 
     def step():
-        if graph is not None:
-            graph.replay()
-            if world > 1:
-                dp.allreduce_mean_(pc.collect_grads())
-        else:
-            eager_step()
+        eng.enqueue_frame()
+        if xchg is not None:
+            xchg.submit(eng.flat_grad())
+            if not args.overlap:
+                xchg.drain()
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    if xchg is not None:
+        xchg.drain()
+    eng.sync()
     dp.barrier()
-    torch.cuda.synchronize()
+    eng.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    if xchg is not None:
+        xchg.drain()          # the last collectives are inside the clock
+    eng.sync()
     dp.barrier()
     elapsed = time.perf_counter() - t0
-    if graph is not None:
-        if rasterizer.check_async_overflow(local):
-            c = rasterizer.last_counts[local]
-            raise SystemExit(f"rank {rank}: binning capacity overflowed inside the captured graph "
-                             f"(instances {c.num_instances}, num_rendered {c.num_rendered}, max list {c.max_tile_list}); "
-                             "rerun (capacity hint was raised)")
-        rasterizer.set_no_wait(False)
-    # per-kernel durations: HIP events around every stage launch, on the launch stream, over eager replays of
-    # the same frame right after the timed region (event records inside a replayed graph cannot be read back)
-    _lib.profile_enable(local, True)
-    for _ in range(min(args.steps, 50)):
-        eager_step()
-    torch.cuda.synchronize()
-    prof = _lib.profile_read(local)
-    _lib.profile_enable(local, False)
-    counts = rasterizer.last_counts[local]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    prof, counts = eng.finish()
+
+    # ---- data-parallel record: who took part, what was exchanged, how long one exchange takes on its own
+    dpinfo = None
+    if world > 1:
+        import torch.distributed as dist
+        reduced = xchg.latest().clone()
+        buf = torch.empty_like(reduced)
+        for _ in range(3):
+            dp.allreduce_mean_async(buf).wait()
+        eng.sync()
+        dp.barrier()
+        t1 = time.perf_counter()
+        n_ar = 20
+        for _ in range(n_ar):
+            dp.allreduce_mean_async(buf).wait()
+        eng.sync()
+        ar_s = (time.perf_counter() - t1) / n_ar
+        mine = torch.tensor([counts["num_rendered"]], dtype=torch.int64, device=eng.dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        payload = reduced.numel() * reduced.element_size()
+        rccl = None
+        if dist.get_backend() == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+        dpinfo = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+                  "num_rendered_per_rank": [int(t.item()) for t in allr], "allreduce_payload_bytes": payload,
+                  "allreduce_us": round(ar_s * 1e6, 1),
+                  "allreduce_busbw_GBps": round(2 * (world - 1) / world * payload / ar_s / 1e9, 1),
+                  "overlap": bool(args.overlap),
+                  "grad_checksum": float(reduced.double().abs().sum().item())}
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
 
     if rank == 0:
         fps = world * args.steps / elapsed
-        R = int(counts.num_rendered)
-        T16 = ((W + 15) // 16) * ((H + 15) // 16)
-        bytes_bwd = 76 * R + 20 * H * W + 8 * T16
-        ms, n = prof["blend_bwd"]
-        roof = None
-        if n:
-            avg_s = ms / n * 1e-3
-            ach = bytes_bwd / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_blend_bwd_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("P") == args.P and tj.get("res") == args.res:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": "k_blend_bwd", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "algorithmic_bytes": bytes_bwd, "avg_launch_us": round(avg_s * 1e6, 2), "launches": n}
-        stages = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}
+        H = W = args.res
+        M = (args.sh_degree + 1) ** 2
+        R = counts["num_rendered"]
+        roof = stage_frac = stages = None
+        if prof:
+            sb = stage_bytes(args.P, M, R, H, W)
+            stages = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}
+            us = dict(stages)
+            us["binning_sort"] = sum(us.get(k, 0.0) for k in ("scan", "emit", "tile_sort"))
+            stage_frac = {k: round(sb[k] / (us[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) for k in sb if us.get(k)}
+            ms, n = prof["blend_bwd"]
+            if n:
+                avg_s = ms / n * 1e-3
+                ach = sb["blend_bwd"] / avg_s / 1e9
+                traffic = valu = src = None
+                cpath = os.path.join(ROOT, "profiles", "blend_bwd_counters.json")
+                if os.path.exists(cpath):   # written by tools/pmc.sh + tools/pmcstats.py from rocprofv3 --pmc passes
+                    try:
+                        cj = json.load(open(cpath))
+                        if cj.get("P") == args.P and cj.get("res") == args.res:
+                            traffic, src = cj.get("hbm_bytes_per_launch"), "profiles/blend_bwd_counters.json (" + str(cj.get("collected")) + ")"
+                            if cj.get("sq_insts_valu_per_launch"):
+                                # wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
+                                valu = round(cj["sq_insts_valu_per_launch"] * 4 / (1024 * 2.4e9 * avg_s), 4)
+                    except Exception:
+                        pass
+                roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
+                        "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
+                        "avg_launch_us": round(avg_s * 1e6, 2), "launches": n}
         cpu = None
-        if args.cpu_frames > 0 and world == 1:
-            v, cores, sample = cpu_baseline(scene, args.cpu_frames)
-            cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+        if args.cpu_seconds > 0 and world == 1 and eng.scene is not None:
+            cpu = cpu_baseline(eng.scene, args.cpu_seconds)
         cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) else
                     "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024)
                     else "custom size (not the metric's configuration)")
         line = {
             "metric": "render+backward frames/sec at 512^2, 100k Gaussians", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "stub" if STUB else "synthetic",
             "config": {"workload": f"{cfg_name}: {args.P} Gaussians on the head template, "
-                                   f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={(args.sh_degree + 1) ** 2}), "
+                                   f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={M}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
                        "frames_per_step_per_gpu": 1,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
-                       "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce)",
-                       "num_rendered": R, "tile_instances_8x8": int(counts.num_instances),
-                       "max_tile_list": int(counts.max_tile_list)},
-            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages,
+                       "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce"
+                                      + (", overlapped with the next frame)" if world > 1 and args.overlap else ")"),
+                       "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
+                       "max_tile_list": counts["max_tile_list"]},
+            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():

@@ -76,6 +76,34 @@ def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
     return flat_grad
 
 
+class PendingReduce:
+    """Handle of an asynchronous all-reduce(mean).  `wait()` orders the CURRENT stream behind the collective (RCCL: no
+    host block; gloo: blocks) and applies the division when the backend cannot average inside the collective."""
+
+    def __init__(self, work, tensor: torch.Tensor, divide_by: int):
+        self.work, self.tensor, self.divide_by = work, tensor, divide_by
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.divide_by:
+                self.tensor.div_(self.divide_by)
+        return self.tensor
+
+
+def allreduce_mean_async(flat_grad: torch.Tensor) -> PendingReduce:
+    """Start the batch-mean all-reduce of a flat gradient buffer and return at once.  RCCL runs it on its own
+    stream, ordered behind the work already enqueued on the current stream, so kernels launched afterwards (the next
+    frame) overlap the exchange; nothing may touch `flat_grad` until `wait()`."""
+    w = world_size()
+    if w == 1:
+        return PendingReduce(None, flat_grad, 0)
+    if _collective_avg_ok(flat_grad):
+        return PendingReduce(dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, async_op=True), flat_grad, 0)
+    return PendingReduce(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True), flat_grad, w)
+
+
 def allreduce_sum_(stats: torch.Tensor) -> torch.Tensor:
     """In-place sum of per-view statistics (densification accumulators) across ranks."""
     if world_size() > 1:

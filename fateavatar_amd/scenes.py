@@ -2,7 +2,7 @@
 
 Host-side numpy only.  Nothing here reads /root/reference at run time: the head
 template geometry used by BASELINE.json configs 2/5 travels as the fixture
-tests/golden/head_template_geom.npz (written by tests/golden/make_golden.py).
+fateavatar_amd/data/head_template_geom.npz (package data, written by tests/golden/make_golden.py).
 
 `make_camera` mirrors what the caller of the path hands to the rasterizer
 (reference volume_rendering/camera_3dgs.py:53-72 and
@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEAD_GEOM = os.path.join(_REPO, "tests", "golden", "head_template_geom.npz")
+HEAD_GEOM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "head_template_geom.npz")
 
 
 @dataclass

@@ -14,7 +14,7 @@ its rasterizer is CUDA and cannot be built in this image):
                      world_view_transform / projection / full_proj_transform / camera_center
   golden_misc.npz    tools/gs_utils/general_utils.py:18-19 inverse_sigmoid
   golden_binding.npz volume_rendering/mesh_compute.py:27-59 compute_face_orientation (+ scale) / compute_face_normals
-  head_template_geom.npz  vertices + triangle indices of weights/head_template_mouth_close.obj
+  ../../fateavatar_amd/data/head_template_geom.npz  vertices + triangle indices of weights/head_template_mouth_close.obj
                      (input geometry of BASELINE.json configs 2 and 5; data, not code)
 """
 import math
@@ -120,7 +120,7 @@ def gen_head():
                 verts.append([float(t) for t in line.split()[1:4]])
             elif line.startswith("f "):
                 faces.append([int(t.split("/")[0]) - 1 for t in line.split()[1:4]])
-    np.savez_compressed(os.path.join(OUT, "head_template_geom.npz"), verts=np.asarray(verts, np.float32),
+    np.savez_compressed(os.path.join(OUT, "..", "..", "fateavatar_amd", "data", "head_template_geom.npz"), verts=np.asarray(verts, np.float32),
                         faces=np.asarray(faces, np.int32))
 
 

@@ -1,0 +1,55 @@
+"""bench.py's N > 1 control flow without GPUs: `python bench.py --gpus 2` must launch its own ranks, exchange the
+gradient of every step with the overlapped double-buffered all-reduce, and print ONE JSON line from rank 0.
+FR_BENCH_STUB=1 swaps the rasterizer for a deterministic CPU gradient (rank- and step-dependent), FR_DIST_BACKEND=gloo
+the collective backend; the launch, exchange, barrier and timing code is the code the GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = dict(os.environ, FR_BENCH_STUB="1", FR_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_bench_spawns_two_ranks_and_averages_every_step(overlap):
+    steps, warm = 7, 3
+    j = _run(["--gpus", "2", "--steps", str(steps), "--warmup", str(warm)] + ([] if overlap else ["--no-overlap"]))
+    assert j["n_gpus"] == 2 and j["data"] == "stub" and j["steps"] == steps and j["scaling"] == "weak"
+    d = j["dp"]
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["overlap"] is overlap
+    assert d["num_rendered_per_rank"] == [1000, 1001]
+    assert d["allreduce_payload_bytes"] == 4 * 4096 and d["allreduce_us"] > 0
+    # the stub gradient of (rank r, frame k) is i * 1e-3 + (r + 1) * (k + 1); the mean over the two ranks of the LAST
+    # frame (k = warm + steps - 1) must be what the exchange buffer holds
+    k = warm + steps - 1
+    want = sum(i * 1e-3 + 1.5 * (k + 1) for i in range(4096))
+    assert abs(d["grad_checksum"] - want) <= 1e-4 * want, (d["grad_checksum"], want)
+    assert j["value"] > 0 and abs(j["value"] - 2 * steps / (j["ms_per_step"] * steps * 1e-3)) <= 0.02 * j["value"]
+
+
+def test_bench_single_rank_stub_line_is_well_formed():
+    j = _run(["--steps", "3", "--warmup", "1", "--cpu-seconds", "0"])
+    assert j["n_gpus"] == 1 and j["dp"] is None and j["data"] == "stub"
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "config",
+              "roofline", "cpu_baseline", "stage_us", "stage_frac"):
+        assert k in j
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, FR_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
