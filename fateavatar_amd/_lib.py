@@ -96,7 +96,8 @@ def lib():
     # HIP runtime instance (two runtimes in one process cannot share streams or device pointers).
     import torch  # noqa: F401
 
-    L = C.CDLL(SO_PATH)
+    # RTLD_GLOBAL: the compiled `_C` extension (fateavatar_amd/torch_ext.py) links against this library by name
+    L = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
     L.fr_create.argtypes = [C.POINTER(C.c_void_p)]
     L.fr_create.restype = C.c_int
     L.fr_destroy.argtypes = [C.c_void_p]
