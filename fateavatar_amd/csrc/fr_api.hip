@@ -85,6 +85,10 @@ int fr_create(fr_handle** out)
     FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
     const char* fb = getenv("FR_FUSED_BLEND");  // experimental one-launch k_unit_blend_fused (measured: no gain yet)
     h->no_fused_blend = !(fb && fb[0] == '1');
+    const char* bf = getenv("FR_BLEND_FWD");
+    h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
+    const char* bb = getenv("FR_BLEND_BWD");
+    h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
     *out = reinterpret_cast<fr_handle*>(h);
     return FR_OK;
 }

@@ -7,11 +7,12 @@
 // order; both blend kernels walk that array with wave-uniform addresses, so the record
 // fetches are scalar loads (SMEM -> SGPRs) and the VALU only does per-pixel math.
 #include "fr_common.hpp"
+#include <cstdlib>
 
 namespace fr {
 
 // 48-byte record = 3 x float4:
-//   q0 = (x, y, conic_a, conic_b)   q1 = (conic_c, opacity, r, g)   q2 = (b, id_bits, 0, 0)
+//   q0 = (x, y, conic_a', conic_b')   q1 = (conic_c', opacity, r, g)   q2 = (b, id_bits, footprint mask lo, hi)
 constexpr int kRecQuads = 3;
 
 typedef unsigned long long u64;
@@ -140,7 +141,52 @@ __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
     if constexpr (K >= 16) big_stage<K, 1024>(v, lane);
 }
 
-__device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g)
+// Which of the 64 pixels of tile (tile_x0, tile_y0) can pass the blend's alpha >= 1/255 test for this splat: a
+// conservative SUPERSET (bit 8*row + column), one x-interval per pixel row from the roots of
+//   a' dx^2 + (b' dy) dx + c' dy^2 >= -log2(255 opacity) - slack       (pre-scaled conic: the left side is log2 G).
+// The blend kernels walk only these pairs and apply the exact tests to each, so a bit too many costs one wasted
+// evaluation and a missing bit would change the image: the slack covers the fp32 evaluation error of log2 G in the
+// blend loops, and anything not plainly an ellipse (a' >= 0, NaN) selects the whole row.
+__device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, float b2, float c2, float opacity,
+                                                float tile_x0, float tile_y0)
+{
+    const float L = __builtin_amdgcn_logf(255.0f * opacity);   // v_log_f32 = log2; alpha >= 1/255 <=> log2 G >= -L
+    // |terms| of log2 G near the footprint edge are O(L + 1); ill-conditioned conics cancel larger terms
+    const float far_x = fmaxf(fabsf(x0 - tile_x0), fabsf(x0 - (tile_x0 + 7.f)));
+    const float far_y = fmaxf(fabsf(y0 - tile_y0), fabsf(y0 - (tile_y0 + 7.f)));
+    const float mag = fabsf(a2) * far_x * far_x + fabsf(c2) * far_y * far_y + fabsf(b2) * far_x * far_y;
+    const float thr = -L - (2e-3f + 4e-6f * mag);
+    const bool ellipse = a2 < 0.f;
+    const float inv2a = __builtin_amdgcn_rcpf(2.f * a2);
+    uint32_t m[2] = {0u, 0u};
+#pragma unroll
+    for (int r = 0; r < kTile; r++) {
+        const float dy = y0 - (tile_y0 + (float)r);
+        const float bb = b2 * dy;
+        const float cc = c2 * dy * dy - thr;
+        const float disc = bb * bb - 4.f * a2 * cc;
+        uint32_t row = 0xFFu;
+        if (ellipse) {
+            if (disc >= 0.f) {
+                const float sq = __builtin_sqrtf(disc);
+                // a' < 0: inv2a < 0, so (-bb + sq) * inv2a is the SMALLER root of dx = x0 - px
+                const float dx_lo = (-bb + sq) * inv2a, dx_hi = (-bb - sq) * inv2a;
+                const float lo = ceilf((x0 - dx_hi) - tile_x0 - 1e-3f), hi = floorf((x0 - dx_lo) - tile_x0 + 1e-3f);
+                if (lo == lo && hi == hi) {   // not NaN
+                    const int il = (int)fminf(fmaxf(lo, 0.f), 8.f), ih = (int)fminf(fmaxf(hi, -1.f), 7.f);
+                    row = il <= ih ? ((2u << ih) - 1u) & ~((1u << il) - 1u) : 0u;
+                }
+            } else if (disc < 0.f) {
+                row = 0u;
+            }
+        }
+        m[r >> 2] |= row << (8 * (r & 3));
+    }
+    return make_uint2(m[0], m[1]);
+}
+
+__device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g, float tile_x0,
+                                             float tile_y0)
 {
     const float2 xy = g.means2D[id];
     const float4 co = g.conic_opacity[id];
@@ -149,9 +195,11 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
     // the conic is stored pre-scaled so that the blend loops get log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into
     // v_exp_f32 (two multiplies less per pixel x Gaussian pair): a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
     constexpr float kLog2e = 1.4426950408889634f;
-    r[0] = make_float4(xy.x, xy.y, co.x * (-0.5f * kLog2e), co.y * (-kLog2e));
-    r[1] = make_float4(co.z * (-0.5f * kLog2e), co.w, c.x, c.y);
-    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);
+    const float a2 = co.x * (-0.5f * kLog2e), b2 = co.y * (-kLog2e), c2 = co.z * (-0.5f * kLog2e);
+    const uint2 fm = footprint_mask(xy.x, xy.y, a2, b2, c2, co.w, tile_x0, tile_y0);
+    r[0] = make_float4(xy.x, xy.y, a2, b2);
+    r[1] = make_float4(c2, co.w, c.x, c.y);
+    r[2] = make_float4(c.z, __uint_as_float(id), __uint_as_float(fm.x), __uint_as_float(fm.y));
 }
 
 // Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
@@ -159,7 +207,7 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
 // written): one memory round trip per four slots instead of one per slot.
 template <int K>
 __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint32_t n, uint32_t base, const u64 (&v)[K],
-                                              int lane, const GeomView& g)
+                                              int lane, const GeomView& g, float tile_x0, float tile_y0)
 {
     constexpr int B = K < 4 ? K : 4;
     constexpr float kLog2e = 1.4426950408889634f;
@@ -181,9 +229,11 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
             const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
             if (i < n) {
                 float4* r = recs + (size_t)(start + i) * kRecQuads;
-                r[0] = make_float4(xy[u].x, xy[u].y, co[u].x * (-0.5f * kLog2e), co[u].y * (-kLog2e));
-                r[1] = make_float4(co[u].z * (-0.5f * kLog2e), co[u].w, c[u].x, c[u].y);
-                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), 0.f, 0.f);
+                const float a2 = co[u].x * (-0.5f * kLog2e), b2 = co[u].y * (-kLog2e), c2 = co[u].z * (-0.5f * kLog2e);
+                const uint2 fm = footprint_mask(xy[u].x, xy[u].y, a2, b2, c2, co[u].w, tile_x0, tile_y0);
+                r[0] = make_float4(xy[u].x, xy[u].y, a2, b2);
+                r[1] = make_float4(c2, co[u].w, c[u].x, c[u].y);
+                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), __uint_as_float(fm.x), __uint_as_float(fm.y));
             }
         }
     }
@@ -191,7 +241,7 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
 
 template <int K>
 __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, uint32_t start, uint32_t n, int lane,
-                                               const GeomView& g)
+                                               const GeomView& g, float tile_x0, float tile_y0)
 {
     u64 v[K];
 #pragma unroll
@@ -200,7 +250,7 @@ __device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, ui
         v[r] = i < n ? keys[start + i] : ~0ull;
     }
     wave_sort<K>(v, lane);
-    write_records<K>(recs, start, n, 0u, v, lane, g);
+    write_records<K>(recs, start, n, 0u, v, lane, g, tile_x0, tile_y0);
 }
 
 // Four waves sort up to 4 * 64 * K keys together (K = 4: 1024, K = 16: 4096): each wave sorts its 64*K keys in
@@ -229,7 +279,7 @@ __device__ __forceinline__ void cross_wave_stage(u64 (&v)[K], SortXchg& sx, int 
 
 template <int K>
 __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
-                                const GeomView& g, SortXchg& sx)
+                                const GeomView& g, SortXchg& sx, float tile_x0, float tile_y0)
 {
     constexpr int KW = 64 * K;  // keys per wave
     u64 v[K];
@@ -248,7 +298,7 @@ __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, u
     cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
     reg_cleaners_from<K, K / 2>(v);
     lane_cleaners_from_32<K>(v, lane);
-    write_records<K>(recs, start, n, (uint32_t)(wave * KW), v, lane, g);
+    write_records<K>(recs, start, n, (uint32_t)(wave * KW), v, lane, g, tile_x0, tile_y0);
 }
 
 #undef SortXchg
@@ -256,7 +306,8 @@ __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, u
 // in global memory by one 256-thread workgroup (virtual +inf padding: a compare-exchange whose
 // upper index is >= n is a no-op in the flip formulation).  Agent-scope accesses keep the data
 // out of the per-CU L1 so that waves of the workgroup see each other's stores.
-__device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g)
+__device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g, float tile_x0,
+                                 float tile_y0)
 {
     u64* seg = keys + start;
     uint32_t N = 1;
@@ -282,7 +333,7 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
     }
     for (uint32_t i = tid; i < n; i += nt) {
         const u64 kv = __hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        write_record(recs, start + i, (uint32_t)kv, g);
+        write_record(recs, start + i, (uint32_t)kv, g, tile_x0, tile_y0);
     }
 }
 
@@ -307,7 +358,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
         const uint32_t nm = v.counts->medium_tiles;
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group<4>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
+            sort_tile_group<4>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+                               (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
         }
         return;
     }
@@ -333,9 +385,10 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             if (unit_tseg)
                 for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
-                if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g);
-                else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g);
-                else sort_tile_regs<4>(keys, recs, start, n, lane, g);
+                const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
+                if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g, tx0, ty0);
+                else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g, tx0, ty0);
+                else sort_tile_regs<4>(keys, recs, start, n, lane, g, tx0, ty0);
             }
         }
     }
@@ -355,11 +408,13 @@ __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, f
     const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
     for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
         const uint32_t tile = v.big_list[item];
-        sort_tile_group<16>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx);
+        sort_tile_group<16>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+                            (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
     for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
         const uint32_t tile = v.large_list[item];
-        sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g);
+        sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+                         (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
 }
 
@@ -849,6 +904,441 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
     }
 }
 
+// ================================================================== sparse blend backward
+// Only ~1 in 7 (pixel, record) pairs of an 8x8 tile passes the alpha test at BASELINE config 2 (splats a few pixels
+// wide); k_unit_blend_bwd above still evaluates all 64 x 64 of a unit and reduces 36 mostly-zero values across the
+// wave for every four records.  This kernel only touches the pairs the records' footprint masks name
+// (footprint_mask(), a superset of the pairs that pass; the exact tests are applied to each), in two phases per unit:
+//   A  lane = PIXEL: walks the records whose mask holds the pixel, back to front (the reference's order), carrying
+//      T and accum_rec . dL_dpixel in registers, and leaves (q = dL_dG G, w = alpha T) of every pair in LDS;
+//   B  lane = RECORD: walks the pixels of its own mask, picks the pairs up and sums its nine gradient moments in
+//      registers — no cross-lane reduction at all;
+// then the 64 x 9 sums are re-laid through LDS so that the lanes of one global_atomic_add_f32 cover 7 records x 9
+// components (lanes of an instruction that fall into the same 64-byte line merge into one L2 request).
+// The pixel-major view of the masks (which records does pixel p touch) is the 64 x 64 bit-matrix transpose of the
+// record-major one, done in registers: v_permlane32_swap for the 32 x 32 blocks, rotate + v_bfi for the rest.
+// LDS per wave decides how many units are in flight per CU (the kernel is latency-bound: a unit is a chain of
+// dependent LDS round trips): 9.25 KB -> 16 waves per CU, enough for every unit of BASELINE config 2 to be resident.
+constexpr int kPairCap = 640;    // (q, w) slots per wave; denser units are processed in several record ranges
+
+struct SparseLds {
+    float4 rec[kBatch * kRecQuads];   // the unit's records (q2.zw = footprint mask)                          3 KB
+    float4 pix[64];                   // per pixel: dL_dpixel (r, g, b, -)                                     1 KB
+    float2 pair[kPairCap];            // (q, w) of every pair, RECORD-major: a record's pairs are consecutive  5 KB
+    uint32_t sbase[64];               // first pair slot of every record                                    0.25 KB
+};
+
+// maximum over the 64 lanes, in every lane's SGPR-able form (result is wave-uniform)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+#define FR_DPP_MAX(CTRL) x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, (CTRL), 0xF, 0xF, false))
+    FR_DPP_MAX(0xB1);   // quad_perm [1,0,3,2]
+    FR_DPP_MAX(0x4E);   // quad_perm [2,3,0,1]
+    FR_DPP_MAX(0x141);  // row_half_mirror
+    FR_DPP_MAX(0x140);  // row_mirror
+#undef FR_DPP_MAX
+    // every lane now holds its 16-lane row's maximum
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t s) { return __builtin_amdgcn_alignbit(x, x, s); }
+
+struct TransposeConsts {
+    uint32_t rot[5], sel[5];  // per level k = 16, 8, 4, 2, 1
+};
+__device__ __forceinline__ TransposeConsts transpose_consts(int lane)
+{
+    TransposeConsts c;
+    const uint32_t keep_low[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint32_t k = 16u >> i;
+        const bool upper = ((uint32_t)lane & k) == 0;
+        c.rot[i] = upper ? 32u - k : k;             // upper block rows take the partner's bits shifted UP by k
+        c.sel[i] = upper ? ~keep_low[i] : keep_low[i];
+    }
+    return c;
+}
+// lane j holds row j (64 bits) of a 64 x 64 bit matrix; on return lane p holds column p
+__device__ __forceinline__ uint2 transpose_bits64(uint2 row, int lane, const TransposeConsts& c)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(row.x, row.y, false, false);   // [lo.low | hi.low], [lo.high | hi.high]
+    uint32_t lo = (uint32_t)r[0], hi = (uint32_t)r[1];
+#define FR_TR_LEVEL(I, K)                                                            \
+    {                                                                                \
+        const uint32_t ylo = (uint32_t)lane_xor_i32<K>((int)lo, lane), yhi = (uint32_t)lane_xor_i32<K>((int)hi, lane); \
+        lo = (c.sel[I] & rotr32(ylo, c.rot[I])) | (~c.sel[I] & lo);                   \
+        hi = (c.sel[I] & rotr32(yhi, c.rot[I])) | (~c.sel[I] & hi);                   \
+    }
+    FR_TR_LEVEL(0, 16)
+    FR_TR_LEVEL(1, 8)
+    FR_TR_LEVEL(2, 4)
+    FR_TR_LEVEL(3, 2)
+    FR_TR_LEVEL(4, 1)
+#undef FR_TR_LEVEL
+    return make_uint2(lo, hi);
+}
+
+// inclusive prefix sum over the 64 lanes with DPP only (no LDS round trips): shifts inside the 16-lane rows, then the
+// row totals broadcast into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+#define FR_DPP_SHR_ADD(CTRL, ROWS) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (CTRL), (ROWS), 0xF, false)
+    FR_DPP_SHR_ADD(0x111, 0xF);  // row_shr:1
+    FR_DPP_SHR_ADD(0x112, 0xF);  // row_shr:2
+    FR_DPP_SHR_ADD(0x114, 0xF);  // row_shr:4
+    FR_DPP_SHR_ADD(0x118, 0xF);  // row_shr:8
+    FR_DPP_SHR_ADD(0x142, 0xA);  // row_bcast:15
+    FR_DPP_SHR_ADD(0x143, 0xC);  // row_bcast:31
+#undef FR_DPP_SHR_ADD
+    return x;
+}
+
+// ================================================================== sparse forward: two launches per frame
+// k_unit_tseg + k_unit_blend + k_tile_combine above evaluate all 64 x 64 (pixel, record) pairs of a unit, twice, in
+// three launches.  The sparse forward walks only the pairs the records' footprint masks name (see the sparse backward
+// below), and walks them ONCE: compositing is linear in the transmittance entering a unit, so
+//   k_unit_blend_local  every unit, as an independent wave, blends its records LOCALLY (T starts at 1, no termination
+//                       test): partial colour, product of (1 - alpha), last blended record
+//   k_tile_finish       one wave per tile chains the units: T_in of a unit = running transmittance; the local result is
+//                       scaled by it.  Only a pixel whose transmittance crosses the reference's 1e-4 threshold INSIDE a
+//                       unit (T_in >= 1e-4 > T_in * product; at most one unit per pixel) is walked again, from T_in, with
+//                       the reference's termination test.  Then: image, final T, contributor count, and every unit's
+//                       backward entry state.
+// (A one-launch variant, one workgroup per tile with barriers between the phases, was measured too: 30.7 us at config 2,
+// bound by the latency chain of its heaviest tiles; the unit-parallel split below has no such tail.)
+
+struct WalkOut {
+    float Cr, Cg, Cb, T;
+    uint32_t last;
+    bool term;
+};
+
+// Front-to-back blend of the records in `Bg` (bit j = record j of the staged unit) for this lane's pixel, starting at
+// transmittance T0; TERMINATE: apply the reference's T test (forward.cu:346-351).  Two records per iteration: their alpha
+// evaluations are independent instruction streams, only the short T / colour recurrence is serial.
+template <bool TERMINATE>
+__device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec, u64 Bg, float T0, float fx, float fy, uint32_t base)
+{
+    WalkOut o;
+    o.Cr = o.Cg = o.Cb = 0.f;
+    o.T = T0;
+    o.last = 0u;
+    o.term = false;
+    while (__any(Bg != 0ull)) {
+        int j[2];
+        bool act[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            act[k] = Bg != 0ull;
+            j[k] = act[k] ? (int)__builtin_ctzll(Bg) : 0;
+            Bg &= Bg - 1ull;
+        }
+        float alpha[2], cr[2], cg[2], cb[2];
+        bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float4 q0 = rec[j[k] * kRecQuads + 0];
+            const float4 q1 = rec[j[k] * kRecQuads + 1];
+            const float q2x = rec[j[k] * kRecQuads + 2].x;
+            const float dx = q0.x - fx, dy = q0.y - fy;
+            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+            ok[k] = act[k] && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+            cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            bool c = ok[k];
+            const float test_T = o.T * (1.f - alpha[k]);
+            if (TERMINATE) {
+                const bool fin = c && !o.term && (test_T < 0.0001f);
+                o.term = o.term || fin;
+                c = c && !o.term;
+            }
+            const float w = c ? alpha[k] * o.T : 0.f;
+            o.Cr += cr[k] * w;
+            o.Cg += cg[k] * w;
+            o.Cb += cb[k] * w;
+            o.T = c ? test_T : o.T;
+            o.last = c ? (base + (uint32_t)j[k] + 1u) : o.last;
+        }
+        if (TERMINATE) Bg = o.term ? 0ull : Bg;
+    }
+    return o;
+}
+
+// ---- launch 1: every unit is an independent wave (grid-stride), blended locally
+__global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __restrict__ counts,
+                                                         const uint4* __restrict__ unit_tile,
+                                                         const float4* __restrict__ recs, int W, int H, int tiles_x,
+                                                         float* __restrict__ g_tseg, float* __restrict__ g_out)
+{
+    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rec = s_rec_all[wave_in_wg];
+    const TransposeConsts tc = transpose_consts(lane);
+    const uint32_t nu = counts->num_units;
+    const uint32_t wave_stride = gridDim.x * kWavesPerWG;
+    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
+        const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
+        __builtin_amdgcn_wave_barrier();   // the previous unit's records are dead
+        const RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+        rec[lane * kRecQuads + 0] = rr.q0;
+        rec[lane * kRecQuads + 1] = rr.q1;
+        rec[lane * kRecQuads + 2] = rr.q2;
+        const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
+        const WalkOut o = walk_unit_fwd<false>(rec, Bp, 1.0f, (float)ui.px, (float)ui.py, ui.base);
+        g_tseg[(size_t)u * kUnit + lane] = o.T;
+        float* out = g_out + (size_t)u * 5 * kUnit + lane;
+        out[0] = o.Cr;
+        out[kUnit] = o.Cg;
+        out[2 * kUnit] = o.Cb;
+        out[4 * kUnit] = __uint_as_float(o.last);
+    }
+}
+
+// ---- launch 2: one wave per tile chains its units (running transmittance), re-walks a unit for the pixels that
+// terminate inside it, writes the image and the backward entry state of every unit
+__global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                    const float4* __restrict__ recs, const float* __restrict__ g_tseg,
+                                                    float* __restrict__ g_out, float4* __restrict__ unit_state, int W, int H,
+                                                    const float* __restrict__ bg, float* __restrict__ out_color)
+{
+    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
+    if (counts->overflow) return;
+    const uint32_t n_tiles = (uint32_t)v.tiles_x * v.tiles_y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * kWavesPerWG + wave;
+    if (tile >= n_tiles) return;
+    const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
+    const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const uint32_t u0 = v.unit_offset[tile], nu = v.unit_offset[tile + 1] - u0;
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
+    uint32_t ncon = 0;
+    if (nu != 0) {
+        float4* rec = s_rec_all[wave];
+        const uint32_t start = v.tile_offset[tile], n = v.tile_offset[tile + 1] - start;
+        const float4* trecs = recs + (size_t)start * kRecQuads;
+        float Tin = 1.0f;
+        bool finished = false;
+        for (uint32_t k = 0; k < nu; k++) {
+            float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
+            const float tl = g_tseg[(size_t)(u0 + k) * kUnit + lane];
+            float cr = out[0], cg = out[kUnit], cb = out[2 * kUnit];
+            uint32_t last = __float_as_uint(out[4 * kUnit]);
+            // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
+            const bool dead = !inside || finished || (Tin < 0.0001f);
+            const bool crosses = !dead && (Tin * tl < 0.0001f);
+            cr = dead ? 0.f : Tin * cr, cg = dead ? 0.f : Tin * cg, cb = dead ? 0.f : Tin * cb;
+            float To = dead ? Tin : Tin * tl;
+            last = dead ? 0u : last;
+            if (__any(crosses)) {   // (a pixel crosses the threshold in at most one unit)
+                const TransposeConsts tc = transpose_consts(lane);
+                __builtin_amdgcn_wave_barrier();
+                const RecRegs rr = fetch_record(trecs, k * kUnit + (uint32_t)lane, n);
+                rec[lane * kRecQuads + 0] = rr.q0;
+                rec[lane * kRecQuads + 1] = rr.q1;
+                rec[lane * kRecQuads + 2] = rr.q2;
+                const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const u64 Bp = crosses ? (((u64)bt.y << 32) | bt.x) : 0ull;
+                const WalkOut x = walk_unit_fwd<true>(rec, Bp, Tin, (float)px, (float)py, k * kUnit);
+                if (crosses) {
+                    cr = x.Cr, cg = x.Cg, cb = x.Cb, To = x.T, last = x.last;
+                    finished = x.term;
+                }
+            }
+            // the unit's final contribution, kept for the suffix pass below (slot 3 = T at its far boundary)
+            out[0] = cr, out[kUnit] = cg, out[2 * kUnit] = cb, out[3 * kUnit] = To;
+            Cr += cr, Cg += cg, Cb += cb;
+            if (!dead) {
+                Tf = To;
+                if (last) ncon = last;
+            }
+            // what enters the next unit: the PRODUCT of the units' products, as the backward's unit-parallel replay assumes
+            Tin = dead ? Tin : (crosses ? To : Tin * tl);
+        }
+        // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at the
+        // unit's far boundary (= what the reference's accum_rec recurrence yields there); see k_tile_combine for the guard
+        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+        for (uint32_t k = nu; k-- > 0;) {
+            const float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
+            const float To = out[3 * kUnit];
+            const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
+            unit_state[(size_t)(u0 + k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
+            Sr += out[0];
+            Sg += out[kUnit];
+            Sb += out[2 * kUnit];
+        }
+    }
+    if (inside) {
+        v.final_T[pix] = Tf;
+        v.n_contrib[pix] = ncon;
+        out_color[pix] = Cr + Tf * bg[0];
+        out_color[HW + pix] = Cg + Tf * bg[1];
+        out_color[2 * HW + pix] = Cb + Tf * bg[2];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                              void* binning, int W, int H, const float* __restrict__ bg,
+                                                              const float* __restrict__ dL_dpix, float* __restrict__ accum)
+{
+    __shared__ SparseLds s_all[kWavesPerWG];
+    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SparseLds& S = s_all[wave_in_wg];
+    const TransposeConsts tc = transpose_consts(lane);
+    const uint32_t nu = counts->num_units;
+    const uint32_t wave_stride = gridDim.x * kWavesPerWG;
+    const u64 lt_mask = (1ull << lane) - 1ull;          // pixels in front of this lane's pixel in mask order
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    // which (record-in-septet, component) this lane flushes: lanes 0..62 = 7 records x 9 components
+    const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;
+    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
+        const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
+        const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
+        const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
+        // nothing at or behind the deepest contributor of any pixel of the tile can matter
+        if (!__any(last > ui.base)) continue;
+
+        // ---- lane = record: stage the records; this lane keeps what phase B needs of its own
+        const RecRegs rr = fetch_record(b.recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+        // ---- lane = pixel: per-pixel inputs (requested together with the record)
+        const float T_final = ui.inside ? v.final_T[pix] : 0.f;
+        const float4 st = b.unit_state[(size_t)u * kUnit + lane];
+        float dpr = 0.f, dpg = 0.f, dpb = 0.f;
+        if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
+        S.rec[lane * kRecQuads + 0] = rr.q0;
+        S.rec[lane * kRecQuads + 1] = rr.q1;
+        S.rec[lane * kRecQuads + 2] = rr.q2;
+        const uint2 mj = make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w));
+        const u64 Mj = ((u64)mj.y << 32) | mj.x;
+        const uint32_t cnt = (uint32_t)__popcll(Mj);
+        const uint32_t cum = wave_incl_scan_u32(cnt);             // pairs of records [0, lane]
+        S.sbase[lane] = cum - cnt;
+        // record-major masks -> pixel-major walk sets, limited to the records in front of the pixel's last contributor
+        const uint2 bt = transpose_bits64(mj, lane, tc);
+        const int lim = (int)last - (int)ui.base;      // records [0, lim) of this unit can contribute to this pixel
+        u64 Bp = ((u64)bt.y << 32) | bt.x;
+        Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
+
+        const float fx = (float)ui.px, fy = (float)ui.py;
+        const float tfb = -T_final * ((bg0 * dpr + bg1 * dpg) + bg2 * dpb);   // -T_final * (bg . dL_dpixel)
+        float T = lim > 0 ? st.w : 0.f;
+        float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel (see k_unit_blend_bwd)
+        const float tile_x0 = (float)((int)(ui.tile % (uint32_t)v.tiles_x) * kTile);
+        const float tile_y0 = (float)((int)(ui.tile / (uint32_t)v.tiles_x) * kTile);
+        S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
+        const float rxl = rr.q0.x - tile_x0, ryl = rr.q0.y - tile_y0;           // own record centre, tile-local
+
+        // ---- record ranges [lo, hi), from the back, each with at most kPairCap mask bits
+        int hi = (int)ui.m;
+        while (hi > 0) {
+            const uint32_t cum_hi = (uint32_t)__builtin_amdgcn_readlane((int)cum, hi - 1);
+            // smallest lo with pairs[lo, hi) <= kPairCap: lanes are monotone in that predicate
+            const bool fits = (lane < hi) && (cum_hi - (cum - cnt) <= (uint32_t)kPairCap);
+            const int lo = (int)__builtin_ctzll(__ballot(fits));   // hi - 1 always fits (a record has <= 64 bits)
+            const u64 range = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)(cum - cnt), lo);   // first slot of the range
+            const uint32_t npairs = cum_hi - slot0;
+            // pairs no pixel walks (record behind the pixel's last contributor) must read as zero in phase B
+            for (uint32_t z = (uint32_t)lane; z * 2u < npairs; z += 64u)
+                reinterpret_cast<float4*>(S.pair)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- phase A: lane = pixel, back to front over the records its mask column names
+            u64 Bg = Bp & range;
+            const uint32_t nA = wave_max_u32((uint32_t)__popcll(Bg));
+            for (uint32_t it = 0; it < nA; it++) {
+                const bool act = Bg != 0ull;
+                const int j = act ? 63 - (int)__builtin_clzll(Bg) : 0;
+                Bg &= ~(1ull << j);       // (no bits set: stays 0)
+                const float4 q0 = S.rec[j * kRecQuads + 0];
+                const float4 q1 = S.rec[j * kRecQuads + 1];
+                const float4 q2 = S.rec[j * kRecQuads + 2];
+                const uint32_t sb = S.sbase[j];
+                const float dx = q0.x - fx, dy = q0.y - fy;
+                const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+                const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
+                const bool ok = act && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+                const float cd = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;    // colour . dL_dpixel
+                const float ar_e = ok ? araw : 0.f;                         // failed pair: alpha = 0, every update is the identity
+                const float a_e = __builtin_amdgcn_fmed3f(ar_e, 0.f, 0.99f);
+                const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
+                T *= inv;                                                   // backward.cu:503
+                const float e = cd - A;
+                const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
+                A += a_e * e;
+                const uint32_t rank = (uint32_t)__popc(__float_as_uint(q2.z) & (uint32_t)lt_mask) +
+                                      (uint32_t)__popc(__float_as_uint(q2.w) & (uint32_t)(lt_mask >> 32));
+                if (act) S.pair[sb - slot0 + rank] = make_float2(dL_dalpha * ar_e, a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- phase B: lane = record, over its own pixels; its pairs are consecutive slots
+            float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
+            uint32_t slot = (cum - cnt) - slot0;
+            const uint32_t nB = wave_max_u32((uint32_t)__popcll(Mg));
+            for (uint32_t it = 0; it < nB; it++) {
+                const bool act = Mg != 0ull;
+                const int p = act ? (int)__builtin_ctzll(Mg) : 0;
+                Mg &= Mg - 1ull;
+                float2 qw = S.pair[act ? slot : 0u];
+                qw.x = act ? qw.x : 0.f;
+                qw.y = act ? qw.y : 0.f;
+                slot += act ? 1u : 0u;
+                const float4 dp = S.pix[p];
+                const float dx = rxl - (float)(p & 7), dy = ryl - (float)(p >> 3);
+                const float qdx = qw.x * dx, qdy = qw.x * dy;
+                sm[ACC_MX] += qdx;
+                sm[ACC_MY] += qdy;
+                sm[ACC_CA] += qdx * dx;
+                sm[ACC_CB] += qdx * dy;
+                sm[ACC_CC] += qdy * dy;
+                sm[ACC_OP] += qw.x;
+                sm[ACC_R] += qw.y * dp.x;
+                sm[ACC_G] += qw.y * dp.y;
+                sm[ACC_B] += qw.y * dp.z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- flush: [record][9] through LDS (the pair slots are dead now), then 7 records x 9 components per atomic
+            float* fl = reinterpret_cast<float*>(S.pair);
+#pragma unroll
+            for (int c = 0; c < 9; c++) fl[lane * 9 + c] = sm[c];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int r0 = lo; r0 < hi; r0 += 7) {
+                const int rj = r0 + fl_rec;
+                if (lane < 63 && rj < hi) {
+                    const uint32_t id = __float_as_uint(S.rec[rj * kRecQuads + 2].y);
+                    const float val = fl[rj * 9 + fl_c];
+                    if (val != 0.f) atomic_add_f32(accum + (size_t)id * kAccumStride + fl_c, val);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            hi = lo;
+        }
+    }
+}
+
 // test hook: run the 36-value reduce-scatter on in[lane*36 + k] and return each lane's result
 __global__ void __launch_bounds__(64) k_selftest_reduce(const float* in, float* out)
 {
@@ -901,7 +1391,15 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
-    {
+    if (!h->dense_blend_fwd) {
+        StageScope sc(h, ST_BLEND_FWD, s);
+        uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
+        if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
+        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                           (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        hipLaunchKernelGGL(k_tile_finish, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
+                           (const float4*)b.recs, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
+    } else {
         StageScope sc(h, ST_BLEND_FWD, s);
         if (fused) {
             hipLaunchKernelGGL(k_unit_blend_fused, dim3(fgrid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
@@ -926,11 +1424,16 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
                           void* binning, const float* dL_dpix, hipStream_t s, bool debug)
 {
     // the unit count lives on the device: fixed grid, grid-stride loop over the units
-    const uint32_t unit_grid = kUnitGrid;
+    uint32_t unit_grid = kUnitGrid;
+    if (const char* e = getenv("FR_BWD_GRID")) unit_grid = (uint32_t)atoi(e);   // (tuning experiments)
     {
         StageScope sc(h, ST_BLEND_BWD, s);
-        hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W, prm.H,
-                           in.background, dL_dpix, g.accum);
+        if (h->dense_blend_bwd)
+            hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,
+                               prm.H, in.background, dL_dpix, g.accum);
+        else
+            hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning,
+                               prm.W, prm.H, in.background, dL_dpix, g.accum);
     }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");

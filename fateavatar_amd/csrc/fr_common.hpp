@@ -222,6 +222,8 @@ struct fr_handle_impl {
     uint32_t fused_grid = 0;     // resident-grid size of k_unit_blend_fused (0 = not queried yet, 1 = kernel not usable)
     bool no_fused_blend = true;  // default; FR_FUSED_BLEND=1 in the environment selects the experimental one-launch
                                  // k_unit_blend_fused instead of k_unit_tseg + k_unit_blend
+    bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
+    bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];
 };

@@ -5,10 +5,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-frames 2 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
+python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-seconds 5 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
-$R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --cpu-frames 0 --no-graph > /dev/null 2>&1
-$R/tools/profile.sh ${tag}_graph python $R/bench.py --steps 100 --warmup 10 --cpu-frames 0 > /dev/null 2>&1
+$R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --no-graph > /dev/null 2>&1
+$R/tools/profile.sh ${tag}_graph python $R/bench.py --steps 100 --warmup 10 --cpu-seconds 0 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_fetch "FETCH_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_write "WRITE_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
