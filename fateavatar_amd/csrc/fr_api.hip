@@ -63,6 +63,21 @@ int launch_zero(void* ptr, size_t bytes, hipStream_t s)
     return FR_OK;
 }
 
+int ensure_accum(fr_handle_impl* h, size_t P, hipStream_t s)
+{
+    if (P <= h->accum_rows) return FR_OK;
+    // (frames in flight still hold the old pointer in kernels already enqueued on this stream: free behind them)
+    if (h->accum) {
+        FR_HIP(hipStreamSynchronize(s));
+        FR_HIP(hipFree(h->accum));
+    }
+    h->accum = nullptr, h->accum_rows = 0;
+    const size_t rows = P + P / 4 + 1024;
+    FR_HIP(hipMalloc(reinterpret_cast<void**>(&h->accum), rows * kAccumStride * sizeof(float)));
+    h->accum_rows = rows;
+    return launch_zero(h->accum, rows * kAccumStride * sizeof(float), s);
+}
+
 }  // namespace fr
 
 using namespace fr;
@@ -106,6 +121,7 @@ int fr_destroy(fr_handle* hh)
         }
     (void)hipHostFree(h->host_counts);
     if (h->tile_counters) (void)hipFree(h->tile_counters);
+    if (h->accum) (void)hipFree(h->accum);
     delete h;
     return FR_OK;
 }
@@ -206,7 +222,7 @@ const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t fie
         case 4: return g.cov3D;
         case 5: return g.rect;
         case 6: return g.clamped;
-        case 7: return g.accum;
+        case 7: return nullptr;   // (the gradient accumulators moved into the handle)
         default: return nullptr;
     }
 }

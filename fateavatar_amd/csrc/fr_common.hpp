@@ -59,7 +59,10 @@ struct GeomView {
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* cull_tau2;       // [P] threshold of the per-tile footprint test: a pixel can only reach alpha >= 1/255 where
                             //     a dx^2 + 2 b dx dy + c dy^2 <= cull_tau2 (evaluation slack included; +inf = never cull)
-    float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward
+    float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward.  NOT part of the geometry
+                            // buffer: they belong to the handle (fr_handle_impl::accum), are all zero between
+                            // backward passes (k_preprocess_bwd zeroes each row after reading it) and so cost the
+                            // forward no zeroing writes; launch_forward / launch_backward point this member at them
     uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
     uint32_t* block_xcc;        // [ceil(P/256)] XCD the preprocess workgroup ran on (whose counters it used)
     uint32_t* inline_slots;     // [P*kInlineSlots] position inside its tile's segment of each of a Gaussian's first
@@ -76,7 +79,7 @@ struct GeomView {
         g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
         g.cull_tau2 = carve<float>(p, P);
-        g.accum = carve<float>(p, P * kAccumStride);
+        g.accum = nullptr;
         g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
         g.block_xcc = carve<uint32_t>(p, (P + 255) / 256 + 1);
         g.inline_slots = carve<uint32_t>(p, P * kInlineSlots);
@@ -212,6 +215,10 @@ struct fr_handle_impl {
     uint32_t* tile_counters = nullptr;
     size_t tile_counter_tiles = 0;
     bool counters_clean = false;
+    // gradient accumulators of the blend backward (GeomView::accum): device memory owned by the handle, all zero
+    // between backward passes
+    float* accum = nullptr;
+    size_t accum_rows = 0;
     // Frames of one handle share those counters, so they must not overlap on the device.  Frames enqueued on ONE
     // stream are ordered by it; when the stream changes, the new frame first waits for `frame_done`, recorded
     // behind the last kernel that touches the counters of the previous frame (not while a stream is being captured:
@@ -265,6 +272,8 @@ size_t knn_workspace_bytes(int P);
 // memset NODE of a captured graph it stopped taking effect once an eager kernel had been launched between two
 // replays (ROCm 7.0 runtime shipped with PyTorch 2.10; reproduced with tools/dbg_graph.py).
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
+// make h->accum hold at least P zeroed rows (hipMalloc when it grows: not while the stream is being captured)
+int ensure_accum(fr_handle_impl* h, size_t P, hipStream_t s);
 int launch_bind_forward(const fr_binding& b, float* xyz, float* rot, float* scale, hipStream_t s);
 int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g_rot, const float* g_scale, float* d_verts,
                          float* d_offset, float* d_rotation, float* d_scaling, hipStream_t s);

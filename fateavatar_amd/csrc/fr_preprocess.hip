@@ -177,10 +177,6 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     float2 ctr = make_float2(0.f, 0.f);
     if (idx < a.P) {
         int radius_out = 0;
-        {   // the blend backward ADDS into this row (9 of its 16 floats); k_preprocess_bwd zeroes it again after reading
-            float4* acc = reinterpret_cast<float4*>(a.g.accum + (size_t)idx * kAccumStride);
-            acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         do {
             // near cull only (auxiliary.h:154)
             const float3 p_view = xform4x3(p_orig, cam.view);
@@ -691,6 +687,10 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     BinningView b = BinningView::make(binning, (size_t)cap, (size_t)T);
     const bool debug = prm.debug != 0;
     int rc;
+    // the backward's gradient accumulators live in the handle (zero between backward passes): size them here, where an
+    // allocation is still allowed (a backward may be part of a captured graph)
+    if ((rc = ensure_accum(h, (size_t)P, s))) return rc;
+    g.accum = h->accum;
 
     // frames of one handle share the per-tile counters: order this frame behind the previous one if that was
     // enqueued on a different stream (fr_common.hpp, fr_handle_impl::frame_done)

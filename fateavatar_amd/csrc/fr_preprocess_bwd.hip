@@ -63,8 +63,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
         return;
     }
-    // read the accumulator row and leave it zeroed for the next backward over this frame (the forward zeroed it
-    // the first time): no separate zeroing launch
+    // read the accumulator row and leave it zeroed for the next backward (the rows are zero between backward
+    // passes: no zeroing launch, and no zeroing writes in the forward)
     float acc[12];
     {
         float4* row4 = reinterpret_cast<float4*>(a.g.accum + i * kAccumStride);
@@ -411,9 +411,14 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     const int P = prm.P;
     if (P <= 0) return FR_OK;
     GeomView g = GeomView::make(geometry, (size_t)P);
+    {   // gradient accumulators: handle-owned, zero between backward passes (normally sized by the forward already)
+        int rc0 = ensure_accum(h, (size_t)P, s);
+        if (rc0) return rc0;
+        g.accum = h->accum;
+    }
     ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
     const bool debug = prm.debug != 0;
-    // g.accum is all zero here: zeroed by k_preprocess_fwd, and again by k_preprocess_bwd after every backward
+    // g.accum is all zero here: zeroed when allocated, and again by k_preprocess_bwd after every backward
     int rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
     if (rc) return rc;
 

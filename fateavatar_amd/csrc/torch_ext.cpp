@@ -11,8 +11,8 @@
 // fr_forward / fr_backward / fr_mark_visible.  Built by __graft_entry__.build() (torch.utils.cpp_extension, host
 // compiler only: there is no device code in this file).
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>   // PyTorch-ROCm presents its HIP devices as device type "cuda"
+#include <c10/core/DeviceGuard.h>
 #include <algorithm>
 #include <mutex>
 #include <tuple>
@@ -60,7 +60,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
     TORCH_CHECK(means3D.is_cuda(), "fateavatar_amd rasterizer: tensors must be on a HIP device (torch device 'cuda'); there is no CPU path");
     const int P = (int)means3D.size(0), H = image_height, W = image_width;
-    c10::hip::HIPGuard guard(means3D.device());
+    c10::DeviceGuard guard(means3D.device());
     auto f32 = means3D.options().dtype(torch::kFloat32);
     auto u8 = means3D.options().dtype(torch::kByte);
     torch::Tensor out_color = torch::empty({3, H, W}, f32);
@@ -81,7 +81,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     uint64_t cap = std::max<uint64_t>(st.capacity, 4ull * (uint64_t)P + 65536ull);
     fr_counts counts{};
     torch::Tensor binning;
-    void* stream = c10::hip::getCurrentHIPStream(means3D.get_device()).stream();
+    void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means3D.get_device()).stream();
     for (;;) {
         binning = torch::empty({(int64_t)fr_binning_bytes(cap, W, H)}, u8);
         const int rc = fr_forward(st.handle, &prm, &in, out_color.data_ptr<float>(), radii.data_ptr<int>(), geom.data_ptr(),
@@ -110,7 +110,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
     TORCH_CHECK(means3D.is_cuda(), "fateavatar_amd rasterizer: tensors must be on a HIP device (torch device 'cuda'); there is no CPU path");
     const int P = (int)means3D.size(0);
     const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
-    c10::hip::HIPGuard guard(means3D.device());
+    c10::DeviceGuard guard(means3D.device());
     const torch::Tensor shs = f32c(sh);
     const int M = shs.numel() ? (int)shs.size(1) : 0;
     auto f32 = means3D.options().dtype(torch::kFloat32);
@@ -132,7 +132,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                    dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>()};
         const int rc = fr_backward(st.handle, &prm, &in, rad.data_ptr<int>(), geomBuffer.data_ptr(), imageBuffer.data_ptr(),
                                    binningBuffer.data_ptr(), dpix.data_ptr<float>(), &g,
-                                   c10::hip::getCurrentHIPStream(means3D.get_device()).stream());
+                                   c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means3D.get_device()).stream());
         TORCH_CHECK(rc == FR_OK, "fr_backward failed (code ", rc, "): ", fr_last_error());
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
@@ -142,13 +142,13 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
 {
     TORCH_CHECK(means3D.is_cuda(), "fateavatar_amd rasterizer: tensors must be on a HIP device (torch device 'cuda'); there is no CPU path");
     const int P = (int)means3D.size(0);
-    c10::hip::HIPGuard guard(means3D.device());
+    c10::DeviceGuard guard(means3D.device());
     torch::Tensor present = torch::full({P}, false, means3D.options().dtype(at::kBool));
     if (P != 0) {
         const torch::Tensor m3 = f32c(means3D), view = f32c(viewmatrix), proj = f32c(projmatrix);
         const int rc = fr_mark_visible(P, m3.data_ptr<float>(), view.data_ptr<float>(), proj.data_ptr<float>(),
                                        reinterpret_cast<uint8_t*>(present.data_ptr<bool>()),
-                                       c10::hip::getCurrentHIPStream(means3D.get_device()).stream());
+                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(means3D.get_device()).stream());
         TORCH_CHECK(rc == FR_OK, "fr_mark_visible failed: ", fr_last_error());
     }
     return present;
@@ -159,13 +159,13 @@ torch::Tensor distCUDA2(const torch::Tensor& points)
 {
     TORCH_CHECK(points.is_cuda(), "simple_knn: points must be on a HIP device");
     const int P = (int)points.size(0);
-    c10::hip::HIPGuard guard(points.device());
+    c10::DeviceGuard guard(points.device());
     const torch::Tensor pts = points.to(torch::kFloat32).contiguous();
     torch::Tensor means = torch::full({P}, 0.0, pts.options());
     if (P != 0) {
         torch::Tensor ws = torch::empty({(int64_t)fr_knn_workspace_bytes(P)}, pts.options().dtype(torch::kByte));
         const int rc = fr_knn_mean_dist2(P, pts.data_ptr<float>(), means.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
-                                         c10::hip::getCurrentHIPStream(points.get_device()).stream());
+                                         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(points.get_device()).stream());
         TORCH_CHECK(rc == FR_OK, "fr_knn_mean_dist2 failed: ", fr_last_error());
     }
     return means;

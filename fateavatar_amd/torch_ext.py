@@ -32,7 +32,10 @@ def build(force: bool = False) -> str:
     import torch
     from torch.utils import cpp_extension as ce
     from . import _lib
-    deps = [SRC, os.path.join(_HERE, "..", "include", "fr_rasterizer.h"), _lib.SO_PATH]
+    # (the extension only links against libfr_hip.so's C ABI: a rebuilt library does not require a rebuilt extension)
+    deps = [SRC, os.path.join(_HERE, "..", "include", "fr_rasterizer.h")]
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
