@@ -1,0 +1,257 @@
+"""FateAvatar's own per-frame optimisation loop around the path (BASELINE.json configs[2]).
+
+reference:
+  * parameters and their Adam groups — `_opacity, _offset, _features_dc, _rotation, _scaling` in that order
+    (train/optim.py:15-21), learning rates of config/fateavatar.yaml:34-39, Adam(eps 1e-8, default betas)
+  * a frame — model/fateavatar.py:225-276: the Gaussians are BOUND to the posed mesh (`bind_gaussians`: position =
+    barycentric point + normal * shell_len * tanh(offset); rotation = face quaternion (x) rotation; scaling += log of
+    the face's scale ratio), rendered with SH degree 0, one L1 term here (train/loss.py:92)
+  * the step — train/iteration.py:21-60: zero_grad(set_to_none) -> render -> loss -> backward -> densification
+    statistics -> Adam
+  * maintenance — train/iteration.py:62-86 with model/fateavatar.py:610-731: `_uv_densify` (multinomial draw by
+    accumulated screen-space gradient, NEW barycentrics on the sampled rows' faces, scale * 0.75, zero Adam moments,
+    statistics reset), `_prune_low_opacity_points` (statistics kept for the surviving rows), `_reset_opacity`.
+What is fused: binding forward / backward are one kernel each, activations and statistics run inside the rasterizer
+kernels, Adam is one kernel over the flat buffer, and the whole step replays as ONE HIP graph.  Data-parallel: one frame
+per rank, one flat-gradient all-reduce; the random draws of a densification are made on rank 0 from the SUMMED
+statistics and broadcast, so every rank appends identical rows.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import dp
+from .binding import bind_gaussians, face_scale
+from .model import TorchCamera
+from .optim import FusedAdam
+from .rasterizer import GradOut
+from .render import render
+from .train import TrainStep
+
+# config/fateavatar.yaml:34-39 (group names of train/optim.py:15-21)
+FATE_LRS = dict(opacity=0.05, offset=0.0016, color=0.0025, rotation=0.001, scaling=0.005)
+# config/fateavatar.yaml:41-47
+FATE_MAINTAIN = dict(opacity_reset_interval=60000, densify_interval=3000, prune_interval=2000, min_opacity=0.005,
+                     increase_num=1000, max_points_num=200000)
+
+
+class AvatarGaussians(torch.nn.Module):
+    """The mesh-bound Gaussian parameters of FateAvatar (model/fateavatar.py:166-190) in ONE flat buffer, in the order
+    of the optimizer groups.  `face_index` / `bary_coords` are the binding (model/fateavatar.py:120-164)."""
+    FIELDS = (("_opacity", 1), ("_offset", 1), ("_features_dc", 3), ("_rotation", 4), ("_scaling", 3))
+    SHAPES = {"_opacity": (1,), "_offset": (1,), "_features_dc": (1, 3), "_rotation": (4,), "_scaling": (3,)}
+    max_sh_degree = 0   # model/fateavatar.py:54,244
+    fused_activations = True
+
+    def __init__(self, face_index, bary_coords, scale_init: float, device):
+        """_register_init_gaussian (model/fateavatar.py:166-190): grey colour (DC = inverse_sigmoid(0.5) = 0), log
+        scale_init on all axes, identity rotation, opacity 0.1, zero offset."""
+        super().__init__()
+        P = int(len(face_index))
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)  # noqa: E731
+        rot = z(P, 4)
+        rot[:, 0] = 1
+        op = torch.full((P, 1), float(np.log(0.1 / 0.9)), dtype=torch.float32, device=device)
+        self.face_index = torch.as_tensor(np.asarray(face_index), dtype=torch.int32, device=device).contiguous()
+        self.bary_coords = torch.as_tensor(np.asarray(bary_coords), dtype=torch.float32, device=device).contiguous()
+        self._bind([op, z(P, 1), z(P, 1, 3), rot, torch.full((P, 3), float(scale_init), dtype=torch.float32, device=device)])
+
+    @property
+    def P(self):
+        return int(self.face_index.shape[0])
+
+    def widths(self):
+        return [w for _, w in self.FIELDS]
+
+    def _bind(self, raw):
+        P = raw[0].shape[0]
+        dev = raw[0].device
+        sizes = [P * w for _, w in self.FIELDS]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat)
+        off = 0
+        for (name, w), n, r in zip(self.FIELDS, sizes, raw):
+            shp = (P,) + self.SHAPES[name]
+            self.flat[off:off + n].copy_(r.detach().reshape(-1))
+            p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
+            # every parameter reaches a HIP kernel raw (the rasterizer or the binding op): its gradient is written straight
+            # into the flat gradient buffer
+            p._fr_grad_out = GradOut(self.flat_grad[off:off + n].view(shp))
+            setattr(self, name, p)
+            off += n
+
+    def begin_step(self):
+        for name, _ in self.FIELDS:
+            getattr(self, name).grad = None
+
+    def collect_grads(self) -> torch.Tensor:
+        off = 0
+        for name, w in self.FIELDS:
+            n = self.P * w
+            g, view = getattr(self, name).grad, self.flat_grad[off:off + n]
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != view.data_ptr():
+                view.copy_(g.reshape(-1))
+            off += n
+        return self.flat_grad
+
+    @torch.no_grad()
+    def resize(self, keep_mask=None, new_rows=None, new_face_index=None, new_bary=None):
+        """Drop the rows where keep_mask is False, then append `new_rows` (one tensor per field) with their binding.
+        Returns the row map (old row of every new row, -1 for appended ones) the optimizer state has to follow."""
+        dev = self.flat.device
+        keep = torch.ones(self.P, dtype=torch.bool, device=dev) if keep_mask is None else keep_mask.reshape(-1).bool()
+        old_index = torch.nonzero(keep).reshape(-1)
+        raw = [getattr(self, name).detach()[old_index] for name, _ in self.FIELDS]
+        fi, bc = self.face_index[old_index], self.bary_coords[old_index]
+        n_new = 0
+        if new_rows is not None:
+            n_new = int(new_rows[0].shape[0])
+            raw = [torch.cat([r, a.to(dev, torch.float32).reshape((n_new,) + tuple(r.shape[1:]))]) for r, a in zip(raw, new_rows)]
+            fi = torch.cat([fi, new_face_index.to(dev, torch.int32)])
+            bc = torch.cat([bc, new_bary.to(dev, torch.float32)])
+        self.face_index, self.bary_coords = fi.contiguous(), bc.contiguous()
+        self._bind(raw)
+        return torch.cat([old_index, torch.full((n_new,), -1, dtype=torch.int64, device=dev)])
+
+
+class _BoundFrame:
+    """What render() reads of a Gaussian holder (render_3dgs.py:19-63), for one frame's bound values."""
+    max_sh_degree = 0
+    fused_activations = True
+
+    def __init__(self, xyz, pc: AvatarGaussians, rot, scl, stats):
+        self.get_xyz, self._opacity, self._scaling, self._rotation = xyz, pc._opacity, scl, rot
+        self.get_features = pc._features_dc            # cat(features_dc, features_rest) with an empty rest (M = 1)
+        self.fused_densification_stats = stats
+
+
+class AvatarStep(TrainStep):
+    """One optimisation step of FateAvatar per call: `step(camera, posed_verts, gt_image)`."""
+
+    def __init__(self, pc: AvatarGaussians, faces: torch.Tensor, canonical_verts: torch.Tensor, camera: TorchCamera,
+                 bg: torch.Tensor, lrs: Optional[dict] = None, shell_len: float = 0.05, resize_scale: bool = True,
+                 use_graph: bool = True):
+        self.pc, self.bg = pc, bg
+        self.dev = pc.flat.device
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.lr = dict(FATE_LRS, **(lrs or {}))
+        self.faces = faces.to(self.dev, torch.int32).contiguous()
+        self.shell_len, self.resize_scale = float(shell_len), bool(resize_scale)
+        # compute_face_orientation(canonical verts, return_scale=True)[1] (model/fateavatar.py:84-85)
+        self.face_scale_canonical = face_scale(canonical_verts.to(self.dev, torch.float32), self.faces)
+        self._make_adam()
+        self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
+        self.denom = torch.zeros((pc.P, 1), device=self.dev)
+        self.cam = camera
+        self.verts = canonical_verts.to(self.dev, torch.float32).clone().contiguous()   # static input of the captured step
+        self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
+        self.loss = torch.zeros((), device=self.dev)
+        self.out = None
+        self.use_graph = bool(use_graph)
+        self._graph, self._eager_steps, self.overflows = None, 0, 0
+
+    def _make_adam(self):
+        pc, lr, P = self.pc, self.lr, self.pc.P
+        self.adam = FusedAdam(pc.flat, pc.flat_grad, [(P * 1, lr["opacity"]), (P * 1, lr["offset"]), (P * 3, lr["color"]),
+                                                      (P * 4, lr["rotation"]), (P * 3, lr["scaling"])],
+                              grad_scale=1.0 / self.world)
+
+    def _forward_backward(self):
+        pc = self.pc
+        pc.begin_step()                                             # zero_grad(set_to_none=True), iteration.py:48-49
+        xyz, rot, scl = bind_gaussians(self.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
+                                       pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
+        frame = _BoundFrame(xyz, pc, rot, scl, (self.xyz_gradient_accum, self.denom))
+        out = render(self.cam, frame, self.bg)
+        loss = torch.nn.functional.l1_loss(out["render"], self.gt)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
+
+    def step(self, camera: TorchCamera, posed_verts: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
+        self.verts.copy_(posed_verts, non_blocking=True)
+        return super().step(camera, gt_image)
+
+    # ---- maintenance (train/iteration.py:62-86)
+    def maintain(self, global_step: int, cfg: Optional[dict] = None) -> dict:
+        """The reference's schedule after the optimizer step of `global_step`.  Returns what was done."""
+        c = dict(FATE_MAINTAIN, **(cfg or {}))
+        did = {}
+        if global_step % c["densify_interval"] == 0 and self.pc.P < c["max_points_num"]:
+            did["densified"] = self.uv_densify(min(c["max_points_num"] - self.pc.P, c["increase_num"]))
+        if global_step % c["prune_interval"] == 0:
+            did["pruned"] = self.prune_low_opacity(c["min_opacity"])
+        if global_step % c["opacity_reset_interval"] == 0 and global_step != 0:
+            self.reset_opacity()
+            did["opacity_reset"] = True
+        return did
+
+    @torch.no_grad()
+    def _rebind_optimizer(self, old_index, old_rows):
+        pc = self.pc
+        self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), old_rows)
+        self._graph, self._eager_steps = None, 0   # buffers moved: the captured step is stale
+
+    @torch.no_grad()
+    def uv_densify(self, increase_num: int, generator: Optional[torch.Generator] = None) -> int:
+        """_uv_densify (model/fateavatar.py:610-672).  The two random draws (multinomial over xyz_gradient_accum, with
+        replacement; uniform barycentrics) are made on rank 0 from the statistics summed over all ranks and broadcast."""
+        pc = self.pc
+        acc, _ = self.reduce_densification_stats()
+        w = acc.reshape(-1)
+        idx = torch.zeros(increase_num, dtype=torch.int64, device=self.dev)
+        uvw = torch.zeros((increase_num, 3), dtype=torch.float32, device=self.dev)
+        if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
+            if float(w.sum()) <= 0:
+                raise RuntimeError("no densification statistics accumulated yet")
+            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+            uvw = torch.rand((increase_num, 3), device=self.dev, generator=generator)
+        dp.broadcast_(idx)
+        dp.broadcast_(uvw)
+        new_bary = uvw / uvw.sum(dim=-1, keepdim=True)
+        rows = [getattr(pc, name).detach()[idx].clone() for name, _ in pc.FIELDS]
+        rows[4] = torch.log(torch.exp(rows[4]) * 0.75)          # new_scaling (:624)
+        old_rows = pc.P
+        old_index = pc.resize(new_rows=rows, new_face_index=pc.face_index[idx], new_bary=new_bary)
+        self._rebind_optimizer(old_index, old_rows)
+        # statistics restart from zero (:667-669)
+        self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
+        self.denom = torch.zeros((pc.P, 1), device=self.dev)
+        self.last_densify = (idx, new_bary)
+        return increase_num
+
+    @torch.no_grad()
+    def prune_low_opacity(self, min_opacity: float = 0.005) -> int:
+        """_prune_low_opacity_points (model/fateavatar.py:674-711): the statistics of the surviving rows are kept."""
+        pc = self.pc
+        keep = ~(torch.sigmoid(pc._opacity) < min_opacity).reshape(-1)
+        old_rows = pc.P
+        acc, den = self.xyz_gradient_accum[keep], self.denom[keep]
+        old_index = pc.resize(keep_mask=keep)
+        self._rebind_optimizer(old_index, old_rows)
+        self.xyz_gradient_accum, self.denom = acc.contiguous(), den.contiguous()
+        return old_rows - pc.P
+
+    @torch.no_grad()
+    def reset_opacity(self) -> None:
+        """_reset_opacity (model/fateavatar.py:713-731), in place (the captured graph stays valid)."""
+        pc = self.pc
+        cur = torch.sigmoid(pc._opacity)
+        new = torch.minimum(cur, torch.full_like(cur, 0.01))
+        pc._opacity.data.copy_(torch.log(new / (1 - new)))
+        self.adam.zero_field_moments(pc.widths(), pc.P, fields=(0,))
+
+    def state_dict(self) -> dict:
+        pc = self.pc
+        model = {name: getattr(pc, name).detach().clone() for name, _ in pc.FIELDS}
+        model["_features_rest"] = torch.zeros((pc.P, 0, 3), device=self.dev)
+        return {"global_step": self.adam.step_count, "model": model,
+                "binding": {"face_index": pc.face_index.clone(), "bary_coords": pc.bary_coords.clone()},
+                "optimizer": {"exp_avg": self.adam.exp_avg.clone(), "exp_avg_sq": self.adam.exp_avg_sq.clone(),
+                              "state": self.adam.state.clone()},
+                "densification": {"xyz_gradient_accum": self.xyz_gradient_accum.clone(), "denom": self.denom.clone()}}

@@ -71,6 +71,10 @@ class _Bind(torch.autograd.Function):
             raise RuntimeError(f"fr_bind_forward failed: {_lib.last_error()}")
         ctx.save_for_backward(verts, offset, rotation, scaling, faces, face_index, bary, canon)
         ctx.consts = (float(shell_len), bool(resize_scale), offset.shape)
+        # optional extension (see rasterizer.GradOut): a raw parameter may carry `_fr_grad_out`, a slot whose preallocated
+        # buffer (a view into a flat gradient buffer) receives its gradient without a copy
+        from .rasterizer import GradOut
+        ctx.grad_slots = (GradOut.of(offset), GradOut.of(rotation), GradOut.of(scaling))
         return xyz, rot, scl
 
     @staticmethod
@@ -82,9 +86,18 @@ class _Bind(torch.autograd.Function):
         c = lambda g: g.contiguous().float() if g is not None else None  # noqa: E731
         g_xyz, g_rot, g_scl = c(g_xyz), c(g_rot), c(g_scl)
         d_verts = torch.zeros_like(verts) if need_v else None
-        d_off = torch.empty((N,), dtype=torch.float32, device=dev) if need_o else None
-        d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev) if need_r else None
-        d_scl = torch.empty((N, 3), dtype=torch.float32, device=dev) if need_s else None
+
+        def out(need, slot, shape):
+            if not need:
+                return None
+            buf = slot.claim() if slot is not None else None   # first backward of the step writes the slot in place
+            if buf is not None and buf.numel() == int(torch.Size(shape).numel()) and buf.is_contiguous():
+                return buf.view(shape)
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        d_off = out(need_o, ctx.grad_slots[0], (N,))
+        d_rot = out(need_r, ctx.grad_slots[1], (N, 4))
+        d_scl = out(need_s, ctx.grad_slots[2], (N, 3))
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         b = _desc(verts, faces, face_index, bary, canon, offset, rotation, scaling, shell_len, resize_scale)
         with torch.cuda.device(dev):

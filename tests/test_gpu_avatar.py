@@ -1,0 +1,219 @@
+"""-m gpu: FateAvatar's own optimisation loop (BASELINE.json configs[2]) at full size — 100 k mesh-bound Gaussians,
+512x512, synthetic INSTA-layout sequence — and its maintenance operations.
+
+reference: model/fateavatar.py:225-276 (bound frame), train/iteration.py:21-89 (step + schedule), train/optim.py:15-21
+(groups), config/fateavatar.yaml:34-47, model/fateavatar.py:610-731 (_uv_densify / _prune_low_opacity_points /
+_reset_opacity), train/dataset.py:474-548 (INSTA cameras)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, P, res, n_frames, seed=0):
+    import torch
+    from fateavatar_amd import insta, mesh_sampling, scenes
+    from fateavatar_amd.avatar import AvatarGaussians
+    from fateavatar_amd.knn import init_scale_by_knn
+    from fateavatar_amd.model import TorchCamera
+    transform, posed, faces = insta.synthetic_sequence(n_frames, res, seed)
+    verts, _, _ = scenes.head_geometry()
+    fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, np.random.default_rng(seed))
+    pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)
+    _, _, scale_init = init_scale_by_knn(torch.from_numpy(pts).to(dev))      # model/fateavatar.py:597-608
+    cams = [TorchCamera(c, dev) for c in insta.camera_arrays(transform)]
+    mk = lambda: AvatarGaussians(fi, bc, float(scale_init), dev)  # noqa: E731
+    return dict(transform=transform, posed=torch.from_numpy(posed).to(dev), faces=torch.from_numpy(faces).to(dev),
+                canon=torch.from_numpy(verts).to(dev), cams=cams, make=mk, scale_init=float(scale_init), fi=fi, bc=bc)
+
+
+def _targets(S, dev, bg):
+    """Images of a hidden ground-truth avatar: the same binding, coloured / opaque / offset differently."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep
+    gt = S["make"]()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        gt._features_dc.copy_((torch.rand(gt.P, 1, 3, generator=g) * 2.0 - 1.0).to(dev))
+        gt._opacity.fill_(float(np.log(0.6 / 0.4)))
+        gt._offset.copy_((0.3 * torch.randn(gt.P, 1, generator=g)).to(dev))
+    st = AvatarStep(gt, S["faces"], S["canon"], S["cams"][0], bg, use_graph=False)
+    imgs = []
+    for f, cam in enumerate(S["cams"]):
+        st.cam.copy_from(cam)
+        st.verts.copy_(S["posed"][f])
+        with torch.no_grad():
+            from fateavatar_amd.avatar import _BoundFrame
+            from fateavatar_amd.binding import bind_gaussians
+            from fateavatar_amd.render import render
+            xyz, rot, scl = bind_gaussians(st.verts, st.faces, gt.face_index, gt.bary_coords, st.face_scale_canonical, gt._offset,
+                                           gt._rotation, gt._scaling, st.shell_len, True)
+            imgs.append(render(st.cam, _BoundFrame(xyz, gt, rot, scl, None), bg)["render"].clone())
+    return imgs
+
+
+def test_config3_fateavatar_loop_100k_512(gpu_device):
+    """60 steps of the FateAvatar step at 100 k / 512x512 over a 16-frame synthetic INSTA sequence: the HIP-graph replay
+    follows the eager step, the loss falls, gradients reach every parameter group through the binding op, nothing
+    overflows."""
+    import torch
+    from fateavatar_amd.avatar import FATE_LRS, AvatarStep
+    dev = gpu_device
+    P, res, n_frames, steps = 100_000, 512, 16, 60
+    S = _setup(dev, P, res, n_frames)
+    assert abs(S["scale_init"] - np.log(6.085e-4)) < 0.02          # SURVEY.md §8d config 2 spacing
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+
+    def run(use_graph):
+        pc = S["make"]()
+        cam0 = type(S["cams"][0]).__new__(type(S["cams"][0]))
+        cam0.__dict__.update(S["cams"][0].__dict__)
+        cam0._packed = S["cams"][0]._packed.clone()
+        cam0.world_view_transform = cam0._packed[0:16].view(4, 4)
+        cam0.full_proj_transform = cam0._packed[16:32].view(4, 4)
+        cam0.camera_center = cam0._packed[32:35]
+        st = AvatarStep(pc, S["faces"], S["canon"], cam0, bg, use_graph=use_graph)
+        losses = []
+        for it in range(steps):
+            f = it % n_frames
+            losses.append(st.step(S["cams"][f], S["posed"][f], gts[f]).clone())
+        torch.cuda.synchronize()
+        st.check()
+        return pc, [float(x) for x in losses], st
+
+    pc_e, loss_e, st_e = run(False)
+    pc_g, loss_g, st_g = run(True)
+    assert st_g._graph is not None and st_e._graph is None and st_g.overflows == 0
+    assert st_g.adam.step_count == steps == st_e.adam.step_count
+    assert np.mean(loss_e[-8:]) < 0.85 * np.mean(loss_e[:8]), (loss_e[:4], loss_e[-4:])
+    assert np.allclose(loss_g, loss_e, rtol=5e-3), (loss_g[-4:], loss_e[-4:])
+    assert torch.equal(st_g.denom, st_e.denom) and float(st_e.denom.max()) > 0
+    # every group moved (gradients flow through the binding op to offset / rotation / scaling)
+    fresh = S["make"]()
+    for name, _ in pc_e.FIELDS:
+        d = float((getattr(pc_e, name).detach() - getattr(fresh, name).detach()).abs().max())
+        assert d > 0, name
+    # the learning rates are the reference's (config/fateavatar.yaml:34-39): first Adam step moves a parameter by ~lr
+    assert FATE_LRS == dict(opacity=0.05, offset=0.0016, color=0.0025, rotation=0.001, scaling=0.005)
+    assert float((pc_g.flat - pc_e.flat).abs().max()) < 2e-2
+
+
+def test_binding_gradients_match_autograd_of_the_torch_ops(gpu_device):
+    """The gradients the step writes into the flat buffer == autograd through stock PyTorch activations + the bound
+    frame (fused activations off, no gradient slots): the fused path changes no number beyond float rounding."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep, _BoundFrame
+    from fateavatar_amd.binding import bind_gaussians
+    from fateavatar_amd.render import render
+    dev = gpu_device
+    S = _setup(dev, 6000, 96, 4, seed=2)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    pc = S["make"]()
+    with torch.no_grad():
+        pc._features_dc.add_(0.2)
+        pc._offset.add_(0.1)
+    st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][1], bg, use_graph=False)
+    st.verts.copy_(S["posed"][1])
+    st.gt.copy_(gts[1])
+    st._forward_backward()
+    got = {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}
+    assert all(getattr(pc, n).grad.data_ptr() == getattr(pc, n)._fr_grad_out.buf.data_ptr() for n, _ in pc.FIELDS)
+    # reference path: same values, plain tensors, PyTorch activations
+    leaves = {n: getattr(pc, n).detach().clone().requires_grad_(True) for n, _ in pc.FIELDS}
+    xyz, rot, scl = bind_gaussians(st.verts, st.faces, pc.face_index, pc.bary_coords, st.face_scale_canonical, leaves["_offset"],
+                                   leaves["_rotation"], leaves["_scaling"], st.shell_len, True)
+
+    class Plain:
+        max_sh_degree = 0
+        get_xyz = xyz
+        get_opacity = torch.sigmoid(leaves["_opacity"])
+        get_scaling = torch.exp(scl)
+        get_rotation = torch.nn.functional.normalize(rot)
+        get_features = leaves["_features_dc"]
+    out = render(st.cam, Plain, bg)
+    torch.nn.functional.l1_loss(out["render"], st.gt).backward()
+    for n in got:
+        ref = leaves[n].grad
+        err = float((got[n] - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert err < 2e-4, (n, err)
+        assert float(ref.abs().max()) > 0
+
+
+def test_uv_densify_prune_reset_follow_the_reference(gpu_device):
+    """_uv_densify: rows appended on the sampled rows' FACES with fresh barycentrics, copied parameters, scale * 0.75,
+    zero moments, statistics reset; _prune_low_opacity_points: rows, binding, moments AND statistics masked together;
+    the schedule of train/iteration.py:62-86; the step keeps training on the re-bound set."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep
+    dev = gpu_device
+    S = _setup(dev, 5000, 96, 4, seed=3)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    pc = S["make"]()
+    st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][0], bg)
+    for it in range(6):
+        st.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4])
+    torch.cuda.synchronize()
+    assert st._graph is not None
+
+    def blocks(flat, rows):
+        out, o = [], 0
+        for w in pc.widths():
+            out.append(flat[o:o + rows * w].view(rows, w).clone())
+            o += rows * w
+        return out
+
+    # ---- densify (the schedule fires at global_step % 3000 == 0, i.e. also at step 0 in the reference)
+    rows0 = pc.P
+    p0, m0 = blocks(pc.flat, rows0), blocks(st.adam.exp_avg, rows0)
+    fi0, bc0 = pc.face_index.clone(), pc.bary_coords.clone()
+    did = st.maintain(3000, dict(increase_num=300, prune_interval=10 ** 9))
+    assert did == {"densified": 300} and pc.P == rows0 + 300 and st._graph is None
+    idx, new_bary = st.last_densify
+    assert torch.equal(pc.face_index[:rows0], fi0) and torch.equal(pc.bary_coords[:rows0], bc0)
+    assert torch.equal(pc.face_index[rows0:], fi0[idx])                      # same faces ...
+    assert torch.equal(pc.bary_coords[rows0:], new_bary)                     # ... fresh barycentrics
+    assert torch.allclose(new_bary.sum(-1), torch.ones(300, device=dev), atol=1e-6) and float(new_bary.min()) >= 0
+    assert not torch.equal(new_bary, bc0[idx])
+    p1, m1, v1 = blocks(pc.flat, pc.P), blocks(st.adam.exp_avg, pc.P), blocks(st.adam.exp_avg_sq, pc.P)
+    for f in range(5):
+        assert torch.equal(p1[f][:rows0], p0[f]) and torch.equal(m1[f][:rows0], m0[f])
+        assert float(m1[f][rows0:].abs().max()) == 0.0 and float(v1[f][rows0:].abs().max()) == 0.0
+        want = torch.log(torch.exp(p0[f][idx]) * 0.75) if f == 4 else p0[f][idx]
+        assert torch.equal(p1[f][rows0:], want)
+    assert float(st.denom.abs().max()) == 0.0 and st.denom.shape == (pc.P, 1)
+    assert st.adam.step_count == 6
+    l0 = float(st.step(S["cams"][0], S["posed"][0], gts[0]))
+    for it in range(8):
+        l1 = float(st.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4]))
+    torch.cuda.synchronize()
+    assert st._graph is not None and np.isfinite(l1)
+
+    # ---- prune
+    with torch.no_grad():
+        pc._opacity[::7] = -8.0                      # sigmoid(-8) < 0.005
+    keep = ~(torch.sigmoid(pc._opacity) < 0.005).reshape(-1)
+    rows1 = pc.P
+    p2, m2 = blocks(pc.flat, rows1), blocks(st.adam.exp_avg, rows1)
+    fi1, acc1, den1 = pc.face_index.clone(), st.xyz_gradient_accum.clone(), st.denom.clone()
+    did = st.maintain(2000, dict(densify_interval=10 ** 9))
+    assert did["pruned"] == int((~keep).sum()) > 0 and pc.P == int(keep.sum())
+    for a, b in zip(blocks(pc.flat, pc.P) + blocks(st.adam.exp_avg, pc.P), p2 + m2):
+        assert torch.equal(a, b[keep])
+    assert torch.equal(pc.face_index, fi1[keep])
+    assert torch.equal(st.xyz_gradient_accum, acc1[keep]) and torch.equal(st.denom, den1[keep]) and float(den1.max()) > 0
+
+    # ---- opacity reset: in place, graph stays valid
+    for it in range(4):
+        st.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4])
+    g_before = st._graph
+    did = st.maintain(60000, dict(densify_interval=10 ** 9, prune_interval=10 ** 9))
+    assert did == {"opacity_reset": True} and st._graph is g_before
+    assert float(torch.sigmoid(pc._opacity.detach()).max()) <= 0.01 + 1e-6
+    assert float(blocks(st.adam.exp_avg, pc.P)[0].abs().max()) == 0.0
+    st.step(S["cams"][0], S["posed"][0], gts[0])
+    torch.cuda.synchronize()
+    st.check()
+    assert st.maintain(7, None) == {}
