@@ -111,9 +111,13 @@ def test_binding_gradients_match_autograd_of_the_torch_ops(gpu_device):
     bg = torch.ones(3, device=dev)
     gts = _targets(S, dev, bg)
     pc = S["make"]()
+    g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         pc._features_dc.add_(0.2)
         pc._offset.add_(0.1)
+        # anisotropic, rotated splats: with the isotropic initial state the rotation gradient is exactly zero
+        pc._scaling.add_((0.5 * torch.randn(pc.P, 3, generator=g)).to(dev))
+        pc._rotation.add_((0.5 * torch.randn(pc.P, 4, generator=g)).to(dev))
     st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][1], bg, use_graph=False)
     st.verts.copy_(S["posed"][1])
     st.gt.copy_(gts[1])

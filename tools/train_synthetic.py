@@ -33,10 +33,15 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fateavatar", action="store_true",
+                    help="FateAvatar's own loop: mesh-bound parameters (offset / rotation / scaling / colour / opacity), "
+                         "synthetic INSTA-layout sequence with per-frame posed mesh, SH degree 0")
     a = ap.parse_args()
     rank, world, local = dp.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.fateavatar:
+        return main_fateavatar(a, rank, world, dev)
     truth = scenes.head_scene(P=a.P, res=a.res, sh_degree=a.sh_degree, seed=0, opacity=0.5)
     cams = [TorchCamera(scenes.head_scene(P=8, res=a.res, sh_degree=a.sh_degree, seed=0, view=v, n_views=a.views).camera, dev)
             for v in range(a.views)]
@@ -71,6 +76,61 @@ def main():
         print(json.dumps({"metric": "optimisation steps/s (render + L1 + backward + stats + Adam)", "value": round(a.steps / dt, 1),
                           "frames_per_s": round(world * a.steps / dt, 1), "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 4),
                           "P": a.P, "res": a.res, "views": a.views, "graph": not a.no_graph,
+                          "loss_first": round(float(np.mean(l[:4])), 6), "loss_last": round(float(np.mean(l[-4:])), 6)}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def main_fateavatar(a, rank, world, dev):
+    from fateavatar_amd import insta, mesh_sampling
+    from fateavatar_amd.avatar import AvatarGaussians, AvatarStep, _BoundFrame
+    from fateavatar_amd.binding import bind_gaussians
+    from fateavatar_amd.knn import init_scale_by_knn
+    n_frames = max(a.views, 8)
+    transform, posed, faces = insta.synthetic_sequence(n_frames, a.res, seed=0)
+    verts, _, _ = scenes.head_geometry()
+    fi, bc = mesh_sampling.random_sampling_barycoords(a.P, verts, faces, np.random.default_rng(0))
+    pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)
+    scale_init = float(init_scale_by_knn(torch.from_numpy(pts).to(dev))[2])
+    cams = [TorchCamera(c, dev) for c in insta.camera_arrays(transform)]
+    posed_t, faces_t, canon = torch.from_numpy(posed).to(dev), torch.from_numpy(faces).to(dev), torch.from_numpy(verts).to(dev)
+    bg = torch.ones(3, device=dev)
+    # hidden ground truth: same binding, other appearance
+    gt = AvatarGaussians(fi, bc, scale_init, dev)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        gt._features_dc.copy_((torch.rand(gt.P, 1, 3, generator=g) * 2.0 - 1.0).to(dev))
+        gt._opacity.fill_(float(np.log(0.6 / 0.4)))
+        gt._offset.copy_((0.3 * torch.randn(gt.P, 1, generator=g)).to(dev))
+    ref = AvatarStep(gt, faces_t, canon, TorchCamera(insta.camera_arrays(transform)[0], dev), bg, use_graph=False)
+    gts = []
+    with torch.no_grad():
+        for f in range(n_frames):
+            xyz, rot, scl = bind_gaussians(posed_t[f], ref.faces, gt.face_index, gt.bary_coords, ref.face_scale_canonical, gt._offset,
+                                           gt._rotation, gt._scaling, ref.shell_len, True)
+            gts.append(render(cams[f], _BoundFrame(xyz, gt, rot, scl, None), bg)["render"].clone())
+    pc = AvatarGaussians(fi, bc, scale_init, dev)
+    st = AvatarStep(pc, faces_t, canon, TorchCamera(insta.camera_arrays(transform)[0], dev), bg, use_graph=not a.no_graph)
+    losses, warm = [], 10
+    for it in range(warm):
+        f = (it * world + rank) % n_frames
+        losses.append(st.step(cams[f], posed_t[f], gts[f]).clone())
+    torch.cuda.synchronize()
+    dp.barrier()
+    t0 = time.perf_counter()
+    for it in range(warm, warm + a.steps):
+        f = (it * world + rank) % n_frames
+        losses.append(st.step(cams[f], posed_t[f], gts[f]).clone())
+    torch.cuda.synchronize()
+    dp.barrier()
+    dt = time.perf_counter() - t0
+    st.check()
+    if rank == 0:
+        l = [float(x) for x in losses]
+        print(json.dumps({"metric": "FateAvatar optimisation steps/s (bind + render + L1 + backward + stats + Adam)",
+                          "value": round(a.steps / dt, 1), "frames_per_s": round(world * a.steps / dt, 1), "n_gpus": world,
+                          "ms_per_step": round(dt / a.steps * 1e3, 4), "P": a.P, "res": a.res, "frames": n_frames, "sh_degree": 0,
+                          "graph": not a.no_graph, "overflows": st.overflows,
                           "loss_first": round(float(np.mean(l[:4])), 6), "loss_last": round(float(np.mean(l[-4:])), 6)}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
