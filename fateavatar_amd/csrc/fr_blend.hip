@@ -1260,61 +1260,85 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            // ---- phase A: lane = pixel, back to front over the records its mask column names
+            // ---- phase A: lane = pixel, back to front over the records its mask column names.  Two records per
+            // iteration: their alpha evaluations and slot computations are independent instruction streams (the kernel is
+            // bound by the latency of its LDS round trips, not by issue slots); only the T / accum_rec recurrence is serial
             u64 Bg = Bp & range;
-            const uint32_t nA = wave_max_u32((uint32_t)__popcll(Bg));
+            const uint32_t nA = (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1;
             for (uint32_t it = 0; it < nA; it++) {
-                const bool act = Bg != 0ull;
-                const int j = act ? 63 - (int)__builtin_clzll(Bg) : 0;
-                Bg &= ~(1ull << j);       // (no bits set: stays 0)
-                const float4 q0 = S.rec[j * kRecQuads + 0];
-                const float4 q1 = S.rec[j * kRecQuads + 1];
-                const float4 q2 = S.rec[j * kRecQuads + 2];
-                const uint32_t sb = S.sbase[j];
-                const float dx = q0.x - fx, dy = q0.y - fy;
-                const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-                const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
-                const bool ok = act && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
-                const float cd = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;    // colour . dL_dpixel
-                const float ar_e = ok ? araw : 0.f;                         // failed pair: alpha = 0, every update is the identity
-                const float a_e = __builtin_amdgcn_fmed3f(ar_e, 0.f, 0.99f);
-                const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
-                T *= inv;                                                   // backward.cu:503
-                const float e = cd - A;
-                const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
-                A += a_e * e;
-                const uint32_t rank = (uint32_t)__popc(__float_as_uint(q2.z) & (uint32_t)lt_mask) +
-                                      (uint32_t)__popc(__float_as_uint(q2.w) & (uint32_t)(lt_mask >> 32));
-                if (act) S.pair[sb - slot0 + rank] = make_float2(dL_dalpha * ar_e, a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
+                bool act[2];
+                int j[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    act[k] = Bg != 0ull;
+                    j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
+                    Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
+                }
+                float ar_e[2], cd[2];
+                uint32_t slot[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const float4 q0 = S.rec[j[k] * kRecQuads + 0];
+                    const float4 q1 = S.rec[j[k] * kRecQuads + 1];
+                    const float4 q2 = S.rec[j[k] * kRecQuads + 2];
+                    const uint32_t sb = S.sbase[j[k]];
+                    const float dx = q0.x - fx, dy = q0.y - fy;
+                    const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+                    const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
+                    const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+                    cd[k] = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;              // colour . dL_dpixel
+                    ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity
+                    slot[k] = sb - slot0 + (uint32_t)__popc(__float_as_uint(q2.z) & (uint32_t)lt_mask) +
+                              (uint32_t)__popc(__float_as_uint(q2.w) & (uint32_t)(lt_mask >> 32));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const float a_e = __builtin_amdgcn_fmed3f(ar_e[k], 0.f, 0.99f);
+                    const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
+                    T *= inv;                                                   // backward.cu:503
+                    const float e = cd[k] - A;
+                    const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
+                    A += a_e * e;
+                    if (act[k]) S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            // ---- phase B: lane = record, over its own pixels; its pairs are consecutive slots
+            // ---- phase B: lane = record, over its own pixels (two per iteration); its pairs are consecutive slots
             float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
             uint32_t slot = (cum - cnt) - slot0;
-            const uint32_t nB = wave_max_u32((uint32_t)__popcll(Mg));
+            const uint32_t nB = (wave_max_u32((uint32_t)__popcll(Mg)) + 1u) >> 1;
             for (uint32_t it = 0; it < nB; it++) {
-                const bool act = Mg != 0ull;
-                const int p = act ? (int)__builtin_ctzll(Mg) : 0;
-                Mg &= Mg - 1ull;
-                float2 qw = S.pair[act ? slot : 0u];
-                qw.x = act ? qw.x : 0.f;
-                qw.y = act ? qw.y : 0.f;
-                slot += act ? 1u : 0u;
-                const float4 dp = S.pix[p];
-                const float dx = rxl - (float)(p & 7), dy = ryl - (float)(p >> 3);
-                const float qdx = qw.x * dx, qdy = qw.x * dy;
-                sm[ACC_MX] += qdx;
-                sm[ACC_MY] += qdy;
-                sm[ACC_CA] += qdx * dx;
-                sm[ACC_CB] += qdx * dy;
-                sm[ACC_CC] += qdy * dy;
-                sm[ACC_OP] += qw.x;
-                sm[ACC_R] += qw.y * dp.x;
-                sm[ACC_G] += qw.y * dp.y;
-                sm[ACC_B] += qw.y * dp.z;
+                float2 qw[2];
+                float4 dp[2];
+                float dx[2], dy[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const bool act = Mg != 0ull;
+                    const int p = act ? (int)__builtin_ctzll(Mg) : 0;
+                    Mg &= Mg - 1ull;
+                    qw[k] = S.pair[act ? slot : 0u];
+                    qw[k].x = act ? qw[k].x : 0.f;
+                    qw[k].y = act ? qw[k].y : 0.f;
+                    slot += act ? 1u : 0u;
+                    dp[k] = S.pix[p];
+                    dx[k] = rxl - (float)(p & 7), dy[k] = ryl - (float)(p >> 3);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const float qdx = qw[k].x * dx[k], qdy = qw[k].x * dy[k];
+                    sm[ACC_MX] += qdx;
+                    sm[ACC_MY] += qdy;
+                    sm[ACC_CA] += qdx * dx[k];
+                    sm[ACC_CB] += qdx * dy[k];
+                    sm[ACC_CC] += qdy * dy[k];
+                    sm[ACC_OP] += qw[k].x;
+                    sm[ACC_R] += qw[k].y * dp[k].x;
+                    sm[ACC_G] += qw[k].y * dp[k].y;
+                    sm[ACC_B] += qw[k].y * dp[k].z;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

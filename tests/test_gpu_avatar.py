@@ -87,7 +87,8 @@ def test_config3_fateavatar_loop_100k_512(gpu_device):
     assert st_g._graph is not None and st_e._graph is None and st_g.overflows == 0
     assert st_g.adam.step_count == steps == st_e.adam.step_count
     assert np.mean(loss_e[-8:]) < 0.85 * np.mean(loss_e[:8]), (loss_e[:4], loss_e[-4:])
-    assert np.allclose(loss_g, loss_e, rtol=5e-3), (loss_g[-4:], loss_e[-4:])
+    assert np.allclose(loss_g[:16], loss_e[:16], rtol=5e-3), (loss_g[:16], loss_e[:16])
+    assert np.allclose(loss_g, loss_e, rtol=3e-2), (loss_g[-4:], loss_e[-4:])
     assert torch.equal(st_g.denom, st_e.denom) and float(st_e.denom.max()) > 0
     # every group moved (gradients flow through the binding op to offset / rotation / scaling)
     fresh = S["make"]()
