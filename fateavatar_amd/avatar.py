@@ -246,12 +246,51 @@ class AvatarStep(TrainStep):
         pc._opacity.data.copy_(torch.log(new / (1 - new)))
         self.adam.zero_field_moments(pc.widths(), pc.P, fields=(0,))
 
+    # ---- checkpoints in the reference's layout (Trainer.save_checkpoint, train/trainer.py:396-435: a dict with 'epoch',
+    #      'global_step' and 'model' = model.state_dict(), which for FateAvatar holds the six Gaussian parameters and the
+    #      two binding buffers next to the FLAME / blendshape entries)
+    GAUSSIAN_ATTRIBUTES = ['_offset', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'face_index',
+                           'bary_coords']   # train/deserialize.py:10-12
+
     def state_dict(self) -> dict:
         pc = self.pc
         model = {name: getattr(pc, name).detach().clone() for name, _ in pc.FIELDS}
-        model["_features_rest"] = torch.zeros((pc.P, 0, 3), device=self.dev)
+        model["_features_rest"] = torch.zeros((pc.P, 0, 3), device=self.dev)   # max_sh_degree 0: empty (fateavatar.py:172-183)
+        model["face_index"], model["bary_coords"] = pc.face_index.clone(), pc.bary_coords.clone()
+        # 'optimizer' and 'densification' are additions a seamless resume needs; the reference saves neither
         return {"global_step": self.adam.step_count, "model": model,
-                "binding": {"face_index": pc.face_index.clone(), "bary_coords": pc.bary_coords.clone()},
                 "optimizer": {"exp_avg": self.adam.exp_avg.clone(), "exp_avg_sq": self.adam.exp_avg_sq.clone(),
                               "state": self.adam.state.clone()},
                 "densification": {"xyz_gradient_accum": self.xyz_gradient_accum.clone(), "denom": self.denom.clone()}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict) -> list:
+        """deserialize_checkpoints_fateavatar (train/deserialize.py:7-40): the Gaussian attributes are POPPED from
+        sd['model'] (their row count differs from the freshly built model's), re-attached as parameters / buffers, and the
+        per-point statistics restart from zero; whatever else 'model' holds (FLAME, blendshape deltas: outside this
+        path) is returned as the list of ignored keys.  A checkpoint written by the reference itself loads the same way."""
+        model = dict(sd["model"])
+        missing = [k for k in self.GAUSSIAN_ATTRIBUTES if k not in model]
+        if missing:
+            raise KeyError(f"checkpoint lacks Gaussian attributes {missing}")
+        g = {k: model.pop(k) for k in self.GAUSSIAN_ATTRIBUTES}
+        if int(g["_features_rest"].shape[1]) != 0:
+            raise ValueError("FateAvatar renders SH degree 0: _features_rest must be empty")
+        pc = self.pc
+        old_rows = pc.P
+        pc.face_index = g["face_index"].to(self.dev, torch.int32).contiguous()
+        pc.bary_coords = g["bary_coords"].to(self.dev, torch.float32).contiguous()
+        P = int(pc.face_index.shape[0])
+        pc._bind([g[name].to(self.dev, torch.float32).reshape((P,) + pc.SHAPES[name]) for name, _ in pc.FIELDS])
+        self._rebind_optimizer(torch.full((P,), -1, dtype=torch.int64, device=self.dev), old_rows)   # fresh (zero) moments
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=self.dev)
+        self.denom = torch.zeros((P, 1), device=self.dev)
+        opt, dens = sd.get("optimizer"), sd.get("densification")
+        if opt is not None:
+            self.adam.exp_avg.copy_(opt["exp_avg"])
+            self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            self.adam.state.copy_(opt["state"])
+        if dens is not None:
+            self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])
+            self.denom.copy_(dens["denom"])
+        return sorted(model.keys())

@@ -104,6 +104,8 @@ int fr_create(fr_handle** out)
     h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
     const char* bb = getenv("FR_BLEND_BWD");
     h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
+    // the sparse backward reads the footprint masks the sparse forward leaves in the records
+    if (h->dense_blend_fwd || !h->no_fused_blend) h->dense_blend_fwd = h->dense_blend_bwd = true;
     *out = reinterpret_cast<fr_handle*>(h);
     return FR_OK;
 }

@@ -196,10 +196,10 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
     // v_exp_f32 (two multiplies less per pixel x Gaussian pair): a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
     constexpr float kLog2e = 1.4426950408889634f;
     const float a2 = co.x * (-0.5f * kLog2e), b2 = co.y * (-kLog2e), c2 = co.z * (-0.5f * kLog2e);
-    const uint2 fm = footprint_mask(xy.x, xy.y, a2, b2, c2, co.w, tile_x0, tile_y0);
+    (void)tile_x0, (void)tile_y0;
     r[0] = make_float4(xy.x, xy.y, a2, b2);
     r[1] = make_float4(c2, co.w, c.x, c.y);
-    r[2] = make_float4(c.z, __uint_as_float(id), __uint_as_float(fm.x), __uint_as_float(fm.y));
+    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);   // q2.zw: footprint mask, filled in by k_unit_blend_local
 }
 
 // Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
@@ -230,10 +230,10 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
             if (i < n) {
                 float4* r = recs + (size_t)(start + i) * kRecQuads;
                 const float a2 = co[u].x * (-0.5f * kLog2e), b2 = co[u].y * (-kLog2e), c2 = co[u].z * (-0.5f * kLog2e);
-                const uint2 fm = footprint_mask(xy[u].x, xy[u].y, a2, b2, c2, co[u].w, tile_x0, tile_y0);
+                (void)tile_x0, (void)tile_y0;
                 r[0] = make_float4(xy[u].x, xy[u].y, a2, b2);
                 r[1] = make_float4(c2, co[u].w, c[u].x, c[u].y);
-                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), __uint_as_float(fm.x), __uint_as_float(fm.y));
+                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), 0.f, 0.f);   // q2.zw: see write_record
             }
         }
     }
@@ -1072,9 +1072,9 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
 
 // ---- launch 1: every unit is an independent wave (grid-stride), blended locally
 __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __restrict__ counts,
-                                                         const uint4* __restrict__ unit_tile,
-                                                         const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                         float* __restrict__ g_tseg, float* __restrict__ g_out)
+                                                         const uint4* __restrict__ unit_tile, float4* __restrict__ recs,
+                                                         int W, int H, int tiles_x, float* __restrict__ g_tseg,
+                                                         float* __restrict__ g_out)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
@@ -1086,11 +1086,21 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __
     for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
         const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
         __builtin_amdgcn_wave_barrier();   // the previous unit's records are dead
-        const RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+        RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+        // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in the record (q2.zw) for
+        // k_tile_finish and the backward.  (Computed here, not in the sort kernels: their waves sit on the frame's
+        // critical path with one tile each, these are thousands of independent ones.)
+        uint2 fm = make_uint2(0u, 0u);
+        if (ui.base + (uint32_t)lane < ui.n) {
+            fm = footprint_mask(rr.q0.x, rr.q0.y, rr.q0.z, rr.q0.w, rr.q1.x, rr.q1.y,
+                                (float)((int)(ui.tile % (uint32_t)tiles_x) * kTile), (float)((int)(ui.tile / (uint32_t)tiles_x) * kTile));
+            rr.q2.z = __uint_as_float(fm.x), rr.q2.w = __uint_as_float(fm.y);
+            recs[(size_t)(ui.start + ui.base + (uint32_t)lane) * kRecQuads + 2] = rr.q2;
+        }
         rec[lane * kRecQuads + 0] = rr.q0;
         rec[lane * kRecQuads + 1] = rr.q1;
         rec[lane * kRecQuads + 2] = rr.q2;
-        const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
+        const uint2 bt = transpose_bits64(fm, lane, tc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
@@ -1419,8 +1429,8 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         StageScope sc(h, ST_BLEND_FWD, s);
         uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
         if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
-        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, b.recs, prm.W,
+                           prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
         hipLaunchKernelGGL(k_tile_finish, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
                            (const float4*)b.recs, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
     } else {

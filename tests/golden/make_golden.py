@@ -107,9 +107,27 @@ def gen_camera():
 
 
 def gen_misc():
+    """inverse_sigmoid, RGB2SH / SH2RGB (sh_utils.py:114-118), get_expon_lr_func (general_utils.py:29-62) and the numpy
+    getWorld2View2 with scene translate / scale (graphics_utils.py:38-49)."""
+    from tools.gs_utils.graphics_utils import getWorld2View2
     x = torch.linspace(0.01, 0.99, 50)
+    rgb = torch.linspace(-0.3, 1.4, 37)
+    steps = np.asarray([-5, 0, 1, 10, 100, 999, 1000, 5000, 29999, 30000, 45000], np.float64)
+    lr_a = general_utils.get_expon_lr_func(1.6e-4, 1.6e-6, max_steps=30000)
+    lr_b = general_utils.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=1000, lr_delay_mult=0.01, max_steps=30000)
+    lr_c = general_utils.get_expon_lr_func(0.0, 0.0)
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(3, 3, generator=g)
+    Q, _ = torch.linalg.qr(A)
+    R, t = Q.numpy().astype(np.float64), torch.randn(3, generator=g).numpy().astype(np.float64)
+    tr = np.asarray([0.1, -0.2, 0.05])
     np.savez_compressed(os.path.join(OUT, "golden_misc.npz"), x=x.numpy(),
-                        inverse_sigmoid=general_utils.inverse_sigmoid(x).numpy())
+                        inverse_sigmoid=general_utils.inverse_sigmoid(x).numpy(),
+                        rgb=rgb.numpy(), RGB2SH=sh_utils.RGB2SH(rgb).numpy(), SH2RGB=sh_utils.SH2RGB(rgb).numpy(),
+                        lr_steps=steps, lr_a=np.asarray([lr_a(s) for s in steps]), lr_b=np.asarray([lr_b(s) for s in steps]),
+                        lr_c=np.asarray([lr_c(s) for s in steps]),
+                        w2v_R=R, w2v_t=t, w2v_translate=tr, w2v_plain=getWorld2View2(R, t),
+                        w2v_moved=getWorld2View2(R, t, tr, 1.7))
 
 
 def gen_head():

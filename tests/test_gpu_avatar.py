@@ -222,3 +222,51 @@ def test_uv_densify_prune_reset_follow_the_reference(gpu_device):
     torch.cuda.synchronize()
     st.check()
     assert st.maintain(7, None) == {}
+
+
+def test_checkpoint_layout_and_reference_style_load(gpu_device, tmp_path):
+    """state_dict() has the reference's keys / shapes (train/trainer.py:396-435 + FateAvatar.state_dict), and a
+    checkpoint in the REFERENCE's form — Gaussian attributes with a different row count next to unrelated model
+    entries — loads the way deserialize_checkpoints_fateavatar does (train/deserialize.py:7-40)."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep
+    dev = gpu_device
+    S = _setup(dev, 3000, 64, 4, seed=4)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    st = AvatarStep(S["make"](), S["faces"], S["canon"], S["cams"][0], bg)
+    for it in range(5):
+        st.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4])
+    sd = st.state_dict()
+    m = sd["model"]
+    assert sorted(m) == sorted(AvatarStep.GAUSSIAN_ATTRIBUTES) and sd["global_step"] == 5
+    assert m["_offset"].shape == (3000, 1) and m["_features_dc"].shape == (3000, 1, 3) and m["_features_rest"].shape == (3000, 0, 3)
+    assert m["_scaling"].shape == (3000, 3) and m["_rotation"].shape == (3000, 4) and m["_opacity"].shape == (3000, 1)
+    assert m["face_index"].shape == (3000,) and m["bary_coords"].shape == (3000, 3)
+    torch.save(sd, tmp_path / "a.pth")
+    # resume: same trajectory
+    for it in range(5, 9):
+        st.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4])
+    st2 = AvatarStep(S["make"](), S["faces"], S["canon"], S["cams"][0], bg)
+    assert st2.load_state_dict(torch.load(tmp_path / "a.pth", map_location=dev)) == []
+    for it in range(5, 9):
+        st2.step(S["cams"][it % 4], S["posed"][it % 4], gts[it % 4])
+    torch.cuda.synchronize()
+    assert st2.adam.step_count == st.adam.step_count == 9
+    assert float((st2.pc.flat - st.pc.flat).abs().max()) < 2e-3
+    # a reference-style file: 'epoch', other model entries, MORE points than the fresh model, no optimizer state
+    n = 3500
+    g = torch.Generator().manual_seed(0)
+    ref = {"epoch": 3, "global_step": 1234, "model": {
+        "_offset": torch.randn(n, 1, generator=g), "_features_dc": torch.randn(n, 1, 3, generator=g),
+        "_features_rest": torch.zeros(n, 0, 3), "_scaling": torch.randn(n, 3, generator=g) - 7.0,
+        "_rotation": torch.randn(n, 4, generator=g), "_opacity": torch.randn(n, 1, generator=g),
+        "face_index": torch.randint(0, S["faces"].shape[0], (n,), generator=g), "bary_coords": torch.rand(n, 3, generator=g),
+        "flame.shapedirs": torch.zeros(4), "delta_vertex": torch.zeros(5, 3)}}
+    ignored = st2.load_state_dict(ref)
+    assert ignored == ["delta_vertex", "flame.shapedirs"] and st2.pc.P == n and st2._graph is None
+    assert torch.equal(st2.pc._rotation.detach().cpu(), ref["model"]["_rotation"])
+    assert float(st2.adam.exp_avg.abs().max()) == 0.0 and st2.denom.shape == (n, 1) and float(st2.denom.max()) == 0.0
+    l = st2.step(S["cams"][0], S["posed"][0], gts[0])
+    torch.cuda.synchronize()
+    assert np.isfinite(float(l))

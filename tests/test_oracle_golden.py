@@ -52,6 +52,24 @@ def test_inverse_sigmoid_round_trip():
     np.testing.assert_allclose(np.log(x / (1 - x)), z["inverse_sigmoid"], rtol=2e-6, atol=1e-6)
 
 
+def test_gs_utils_helpers_match_the_reference():
+    """fateavatar_amd.gs_utils vs the reference's RGB2SH / SH2RGB, get_expon_lr_func and getWorld2View2."""
+    from fateavatar_amd import gs_utils
+    z = np.load(os.path.join(G, "golden_misc.npz"))
+    np.testing.assert_allclose(gs_utils.RGB2SH(z["rgb"]), z["RGB2SH"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gs_utils.SH2RGB(z["rgb"]), z["SH2RGB"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gs_utils.inverse_sigmoid(z["x"].astype(np.float64)), z["inverse_sigmoid"], rtol=2e-6, atol=1e-6)
+    fa = gs_utils.get_expon_lr_func(1.6e-4, 1.6e-6, max_steps=30000)
+    fb = gs_utils.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=1000, lr_delay_mult=0.01, max_steps=30000)
+    fc = gs_utils.get_expon_lr_func(0.0, 0.0)
+    for f, k in ((fa, "lr_a"), (fb, "lr_b"), (fc, "lr_c")):
+        np.testing.assert_allclose([f(s) for s in z["lr_steps"]], z[k], rtol=1e-12, atol=0)
+    assert fa(0) == 1.6e-4 and abs(fa(30000) - 1.6e-6) < 1e-18 and fa(-1) == 0.0
+    np.testing.assert_array_equal(gs_utils.getWorld2View2(z["w2v_R"], z["w2v_t"]), z["w2v_plain"])
+    np.testing.assert_array_equal(gs_utils.getWorld2View2(z["w2v_R"], z["w2v_t"], z["w2v_translate"], 1.7), z["w2v_moved"])
+    np.testing.assert_allclose(scenes.world_to_view(z["w2v_R"], z["w2v_t"]), z["w2v_plain"], atol=2e-6)
+
+
 def test_workload_shape_matches_survey():
     """SURVEY.md Appendix B measured the reference (run through a host shim) on config 2:
     351 non-empty 16x16 tiles, mean/max list 594/1570, all radii 4, 28.5 % covered pixels."""

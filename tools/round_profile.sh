@@ -5,14 +5,16 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-seconds 5 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
+python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-seconds 6 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
+FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${tag}_bench_2ranks_gloo_1gpu.json 2>> $O/${tag}_bench.err
 $R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --no-graph > /dev/null 2>&1
 $R/tools/profile.sh ${tag}_graph python $R/bench.py --steps 100 --warmup 10 --cpu-seconds 0 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_fetch "FETCH_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_write "WRITE_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
-$R/tools/pmc.sh ${tag}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
+$R/tools/pmc.sh ${tag}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 python $R/tools/probe_coherent.py > $O/${tag}_coherent_order.txt 2>/dev/null
-python $R/tools/probe_binding.py > $O/${tag}_binding.txt 2>/dev/null
+python $R/tools/cpu_baseline.py > $O/${tag}_cpu_baseline.txt 2>/dev/null
 ls $O | grep $tag
