@@ -180,7 +180,7 @@ int fr_read_counts(fr_handle* hh, fr_counts* counts)
     fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
     if (!h || !counts) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument");
     *counts = *h->host_counts;
-    return FR_OK;
+    return FR_OK;   // (valid once the frame's stream has been synchronised: the caller's responsibility)
 }
 
 int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,

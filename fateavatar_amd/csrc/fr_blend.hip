@@ -345,7 +345,8 @@ __device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32
 constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
-                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg)
+                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg,
+                                                   int take_long_lists)
 {
     __shared__ SortXchgT<4> sx;
     const bool overflow = v.counts->overflow != 0;
@@ -360,6 +361,17 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             const uint32_t tile = v.medium_list[item];
             sort_tile_group<4>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
                                (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+        }
+        // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
+        // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
+        // global-memory network — correct, just not fast; the next frame gets the big sorter back.
+        if (take_long_lists) {
+            const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
+            for (uint32_t item = blockIdx.x; item < nb + nl; item += kMediumSorters) {
+                const uint32_t tile = item < nb ? v.big_list[item] : v.large_list[item - nb];
+                sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+                                 (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+            }
         }
         return;
     }
@@ -1115,89 +1127,142 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __
 }
 
 // ---- launch 2: one wave per tile chains its units (running transmittance), re-walks a unit for the pixels that
-// terminate inside it, writes the image and the backward entry state of every unit
+// terminate inside it, writes the image and the backward entry state of every unit.  The kernel executes almost no
+// arithmetic: it is a chain of dependent memory round trips, so the partials of up to kFinishRegs units are requested
+// together and stay in registers (one round trip, not one per unit, and no re-read for the suffix pass).
+constexpr int kFinishRegs = 8;
+
+struct FinishUnit {
+    float cr, cg, cb, To;
+};
+
+// one unit of the chain: scale the local result by the transmittance entering it, re-walk the crossing pixels
+__device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr, float cg, float cb, uint32_t last_in,
+                                                  bool inside, float& Tin, bool& finished, float& Tf, uint32_t& ncon,
+                                                  const float4* __restrict__ trecs, uint32_t n, float4* rec, int lane,
+                                                  float fx, float fy)
+{
+    // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
+    const bool dead = !inside || finished || (Tin < 0.0001f);
+    const bool crosses = !dead && (Tin * tl < 0.0001f);
+    FinishUnit o;
+    o.cr = dead ? 0.f : Tin * cr, o.cg = dead ? 0.f : Tin * cg, o.cb = dead ? 0.f : Tin * cb;
+    o.To = dead ? Tin : Tin * tl;
+    uint32_t last = dead ? 0u : last_in;
+    if (__any(crosses)) {   // (a pixel crosses the threshold in at most one unit)
+        const TransposeConsts tc = transpose_consts(lane);
+        __builtin_amdgcn_wave_barrier();
+        const RecRegs rr = fetch_record(trecs, k * kUnit + (uint32_t)lane, n);
+        rec[lane * kRecQuads + 0] = rr.q0;
+        rec[lane * kRecQuads + 1] = rr.q1;
+        rec[lane * kRecQuads + 2] = rr.q2;
+        const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u64 Bp = crosses ? (((u64)bt.y << 32) | bt.x) : 0ull;
+        const WalkOut x = walk_unit_fwd<true>(rec, Bp, Tin, fx, fy, k * kUnit);
+        if (crosses) {
+            o.cr = x.Cr, o.cg = x.Cg, o.cb = x.Cb, o.To = x.T, last = x.last;
+            finished = x.term;
+        }
+    }
+    if (!dead) {
+        Tf = o.To;
+        if (last) ncon = last;
+    }
+    // what enters the next unit: the product of the units' products (the exact value where the unit was re-walked)
+    Tin = dead ? Tin : o.To;
+    return o;
+}
+
 __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                     const float4* __restrict__ recs, const float* __restrict__ g_tseg,
                                                     float* __restrict__ g_out, float4* __restrict__ unit_state, int W, int H,
                                                     const float* __restrict__ bg, float* __restrict__ out_color)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
-    if (counts->overflow) return;
     const uint32_t n_tiles = (uint32_t)v.tiles_x * v.tiles_y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = blockIdx.x * kWavesPerWG + wave;
     if (tile >= n_tiles) return;
+    // everything the tile needs first is requested in one go (the offset tables are valid even for an overflowed frame)
+    const uint32_t overflow = counts->overflow;
+    const uint32_t u0 = v.unit_offset[tile], u1 = v.unit_offset[tile + 1];
+    const uint32_t start = v.tile_offset[tile], n = v.tile_offset[tile + 1] - start;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    if (overflow) return;
+    const uint32_t nu = u1 - u0;
     const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
     const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
     const bool inside = px < W && py < H;
-    const uint32_t u0 = v.unit_offset[tile], nu = v.unit_offset[tile + 1] - u0;
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
     uint32_t ncon = 0;
     if (nu != 0) {
         float4* rec = s_rec_all[wave];
-        const uint32_t start = v.tile_offset[tile], n = v.tile_offset[tile + 1] - start;
         const float4* trecs = recs + (size_t)start * kRecQuads;
+        const float fx = (float)px, fy = (float)py;
         float Tin = 1.0f;
         bool finished = false;
-        for (uint32_t k = 0; k < nu; k++) {
-            float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
-            const float tl = g_tseg[(size_t)(u0 + k) * kUnit + lane];
-            float cr = out[0], cg = out[kUnit], cb = out[2 * kUnit];
-            uint32_t last = __float_as_uint(out[4 * kUnit]);
-            // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
-            const bool dead = !inside || finished || (Tin < 0.0001f);
-            const bool crosses = !dead && (Tin * tl < 0.0001f);
-            cr = dead ? 0.f : Tin * cr, cg = dead ? 0.f : Tin * cg, cb = dead ? 0.f : Tin * cb;
-            float To = dead ? Tin : Tin * tl;
-            last = dead ? 0u : last;
-            if (__any(crosses)) {   // (a pixel crosses the threshold in at most one unit)
-                const TransposeConsts tc = transpose_consts(lane);
-                __builtin_amdgcn_wave_barrier();
-                const RecRegs rr = fetch_record(trecs, k * kUnit + (uint32_t)lane, n);
-                rec[lane * kRecQuads + 0] = rr.q0;
-                rec[lane * kRecQuads + 1] = rr.q1;
-                rec[lane * kRecQuads + 2] = rr.q2;
-                const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const u64 Bp = crosses ? (((u64)bt.y << 32) | bt.x) : 0ull;
-                const WalkOut x = walk_unit_fwd<true>(rec, Bp, Tin, (float)px, (float)py, k * kUnit);
-                if (crosses) {
-                    cr = x.Cr, cg = x.Cg, cb = x.Cb, To = x.T, last = x.last;
-                    finished = x.term;
+        if (nu <= (uint32_t)kFinishRegs) {
+            float tl[kFinishRegs], cr[kFinishRegs], cg[kFinishRegs], cb[kFinishRegs];
+            uint32_t ls[kFinishRegs];
+#pragma unroll
+            for (int k = 0; k < kFinishRegs; k++) {
+                const uint32_t kk = (uint32_t)k < nu ? (uint32_t)k : 0u;   // (clamped: the loads stay unconditional)
+                const float* out = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+                tl[k] = g_tseg[(size_t)(u0 + kk) * kUnit + lane];
+                cr[k] = out[0], cg[k] = out[kUnit], cb[k] = out[2 * kUnit];
+                ls[k] = __float_as_uint(out[4 * kUnit]);
+            }
+            FinishUnit f[kFinishRegs];
+#pragma unroll
+            for (int k = 0; k < kFinishRegs; k++) {
+                if ((uint32_t)k < nu) {
+                    f[k] = finish_unit((uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs, n, rec,
+                                       lane, fx, fy);
+                    Cr += f[k].cr, Cg += f[k].cg, Cb += f[k].cb;
                 }
             }
-            // the unit's final contribution, kept for the suffix pass below (slot 3 = T at its far boundary)
-            out[0] = cr, out[kUnit] = cg, out[2 * kUnit] = cb, out[3 * kUnit] = To;
-            Cr += cr, Cg += cg, Cb += cb;
-            if (!dead) {
-                Tf = To;
-                if (last) ncon = last;
+            // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at
+            // the unit's far boundary (= what the reference's accum_rec recurrence yields there); guard: k_tile_combine
+            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+            for (int k = kFinishRegs - 1; k >= 0; k--) {
+                if ((uint32_t)k < nu) {
+                    const float inv = (f[k].To >= 0.0001f) ? __builtin_amdgcn_rcpf(f[k].To) : 0.f;
+                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, f[k].To);
+                    Sr += f[k].cr, Sg += f[k].cg, Sb += f[k].cb;
+                }
             }
-            // what enters the next unit: the PRODUCT of the units' products, as the backward's unit-parallel replay assumes
-            Tin = dead ? Tin : (crosses ? To : Tin * tl);
-        }
-        // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at the
-        // unit's far boundary (= what the reference's accum_rec recurrence yields there); see k_tile_combine for the guard
-        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-        for (uint32_t k = nu; k-- > 0;) {
-            const float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
-            const float To = out[3 * kUnit];
-            const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
-            unit_state[(size_t)(u0 + k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
-            Sr += out[0];
-            Sg += out[kUnit];
-            Sb += out[2 * kUnit];
+        } else {   // long tile: one unit at a time, the final contributions parked in the partial array
+            for (uint32_t k = 0; k < nu; k++) {
+                float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
+                const FinishUnit f = finish_unit(k, g_tseg[(size_t)(u0 + k) * kUnit + lane], out[0], out[kUnit], out[2 * kUnit],
+                                                 __float_as_uint(out[4 * kUnit]), inside, Tin, finished, Tf, ncon, trecs, n, rec, lane,
+                                                 fx, fy);
+                out[0] = f.cr, out[kUnit] = f.cg, out[2 * kUnit] = f.cb, out[3 * kUnit] = f.To;
+                Cr += f.cr, Cg += f.cg, Cb += f.cb;
+            }
+            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+            for (uint32_t k = nu; k-- > 0;) {
+                const float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
+                const float To = out[3 * kUnit];
+                const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
+                unit_state[(size_t)(u0 + k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
+                Sr += out[0];
+                Sg += out[kUnit];
+                Sb += out[2 * kUnit];
+            }
         }
     }
     if (inside) {
         v.final_T[pix] = Tf;
         v.n_contrib[pix] = ncon;
-        out_color[pix] = Cr + Tf * bg[0];
-        out_color[HW + pix] = Cg + Tf * bg[1];
-        out_color[2 * HW + pix] = Cb + Tf * bg[2];
+        out_color[pix] = Cr + Tf * bg0;
+        out_color[HW + pix] = Cg + Tf * bg1;
+        out_color[2 * HW + pix] = Cb + Tf * bg2;
     }
 }
 
@@ -1418,10 +1483,13 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     const uint32_t fgrid = unit_wgs < h->fused_grid ? unit_wgs : h->fused_grid;
     {
         StageScope sc(h, ST_SORT, s);
+        // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
+        // longer than 1024 (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
+        const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           fused ? b.unit_tseg : nullptr);  // small_blocks == Q
-        hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
+                           fused ? b.unit_tseg : nullptr, launch_big ? 0 : 1);  // small_blocks == Q
+        if (launch_big) hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;

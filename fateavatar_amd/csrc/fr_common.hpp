@@ -211,6 +211,7 @@ struct fr_handle_impl {
     fr_counts* host_counts;      // pinned, mapped
     fr_counts* host_counts_dev;  // device view of the same memory
     hipEvent_t counts_ready;
+    bool counts_seen = false;    // host_counts holds the counts of a completed frame of this handle
     // per-tile instance counters (see ImageView): device memory owned by the handle, all zero between frames
     uint32_t* tile_counters = nullptr;
     size_t tile_counter_tiles = 0;

@@ -767,6 +767,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     if (no_wait) return FR_OK;
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).
     FR_HIP(hipEventSynchronize(h->counts_ready));
+    h->counts_seen = true;
     fr_counts c = *h->host_counts;
     if (counts) *counts = c;
     if (c.overflow) return FR_ERR_BINNING_CAPACITY;

@@ -752,3 +752,25 @@ def test_experimental_fused_blend_kernel_stays_correct(gpu_device):
     env = dict(os.environ, FR_FUSED_BLEND="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "fused-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_long_lists_without_the_big_sorter_launch(gpu_device):
+    """The big-list sorter is only launched when the previous frame had a list longer than 1024; a frame whose long
+    lists come as a surprise is sorted by the slow path inside k_tile_sort and must be just as correct.  Frame order:
+    short lists -> long lists (slow path) -> long lists again (big sorter) -> short lists."""
+    rng = np.random.default_rng(3)
+    short = SCENES["rand_deg0"]
+    long_ = scenes.random_scene(3000, 32, 32, sh_degree=0, seed=9, spread=0.004, scale_lo=0.002, scale_hi=0.004,
+                                opacity_lo=0.02, opacity_hi=0.05)
+    long_.means3D[:, 2] = 1.0 + rng.uniform(0, 0.5, long_.P).astype(np.float32)
+    o_short, o_long = util.oracle_forward(short), util.oracle_forward(long_)
+    h = util.HipFrame(short, gpu_device)
+    assert h.counts.max_tile_list <= 1024
+    _check_forward(o_short, h, "short-1")
+    for tag in ("long-surprise", "long-again"):
+        h = util.HipFrame(long_, gpu_device)
+        assert h.counts.max_tile_list > 1024
+        _check_forward(o_long, h, tag)
+        dpix = (rng.uniform(-1, 1, (3, 32, 32)) / (32 * 32)).astype(np.float32)
+        _check_backward(o_long, h, dpix, tag)
+    _check_forward(o_short, util.HipFrame(short, gpu_device), "short-2")
