@@ -199,7 +199,7 @@ __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_
     (void)tile_x0, (void)tile_y0;
     r[0] = make_float4(xy.x, xy.y, a2, b2);
     r[1] = make_float4(c2, co.w, c.x, c.y);
-    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);   // q2.zw: footprint mask, filled in by k_unit_blend_local
+    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);   // (q2.zw: the footprint mask while a unit is staged in LDS)
 }
 
 // Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
@@ -1084,8 +1084,9 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
 
 // ---- launch 1: every unit is an independent wave (grid-stride), blended locally
 __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __restrict__ counts,
-                                                         const uint4* __restrict__ unit_tile, float4* __restrict__ recs,
-                                                         int W, int H, int tiles_x, float* __restrict__ g_tseg,
+                                                         const uint4* __restrict__ unit_tile,
+                                                         const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
+                                                         int H, int tiles_x, float* __restrict__ g_tseg,
                                                          float* __restrict__ g_out)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
@@ -1099,15 +1100,15 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __
         const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
         __builtin_amdgcn_wave_barrier();   // the previous unit's records are dead
         RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
-        // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in the record (q2.zw) for
-        // k_tile_finish and the backward.  (Computed here, not in the sort kernels: their waves sit on the frame's
-        // critical path with one tile each, these are thousands of independent ones.)
+        // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in `masks` for k_tile_finish
+        // and the backward.  (Computed here, not in the sort kernels: their waves sit on the frame's critical path
+        // with one tile each, these are thousands of independent ones.)
         uint2 fm = make_uint2(0u, 0u);
         if (ui.base + (uint32_t)lane < ui.n) {
             fm = footprint_mask(rr.q0.x, rr.q0.y, rr.q0.z, rr.q0.w, rr.q1.x, rr.q1.y,
                                 (float)((int)(ui.tile % (uint32_t)tiles_x) * kTile), (float)((int)(ui.tile / (uint32_t)tiles_x) * kTile));
             rr.q2.z = __uint_as_float(fm.x), rr.q2.w = __uint_as_float(fm.y);
-            recs[(size_t)(ui.start + ui.base + (uint32_t)lane) * kRecQuads + 2] = rr.q2;
+            masks[(size_t)ui.start + ui.base + (uint32_t)lane] = fm;
         }
         rec[lane * kRecQuads + 0] = rr.q0;
         rec[lane * kRecQuads + 1] = rr.q1;
@@ -1139,8 +1140,8 @@ struct FinishUnit {
 // one unit of the chain: scale the local result by the transmittance entering it, re-walk the crossing pixels
 __device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr, float cg, float cb, uint32_t last_in,
                                                   bool inside, float& Tin, bool& finished, float& Tf, uint32_t& ncon,
-                                                  const float4* __restrict__ trecs, uint32_t n, float4* rec, int lane,
-                                                  float fx, float fy)
+                                                  const float4* __restrict__ trecs, const uint2* __restrict__ tmasks,
+                                                  uint32_t n, float4* rec, int lane, float fx, float fy)
 {
     // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
     const bool dead = !inside || finished || (Tin < 0.0001f);
@@ -1153,10 +1154,11 @@ __device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr
         const TransposeConsts tc = transpose_consts(lane);
         __builtin_amdgcn_wave_barrier();
         const RecRegs rr = fetch_record(trecs, k * kUnit + (uint32_t)lane, n);
+        const uint2 fm = (k * kUnit + (uint32_t)lane < n) ? tmasks[k * kUnit + (uint32_t)lane] : make_uint2(0u, 0u);
         rec[lane * kRecQuads + 0] = rr.q0;
         rec[lane * kRecQuads + 1] = rr.q1;
         rec[lane * kRecQuads + 2] = rr.q2;
-        const uint2 bt = transpose_bits64(make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w)), lane, tc);
+        const uint2 bt = transpose_bits64(fm, lane, tc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u64 Bp = crosses ? (((u64)bt.y << 32) | bt.x) : 0ull;
@@ -1176,7 +1178,8 @@ __device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr
 }
 
 __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                    const float4* __restrict__ recs, const float* __restrict__ g_tseg,
+                                                    const float4* __restrict__ recs, const uint2* __restrict__ masks,
+                                                    const float* __restrict__ g_tseg,
                                                     float* __restrict__ g_out, float4* __restrict__ unit_state, int W, int H,
                                                     const float* __restrict__ bg, float* __restrict__ out_color)
 {
@@ -1202,6 +1205,7 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
     if (nu != 0) {
         float4* rec = s_rec_all[wave];
         const float4* trecs = recs + (size_t)start * kRecQuads;
+        const uint2* tmasks = masks + start;
         const float fx = (float)px, fy = (float)py;
         float Tin = 1.0f;
         bool finished = false;
@@ -1220,8 +1224,8 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
 #pragma unroll
             for (int k = 0; k < kFinishRegs; k++) {
                 if ((uint32_t)k < nu) {
-                    f[k] = finish_unit((uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs, n, rec,
-                                       lane, fx, fy);
+                    f[k] = finish_unit((uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs, tmasks, n,
+                                       rec, lane, fx, fy);
                     Cr += f[k].cr, Cg += f[k].cg, Cb += f[k].cb;
                 }
             }
@@ -1240,8 +1244,8 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
             for (uint32_t k = 0; k < nu; k++) {
                 float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
                 const FinishUnit f = finish_unit(k, g_tseg[(size_t)(u0 + k) * kUnit + lane], out[0], out[kUnit], out[2 * kUnit],
-                                                 __float_as_uint(out[4 * kUnit]), inside, Tin, finished, Tf, ncon, trecs, n, rec, lane,
-                                                 fx, fy);
+                                                 __float_as_uint(out[4 * kUnit]), inside, Tin, finished, Tf, ncon, trecs, tmasks, n, rec,
+                                                 lane, fx, fy);
                 out[0] = f.cr, out[kUnit] = f.cg, out[2 * kUnit] = f.cb, out[3 * kUnit] = f.To;
                 Cr += f.cr, Cg += f.cg, Cb += f.cb;
             }
@@ -1298,8 +1302,8 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
         S.rec[lane * kRecQuads + 0] = rr.q0;
         S.rec[lane * kRecQuads + 1] = rr.q1;
-        S.rec[lane * kRecQuads + 2] = rr.q2;
-        const uint2 mj = make_uint2(__float_as_uint(rr.q2.z), __float_as_uint(rr.q2.w));
+        const uint2 mj = (ui.base + (uint32_t)lane < ui.n) ? b.masks[(size_t)ui.start + ui.base + (uint32_t)lane] : make_uint2(0u, 0u);
+        S.rec[lane * kRecQuads + 2] = make_float4(rr.q2.x, rr.q2.y, __uint_as_float(mj.x), __uint_as_float(mj.y));
         const u64 Mj = ((u64)mj.y << 32) | mj.x;
         const uint32_t cnt = (uint32_t)__popcll(Mj);
         const uint32_t cum = wave_incl_scan_u32(cnt);             // pairs of records [0, lane]
@@ -1497,10 +1501,11 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         StageScope sc(h, ST_BLEND_FWD, s);
         uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
         if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
-        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile, b.recs, prm.W,
-                           prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
         hipLaunchKernelGGL(k_tile_finish, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
-                           (const float4*)b.recs, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
+                           (const float4*)b.recs, (const uint2*)b.masks, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H,
+                           in.background, out_color);
     } else {
         StageScope sc(h, ST_BLEND_FWD, s);
         if (fused) {

@@ -173,6 +173,7 @@ struct BinningView {
     size_t cap, unit_cap;
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
     float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
+    uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_local writes it, the backward reads it)
     uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile, segment, list start, list length)
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
     float* unit_out;      // [unit_cap*5*64] forward partials per pixel: Cr, Cg, Cb, T_out, (last | done<<31)
@@ -186,6 +187,7 @@ struct BinningView {
         b.unit_cap = units_for(cap, T);
         b.recs = carve<float4>(p, cap * 3);
         b.keys = carve<uint64_t>(p, cap);
+        b.masks = carve<uint2>(p, cap);
         b.unit_tile = carve<uint4>(p, b.unit_cap);
         b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
         b.unit_out = carve<float>(p, b.unit_cap * 5 * kUnit);

@@ -282,6 +282,13 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             }
 
             const float opacity = a.raw ? act_sigmoid(in_opacity) : in_opacity;
+            // Contract: a Gaussian whose projected state is not finite (NaN / inf position, scale,
+            // rotation, opacity or colour) is DROPPED like a culled one — radius 0, no instances, zero gradient rows —
+            // instead of spreading NaN over the image and every gradient as the reference's arithmetic would.
+            {
+                const float chk = (((pix_x + pix_y) + (conic_a + conic_b + conic_c)) + (col[0] + col[1] + col[2])) + (opacity + p_view.z);
+                if (!(fabsf(chk) < 3.0e38f)) break;
+            }
             radius_out = mr;
             a.g.depth[idx] = p_view.z;
             a.g.means2D[idx] = make_float2(pix_x, pix_y);

@@ -774,3 +774,31 @@ def test_long_lists_without_the_big_sorter_launch(gpu_device):
         dpix = (rng.uniform(-1, 1, (3, 32, 32)) / (32 * 32)).astype(np.float32)
         _check_backward(o_long, h, dpix, tag)
     _check_forward(o_short, util.HipFrame(short, gpu_device), "short-2")
+
+
+def test_non_finite_gaussians_are_dropped_not_propagated(gpu_device):
+    """Contract: a Gaussian with a non-finite opacity, scale or position is dropped — no instance, no
+    contribution, zero gradient rows — instead of poisoning the image as the reference's arithmetic would; every other
+    Gaussian renders exactly as if the bad ones were not there."""
+    s = scenes.random_scene(1500, 64, 80, sh_degree=1, seed=31)
+    bad = np.zeros(s.P, bool)
+    bad[[3, 400, 777, 1200]] = True
+    clean = scenes.GaussianScene(s.means3D[~bad], s.scales[~bad], s.rotations[~bad], s.opacities[~bad], s.shs[~bad],
+                                 s.sh_degree, s.bg, s.camera)
+    s.opacities[3, 0] = np.nan
+    s.scales[400, 1] = np.inf
+    s.means3D[777, 0] = np.nan
+    s.opacities[1200, 0] = -np.inf
+    h = util.HipFrame(s, gpu_device)
+    hc = util.HipFrame(clean, gpu_device)
+    col = h.color.cpu().numpy()
+    assert np.isfinite(col).all()
+    np.testing.assert_array_equal(col, hc.color.cpu().numpy())
+    np.testing.assert_array_equal(h.final_T.cpu().numpy(), hc.final_T.cpu().numpy())
+    rng = np.random.default_rng(1)
+    dpix = (rng.uniform(-1, 1, (3, 64, 80)) / (64 * 80)).astype(np.float32)
+    g, gc = h.backward(dpix), hc.backward(dpix)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert np.isfinite(g[k]).all(), k
+        assert np.abs(g[k][bad]).max() == 0, k
+        assert util.rel_l2(g[k][~bad], gc[k]) < 1e-5, k
