@@ -124,6 +124,7 @@ int fr_destroy(fr_handle* hh)
     (void)hipHostFree(h->host_counts);
     if (h->tile_counters) (void)hipFree(h->tile_counters);
     if (h->accum) (void)hipFree(h->accum);
+    if (h->key_buckets) (void)hipFree(h->key_buckets);
     delete h;
     return FR_OK;
 }

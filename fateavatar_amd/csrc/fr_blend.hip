@@ -50,6 +50,35 @@ __device__ __forceinline__ u64 lane_xor_u64(u64 v, int lane)
     const uint32_t hi = (uint32_t)lane_xor_i32<MASK>((int)(uint32_t)(v >> 32), lane);
     return ((u64)hi << 32) | lo;
 }
+// Where a tile's unsorted keys live: eight per-XCD buckets (ImageView::buckets), sub-list x starting at position
+// sub[x] of the tile's list.  key(i) = i-th key of the tile in that concatenation order.
+struct KeySrc {
+    const u64* base;     // bucket of XCD 0 of this tile
+    uint32_t cap;        // keys per bucket
+    uint32_t sub[kXcds]; // start of every XCD's sub-list (sub[0] == 0)
+    __device__ __forceinline__ u64 key(uint32_t i) const
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 1; k < kXcds; k++) x += (i >= sub[k]) ? 1u : 0u;   // sub[] ascends: x = last sub-list starting at or before i
+        uint32_t s0 = sub[0];
+#pragma unroll
+        for (int k = 1; k < kXcds; k++) s0 = (x == (uint32_t)k) ? sub[k] : s0;
+        return base[(size_t)x * cap + (i - s0)];
+    }
+};
+__device__ __forceinline__ KeySrc key_src(const ImageView& v, uint32_t tile)
+{
+    KeySrc ks;
+    ks.base = reinterpret_cast<const u64*>(v.buckets) + (size_t)tile * kXcds * v.bucket_cap;
+    ks.cap = v.bucket_cap;
+    const uint4 a = *reinterpret_cast<const uint4*>(v.tile_sub + (size_t)tile * kSubWords);
+    const uint4 b = *reinterpret_cast<const uint4*>(v.tile_sub + (size_t)tile * kSubWords + 4);
+    ks.sub[0] = a.x, ks.sub[1] = a.y, ks.sub[2] = a.z, ks.sub[3] = a.w;
+    ks.sub[4] = b.x, ks.sub[5] = b.y, ks.sub[6] = b.z, ks.sub[7] = b.w;
+    return ks;
+}
+
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
@@ -240,14 +269,14 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
 }
 
 template <int K>
-__device__ __forceinline__ void sort_tile_regs(const u64* keys, float4* recs, uint32_t start, uint32_t n, int lane,
+__device__ __forceinline__ void sort_tile_regs(const KeySrc& keys, float4* recs, uint32_t start, uint32_t n, int lane,
                                                const GeomView& g, float tile_x0, float tile_y0)
 {
     u64 v[K];
 #pragma unroll
     for (int r = 0; r < K; r++) {
         const uint32_t i = (uint32_t)(r * 64 + lane);
-        v[r] = i < n ? keys[start + i] : ~0ull;
+        v[r] = i < n ? keys.key(i) : ~0ull;
     }
     wave_sort<K>(v, lane);
     write_records<K>(recs, start, n, 0u, v, lane, g, tile_x0, tile_y0);
@@ -278,7 +307,7 @@ __device__ __forceinline__ void cross_wave_stage(u64 (&v)[K], SortXchg& sx, int 
 }
 
 template <int K>
-__device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
+__device__ void sort_tile_group(const KeySrc& keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
                                 const GeomView& g, SortXchg& sx, float tile_x0, float tile_y0)
 {
     constexpr int KW = 64 * K;  // keys per wave
@@ -286,7 +315,7 @@ __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, u
 #pragma unroll
     for (int r = 0; r < K; r++) {
         const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
-        v[r] = i < n ? keys[start + i] : ~0ull;
+        v[r] = i < n ? keys.key(i) : ~0ull;
     }
     wave_sort<K>(v, lane);
     // blocks of 2*KW: flip with wave ^ 1, then register / lane distances inside the wave
@@ -306,13 +335,15 @@ __device__ void sort_tile_group(const u64* keys, float4* recs, uint32_t start, u
 // in global memory by one 256-thread workgroup (virtual +inf padding: a compare-exchange whose
 // upper index is >= n is a no-op in the flip formulation).  Agent-scope accesses keep the data
 // out of the per-CU L1 so that waves of the workgroup see each other's stores.
-__device__ void sort_tile_global(u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g, float tile_x0,
-                                 float tile_y0)
+__device__ void sort_tile_global(const KeySrc& src, u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g,
+                                 float tile_x0, float tile_y0)
 {
-    u64* seg = keys + start;
+    u64* seg = keys + start;   // contiguous scratch segment of the tile inside the binning buffer
     uint32_t N = 1;
     while (N < n) N <<= 1;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    for (uint32_t i = tid; i < n; i += nt) __hip_atomic_store(seg + i, src.key(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     auto stage = [&](uint32_t mask) {
         for (uint32_t i = tid; i < N; i += nt) {
             const uint32_t p = i ^ mask;
@@ -359,7 +390,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
         const uint32_t nm = v.counts->medium_tiles;
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group<4>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+            sort_tile_group<4>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
                                (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
         }
         // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
@@ -369,7 +400,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
             for (uint32_t item = blockIdx.x; item < nb + nl; item += kMediumSorters) {
                 const uint32_t tile = item < nb ? v.big_list[item] : v.large_list[item - nb];
-                sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+                sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
                                  (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
             }
         }
@@ -380,13 +411,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     {
         const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
         if (tile < T) {
-            if (overflow) {
-                // the emit pass did not run, so its count-down of the overflow counters did not happen: zero them here
-                // (the scan already zeroed tile_count) so that the next frame finds clean counters
-                if (lane < kXcds)
-                    v.tile_over[(size_t)lane * v.tpad + v.counter_index(tile % (uint32_t)v.tiles_x, tile / (uint32_t)v.tiles_x)] = 0u;
-                return;
-            }
+            if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_offset[tile + 1] - start;
             // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
@@ -398,9 +423,10 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
                 for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
                 const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
-                if (n <= 64) sort_tile_regs<1>(keys, recs, start, n, lane, g, tx0, ty0);
-                else if (n <= 128) sort_tile_regs<2>(keys, recs, start, n, lane, g, tx0, ty0);
-                else sort_tile_regs<4>(keys, recs, start, n, lane, g, tx0, ty0);
+                const KeySrc ks = key_src(v, tile);
+                if (n <= 64) sort_tile_regs<1>(ks, recs, start, n, lane, g, tx0, ty0);
+                else if (n <= 128) sort_tile_regs<2>(ks, recs, start, n, lane, g, tx0, ty0);
+                else sort_tile_regs<4>(ks, recs, start, n, lane, g, tx0, ty0);
             }
         }
     }
@@ -420,12 +446,12 @@ __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, f
     const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
     for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
         const uint32_t tile = v.big_list[item];
-        sort_tile_group<16>(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+        sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
                             (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
     for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
         const uint32_t tile = v.large_list[item];
-        sort_tile_global(keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+        sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
                          (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
 }

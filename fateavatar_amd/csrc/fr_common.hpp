@@ -14,8 +14,8 @@ constexpr int kTile = 8;    // 8x8 pixels = one wavefront
 constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): radii / num_rendered semantics
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
 constexpr int kXcds = 8;          // binning counters are privatised per XCD (indexed by HW_REG_XCC_ID & 7)
-constexpr int kSubWords = 16;     // per-tile sub-segment table: starts of the 8 per-XCD sub-segments + of their overflow parts
-constexpr int kInlineSlots = 8;   // instances per Gaussian whose segment position is remembered from the counting pass
+constexpr int kSubWords = 8;      // per-tile sub-list table: start (within the tile's list) of each XCD's sub-list
+constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
 constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)
 constexpr int kSortRegMax = 4096;    // longest list k_tile_sort_big sorts in registers (4 waves x 16 keys per lane);
@@ -55,18 +55,13 @@ struct GeomView {
     float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
     float4* rgba;           // [P] colour fed to the blend (SH result or colors_precomp), w unused
     float* cov3D;           // [P*6]
-    uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive
+    uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive (diagnostics)
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
-    float* cull_tau2;       // [P] threshold of the per-tile footprint test: a pixel can only reach alpha >= 1/255 where
-                            //     a dx^2 + 2 b dx dy + c dy^2 <= cull_tau2 (evaluation slack included; +inf = never cull)
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward.  NOT part of the geometry
                             // buffer: they belong to the handle (fr_handle_impl::accum), are all zero between
                             // backward passes (k_preprocess_bwd zeroes each row after reading it) and so cost the
                             // forward no zeroing writes; launch_forward / launch_backward point this member at them
     uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
-    uint32_t* block_xcc;        // [ceil(P/256)] XCD the preprocess workgroup ran on (whose counters it used)
-    uint32_t* inline_slots;     // [P*kInlineSlots] position inside its tile's segment of each of a Gaussian's first
-                                // kInlineSlots instances (handed out by the counting atomic of the preprocess)
     static GeomView make(void* buf, size_t P)
     {
         char* p = static_cast<char*>(buf);
@@ -78,18 +73,15 @@ struct GeomView {
         g.cov3D = carve<float>(p, P * 6);
         g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
-        g.cull_tau2 = carve<float>(p, P);
         g.accum = nullptr;
         g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
-        g.block_xcc = carve<uint32_t>(p, (P + 255) / 256 + 1);
-        g.inline_slots = carve<uint32_t>(p, P * kInlineSlots);
         return g;
     }
     static size_t bytes(size_t P)
     {
         char* p = nullptr;
         GeomView g = make(p, P);
-        return reinterpret_cast<size_t>(g.inline_slots + P * kInlineSlots) + 256;
+        return reinterpret_cast<size_t>(g.block_ref_tiles + (P + 255) / 256 + 1) + 256;
     }
 };
 
@@ -115,9 +107,12 @@ struct ImageView {
     // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
     // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
     // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
-    uint32_t* tile_count;    // [kXcds][tpad] instances with a remembered position, counted by XCD x (block-major, counter_index)
-    uint32_t* tile_over;     // [kXcds][tpad] instances beyond kInlineSlots of their Gaussian, counted by XCD x
-    uint32_t* tile_sub;      // [T][kSubWords] starts (relative to tile_offset) of sub-segment x [0..7] and of its overflow part [8..15]
+    uint32_t* tile_count;    // [kXcds][tpad] instances counted by XCD x (block-major, counter_index), then one word:
+                             // the largest (tile, XCD) count of the frame (k_tile_totals -> k_scan_tiles, which zeroes it)
+    uint64_t* buckets;       // [T][kXcds][bucket_cap] the keys of the instances, written by the counting pass itself:
+                             // slot s of (tile, XCD x) is the s-th instance XCD x counted into the tile (handle-owned)
+    uint32_t bucket_cap;
+    uint32_t* tile_sub;      // [T][kSubWords] start, within the tile's list, of each XCD's sub-list
     uint32_t tpad;           // row pitch of the two counter arrays
     uint32_t* tile_total;    // [T rounded up to 16] instances per tile (sum over the XCD copies), written by k_tile_totals for the scan
     uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
@@ -142,7 +137,7 @@ struct ImageView {
         v.tiles_y = (H + kTile - 1) / kTile;
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
-        v.tile_count = v.tile_over = nullptr;
+        v.tile_count = nullptr, v.buckets = nullptr, v.bucket_cap = 0;
         // counters are stored in 4x4-tile blocks (one 64-byte line per block): lanes of one atomic instruction that
         // fall into the same line are merged into ONE request (27 requests/ns vs 250 lane-atomics/ns,
         // tools/micro_atomics.hip), and the tiles of one Gaussian's rectangle are 2-D neighbours
@@ -218,6 +213,11 @@ struct fr_handle_impl {
     uint32_t* tile_counters = nullptr;
     size_t tile_counter_tiles = 0;
     bool counters_clean = false;
+    // key buckets (ImageView::buckets): [tiles][8 XCDs][bucket_cap] u64, handle-owned; the capacity doubles when a
+    // frame reports a (tile, XCD) count above it (that frame is invalid and the caller repeats it)
+    uint64_t* key_buckets = nullptr;
+    size_t bucket_tiles = 0;
+    uint32_t bucket_cap = 0;
     // gradient accumulators of the blend backward (GeomView::accum): device memory owned by the handle, all zero
     // between backward passes
     float* accum = nullptr;

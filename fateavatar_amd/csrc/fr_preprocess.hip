@@ -33,7 +33,8 @@ struct PreArgs {
     uint8_t* visible;       // optional (fr_aux): radii > 0
     GeomView g;
     uint32_t* tile_count;
-    uint32_t* tile_over;
+    uint64_t* buckets;      // key buckets [tiles][8][bucket_cap]
+    uint32_t bucket_cap;
     uint32_t tpad;          // row pitch of the per-XCD counter copies
     DeviceCounts* counts;
     int tiles_x, tiles_y;   // 8x8 tiles
@@ -113,7 +114,7 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
 // the ellipse q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2 around `ctr`; the minimum of the convex q over the tile's
 // pixel rectangle is at the centre if that is inside, otherwise on an edge FACING the centre (walking from the
 // minimiser towards the centre decreases q and can only leave the rectangle through such an edge).  Evaluated in
-// double from the float geometry, so that k_preprocess_fwd (counting) and k_emit_instances (writing) take the same
+// double from the float geometry, so that every pass that asks (k_preprocess_fwd counts and writes the instance in one go) takes the same
 // decision; the slack for the blend kernels' fp32 arithmetic is inside tau2.
 __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, const float2 ctr, uint32_t tx, uint32_t ty)
 {
@@ -137,7 +138,7 @@ __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, 
 }
 
 constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
-constexpr int kCountLdsBytes = 2304 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
+constexpr int kCountLdsBytes = 2816 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
 
 __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 {
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     uint2 rect = make_uint2(0u, 0u);
     float4 cull = make_float4(0.f, 0.f, 0.f, __builtin_inff());  // conic + footprint threshold (per-tile culling)
     float2 ctr = make_float2(0.f, 0.f);
+    float key_depth = 0.f;   // view-space z: the sort key of this Gaussian's instances
     if (idx < a.P) {
         int radius_out = 0;
         do {
@@ -291,6 +293,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             }
             radius_out = mr;
             a.g.depth[idx] = p_view.z;
+            key_depth = p_view.z;
             a.g.means2D[idx] = make_float2(pix_x, pix_y);
             a.g.conic_opacity[idx] = make_float4(conic_a, conic_b, conic_c, opacity);
             a.g.rgba[idx] = make_float4(col[0], col[1], col[2], 0.f);
@@ -329,12 +332,12 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         a.radii[idx] = radius_out;
         if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
         a.g.rect[idx] = rect;
-        a.g.cull_tau2[idx] = cull.w;
     }
-    // ---- count the (tile, Gaussian) instances.  The atomic that counts an instance also hands out its
-    // position inside the tile's segment, which is remembered (first kInlineSlots instances of a Gaussian) so
-    // that the emit pass needs no second atomic.  The wave spreads its instances over its lanes: one returning
-    // atomic round trip per 64 instances instead of one per tile of the widest rectangle.
+    // ---- count the (tile, Gaussian) instances AND write their keys.  The atomic that counts an instance hands out
+    // its slot in the (tile, XCD) key bucket, and the key goes there at once: no second pass over the Gaussians (the
+    // reference's duplicateWithKeys, rasterizer_impl.cu:70-111) and no scan in front of it.  The wave spreads its
+    // instances over its lanes: one returning atomic round trip per 64 instances instead of one per tile of the
+    // widest rectangle.
     {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the SH rows have been read: reuse their space
         __builtin_amdgcn_wave_barrier();
@@ -343,13 +346,15 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         uint2* s_rect = reinterpret_cast<uint2*>(cl + 1024);                              // [64]    512 B
         float2* s_ctr = reinterpret_cast<float2*>(cl + 1536);                             // [64]    512 B
         uint32_t* s_excl = reinterpret_cast<uint32_t*>(cl + 2048);                        // [64]    256 B
-        volatile uint32_t* s_gkey = reinterpret_cast<volatile uint32_t*>(cl + 2304);      // [4][64] 1024 B (lanes talk through it)
-        volatile uint32_t* s_gbase = reinterpret_cast<volatile uint32_t*>(cl + 3328);     // [4][64] 1024 B
-        uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 4352);                        // [4][64] 1024 B  -> kCountLdsBytes
+        uint2* s_gk = reinterpret_cast<uint2*>(cl + 2304);                                // [64]    512 B  (id, depth bits)
+        volatile uint32_t* s_gkey = reinterpret_cast<volatile uint32_t*>(cl + 2816);      // [4][64] 1024 B (lanes talk through it)
+        volatile uint32_t* s_gbase = reinterpret_cast<volatile uint32_t*>(cl + 3840);     // [4][64] 1024 B
+        uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 4864);                        // [4][64] 1024 B  -> kCountLdsBytes
         s_cull[lane] = cull;
         s_ctr[lane] = ctr;
         const int w = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), h = (int)(rect.y >> 16) - (int)(rect.x >> 16);
         const uint32_t n = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
+        s_gk[lane] = make_uint2((uint32_t)idx, __float_as_uint(key_depth));
         uint32_t incl = n;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(incl, off);
@@ -360,25 +365,23 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
         s_rect[lane] = rect;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int wave_first = blockIdx.x * 256 + wave * 64;
         // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
         // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several)
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
-        if (threadIdx.x == 0) a.g.block_xcc[blockIdx.x] = xcc;
         // Wave-level aggregation: lanes of one pass that count into the SAME counter (Gaussians stored in a spatially
         // coherent order, e.g. the reference's UV-raster initialisation, hit a handful of tiles per wave) are grouped
         // through a 64-slot table in LDS keyed by the counter index: the group's first lane issues ONE global atomic
         // for the whole group.  Lanes whose slot is taken by another counter fall back to their own atomic, so with
         // random orders (all counters distinct) nothing is lost but a few LDS operations.
         for (uint32_t b0 = 0; b0 < total; b0 += 64 * kCountUnroll) {   // wave-uniform trip count
-            uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll];
-            size_t where[kCountUnroll];
-            bool valid[kCountUnroll], grouped[kCountUnroll], remember[kCountUnroll];
+            uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll], tile_id[kCountUnroll];
+            uint2 gk[kCountUnroll];
+            bool valid[kCountUnroll], grouped[kCountUnroll];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
                 const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
-                valid[u] = false, remember[u] = false, grouped[u] = false;
-                rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, where[u] = 0;
+                valid[u] = false, grouped[u] = false;
+                rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, tile_id[u] = 0, gk[u] = make_uint2(0u, 0u);
                 s_gcnt[u * 64 + lane] = 0u;
                 if (k < total) {
                     int lo = 0, hi = 63;
@@ -395,12 +398,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                     const uint32_t rh = (rr.y >> 16) - y0;
                     if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[lo], s_ctr[lo], tx, ty)) {
                         valid[u] = true;
-                        remember[u] = j < (uint32_t)kInlineSlots;
-                        // counter index in the concatenation [tile_count | tile_over] (tile_over = tile_count + 8 * tpad)
                         const uint32_t bx4 = (uint32_t)(a.tiles_x + 3) / 4;   // ImageView::counter_index
-                        key[u] = (remember[u] ? 0u : (uint32_t)kXcds * a.tpad) + xcc * a.tpad +
-                                 ((ty >> 2) * bx4 + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
-                        where[u] = (size_t)(wave_first + lo) * kInlineSlots + j;
+                        key[u] = xcc * a.tpad + ((ty >> 2) * bx4 + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
+                        tile_id[u] = ty * (uint32_t)a.tiles_x + tx;
+                        gk[u] = s_gk[lo];
                         slot[u] = (key[u] * 2654435761u) >> 26;
                         s_gkey[u * 64 + slot[u]] = key[u];   // several lanes may write: one of them wins the slot
                     }
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 got[u] = 0;
                 if (valid[u] && (!grouped[u] || rank[u] == 0)) {
                     const uint32_t n_add = grouped[u] ? s_gcnt[u * 64 + slot[u]] : 1u;
-                    got[u] = atomicAdd(&a.tile_count[key[u]], n_add);   // (indexes tile_over too, see `key`)
+                    got[u] = atomicAdd(&a.tile_count[key[u]], n_add);
                 }
             }
 #pragma unroll
@@ -425,9 +426,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                 if (grouped[u] && rank[u] == 0) s_gbase[u * 64 + slot[u]] = got[u];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
-                if (!remember[u]) continue;
-                const uint32_t base = grouped[u] ? s_gbase[u * 64 + slot[u]] : got[u];
-                a.g.inline_slots[where[u]] = base + rank[u];
+                if (!valid[u]) continue;
+                const uint32_t pos = (grouped[u] ? s_gbase[u * 64 + slot[u]] : got[u]) + rank[u];
+                // (a position beyond the bucket is dropped: k_tile_totals sees the count and flags the frame)
+                if (pos < a.bucket_cap)
+                    a.buckets[((size_t)tile_id[u] * kXcds + xcc) * a.bucket_cap + pos] = ((uint64_t)gk[u].y << 32) | gk[u].x;
             }
         }
     }
@@ -452,23 +455,28 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
 {
     // every thread: four consecutive counters = one row of a 4x4-tile block
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (i >= v.tpad) return;
     uint32_t sub[4][kSubWords];
     uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    uint32_t biggest = 0;
+    if (i < v.tpad) {
 #pragma unroll
-    for (int x = 0; x < kXcds; x++) {
-        uint4* p1 = reinterpret_cast<uint4*>(v.tile_count + (size_t)x * v.tpad + i);
-        const uint4 c1 = *p1;
-        const uint4 c2 = *reinterpret_cast<const uint4*>(v.tile_over + (size_t)x * v.tpad + i);
-        *p1 = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t a1[4] = {c1.x, c1.y, c1.z, c1.w}, a2[4] = {c2.x, c2.y, c2.z, c2.w};
+        for (int x = 0; x < kXcds; x++) {
+            uint4* p1 = reinterpret_cast<uint4*>(v.tile_count + (size_t)x * v.tpad + i);
+            const uint4 c1 = *p1;
+            *p1 = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t a1[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            sub[q][x] = acc[q];                  // start of XCD x's sub-segment (remembered instances first)
-            sub[q][kXcds + x] = acc[q] + a1[q];  // start of its un-remembered part
-            acc[q] += a1[q] + a2[q];
+            for (int q = 0; q < 4; q++) {
+                sub[q][x] = acc[q];                  // start of XCD x's sub-list inside the tile's list
+                acc[q] += a1[q];
+                biggest = max(biggest, a1[q]);
+            }
         }
     }
+    // the largest (tile, XCD) count of the frame decides whether the key buckets were large enough
+    for (int off = 32; off > 0; off >>= 1) biggest = max(biggest, (uint32_t)__shfl_down(biggest, off));
+    if ((threadIdx.x & 63) == 0 && biggest) atomicMax(v.tile_count + (size_t)kXcds * v.tpad, biggest);
+    if (i >= v.tpad) return;
     const uint32_t bx = (uint32_t)(v.tiles_x + 3) / 4, blk = i >> 4, row = (i >> 2) & 3u;
     const uint32_t ty = (blk / bx) * 4 + row, tx0 = (blk % bx) * 4;
     if (ty >= (uint32_t)v.tiles_y) return;   // padding rows of the block grid: never counted into, already zero
@@ -543,7 +551,10 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         tot += s_sum[w], utot += s_usum[w];
     }
     const uint32_t total = tot;
-    const bool overflow = (uint64_t)total > capacity;
+    // a frame is invalid if its instances exceed the record capacity OR some (tile, XCD) list exceeded its key bucket
+    uint32_t* biggest_word = v.tile_count + (size_t)kXcds * v.tpad;
+    const uint32_t biggest = *biggest_word;
+    const bool overflow = (uint64_t)total > capacity || biggest > v.bucket_cap;
     uint32_t run = wbase + inc - sum, urun = uwbase + uinc - usum;  // exclusive prefixes of this thread's chunk
     for (uint32_t i = b, k = 0; i < e; i += 4, k++) {
         const uint4 c = (k < (uint32_t)kCache) ? cache[k < (uint32_t)kCache ? k : 0] : *reinterpret_cast<const uint4*>(v.tile_total + i);
@@ -583,74 +594,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, ui
         host_counts->num_instances = total;
         host_counts->max_tile_list = m;
         host_counts->overflow = c->overflow;  // made visible to the host by the end-of-kernel release
-    }
-}
-
-// Write (depth | id) keys into the per-tile segments.  reference counterpart: duplicateWithKeys,
-// rasterizer_impl.cu:70-111 (the tile id is implicit in the segment here, and the order inside a segment
-// is fixed later by the per-tile sort).  A thread looping over its own rectangle would serialise one
-// returning atomic (~1 us round trip) per tile; instead each wave spreads the instances of its 64
-// Gaussians over its lanes (prefix sum + binary search), so a wave needs ceil(instances / 64) round trips.
-__global__ void __launch_bounds__(256) k_emit_instances(int P, GeomView g, ImageView v, uint64_t* keys)
-{
-    __shared__ uint32_t s_excl[4][64];
-    __shared__ uint2 s_rect[4][64];
-    __shared__ uint64_t s_key[4][64];
-    if (v.counts->overflow) return;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t xcc = g.block_xcc[blockIdx.x];  // the XCD whose counters numbered this workgroup's instances
-    uint2 r = make_uint2(0u, 0u);
-    uint32_t n = 0;
-    uint64_t key = 0;
-    __shared__ float4 s_cull[4][64];
-    __shared__ float2 s_ctr[4][64];
-    if (idx < P) {
-        const float4 co = g.conic_opacity[idx];
-        s_cull[wave][lane] = make_float4(co.x, co.y, co.z, g.cull_tau2[idx]);
-        s_ctr[wave][lane] = g.means2D[idx];
-        r = g.rect[idx];
-        const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
-        if (w > 0 && h > 0) {
-            n = (uint32_t)(w * h);
-            key = ((uint64_t)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
-        }
-    }
-    // inclusive scan over the wave
-    uint32_t incl = n;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    const uint32_t total = __shfl(incl, 63);
-    s_excl[wave][lane] = incl - n;
-    s_rect[wave][lane] = r;
-    s_key[wave][lane] = key;
-    __syncthreads();
-    for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
-        // owner = last lane whose exclusive prefix is <= k (zero-count lanes share a prefix with their successor,
-        // searching for the LAST such lane with a non-zero count: the first lane whose inclusive prefix exceeds k)
-        int lo = 0, hi = 63;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_excl[wave][mid] <= k) lo = mid; else hi = mid - 1;
-        }
-        const uint2 rr = s_rect[wave][lo];
-        const uint32_t j = k - s_excl[wave][lo];
-        const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, w = (rr.y & 0xffff) - x0;
-        const uint32_t ty = y0 + j / w, tx = x0 + (j - (j / w) * w);
-        const uint32_t h = (rr.y >> 16) - y0;
-        if (w > 1 && h > 1 && !footprint_touches_tile(s_cull[wave][lo], s_ctr[wave][lo], tx, ty)) continue;  // same test as the count
-        const uint32_t tile = ty * (uint32_t)v.tiles_x + tx;
-        // the instance lives in the sub-segment of the XCD that counted it
-        uint32_t slot = v.tile_offset[tile];
-        if (j < (uint32_t)kInlineSlots)
-            slot += v.tile_sub[(size_t)tile * kSubWords + xcc] +
-                    g.inline_slots[(size_t)(blockIdx.x * 256 + wave * 64 + lo) * kInlineSlots + j];
-        else  // un-remembered instances go behind the remembered ones; the overflow counter counts back down to 0
-            slot += v.tile_sub[(size_t)tile * kSubWords + kXcds + xcc] +
-                    (atomicSub(&v.tile_over[(size_t)xcc * v.tpad + v.counter_index(tx, ty)], 1u) - 1u);
-        keys[slot] = s_key[wave][lo];
+        reinterpret_cast<uint32_t*>(host_counts)[4] = biggest;   // (the pinned slot is 64 bytes: word 4 = largest bucket need)
+        *biggest_word = 0u;                                      // zero again for the next frame
     }
 }
 
@@ -709,18 +654,44 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
+    const size_t counter_words = (size_t)kXcds * v.tpad + 16;   // 8 XCD copies + the "largest bucket" word (own line)
     if (v.tpad > h->tile_counter_tiles) {   // (tile_counter_tiles holds the largest pitch allocated so far)
-        if (h->tile_counters) FR_HIP(hipFree(h->tile_counters));
+        if (h->tile_counters) {
+            FR_HIP(hipStreamSynchronize(s));
+            FR_HIP(hipFree(h->tile_counters));
+        }
         h->tile_counters = nullptr, h->tile_counter_tiles = 0;
-        FR_HIP(hipMalloc(&h->tile_counters, (size_t)2 * kXcds * v.tpad * sizeof(uint32_t)));
+        FR_HIP(hipMalloc(&h->tile_counters, counter_words * sizeof(uint32_t)));
         h->tile_counter_tiles = v.tpad;
         h->counters_clean = false;
     }
     if (!h->counters_clean)
-        if ((rc = launch_zero(h->tile_counters, (size_t)2 * kXcds * h->tile_counter_tiles * sizeof(uint32_t), s)))
+        if ((rc = launch_zero(h->tile_counters, ((size_t)kXcds * h->tile_counter_tiles + 16) * sizeof(uint32_t), s)))
             return rc;
     h->counters_clean = false;  // until every stage of this frame has been enqueued
-    v.tile_count = h->tile_counters, v.tile_over = h->tile_counters + (size_t)kXcds * v.tpad;
+    v.tile_count = h->tile_counters;
+    // NOTE the "largest bucket" word sits behind the copies of THIS frame's pitch (k_tile_totals / k_scan_tiles use
+    // v.tpad); a smaller image after a larger one finds it inside the zeroed allocation all the same.
+
+    // key buckets: handle-owned, [tiles][8 XCDs][bucket_cap].  They grow when the tile grid grows, and their capacity
+    // doubles when the last frame that reported back needed more (word 4 of the pinned count slot): that frame was
+    // flagged as overflowed, and the caller is repeating it right now.
+    {
+        uint32_t want = h->bucket_cap ? h->bucket_cap : kBucketCapInit;
+        const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
+        while (want < need + need / 4) want <<= 1;
+        if (want != h->bucket_cap || (size_t)T > h->bucket_tiles) {
+            if (h->key_buckets) {
+                FR_HIP(hipStreamSynchronize(s));
+                FR_HIP(hipFree(h->key_buckets));
+            }
+            h->key_buckets = nullptr;
+            const size_t tiles = (size_t)T > h->bucket_tiles ? (size_t)T : h->bucket_tiles;
+            FR_HIP(hipMalloc(reinterpret_cast<void**>(&h->key_buckets), tiles * kXcds * want * sizeof(uint64_t)));
+            h->bucket_tiles = tiles, h->bucket_cap = want;
+        }
+        v.buckets = h->key_buckets, v.bucket_cap = h->bucket_cap;
+    }
 
     PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
@@ -733,7 +704,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.visible = prm.aux ? prm.aux->visible : nullptr;
-    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.tile_over = v.tile_over, a.tpad = v.tpad, a.counts = v.counts;
+    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
+    a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
     if (P > 0) {
@@ -756,14 +728,6 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
     if (!no_wait) FR_HIP(hipEventRecord(h->counts_ready, s));
     if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
-    if (P > 0) {
-        {
-            StageScope sc(h, ST_EMIT, s);
-            hipLaunchKernelGGL(k_emit_instances, dim3((P + 255) / 256), dim3(256), 0, s, P, g, v, b.keys);
-        }
-        FR_HIP(hipGetLastError());
-        if ((rc = debug_sync(debug, s, "emit_instances"))) return rc;
-    }
     if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
     h->counters_clean = true;
     if (!capturing) {
