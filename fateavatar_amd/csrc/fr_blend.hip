@@ -368,6 +368,13 @@ __device__ void sort_tile_global(const KeySrc& src, u64* keys, float4* recs, uin
     }
 }
 
+// The frame's verdict, from the cursors k_tile_totals left: too many instances for the record capacity, or a
+// (tile, XCD) list longer than its key bucket.
+__device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t bucket_cap)
+{
+    return c->num_instances > c->capacity || c->max_bucket > bucket_cap;
+}
+
 // Grid: kMediumSorters workgroups that sort the medium lists (257..1024 keys, four waves per list, static
 // round-robin over the list the scan kernel built), followed by Q = ceil(T/4) workgroups of 4 waves for the
 // short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
@@ -377,10 +384,22 @@ constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lis
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
                                                    GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg,
-                                                   int take_long_lists)
+                                                   int take_long_lists, fr_counts* host_counts)
 {
     __shared__ SortXchgT<4> sx;
-    const bool overflow = v.counts->overflow != 0;
+    const bool overflow = frame_overflow(v.counts, v.bucket_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the frame's verdict for the later kernels, and the counts for the host (pinned memory; made visible by the
+        // end-of-kernel release; word 4 of the 64-byte slot = largest bucket need)
+        DeviceCounts* c = v.counts;
+        c->overflow = overflow ? 1u : 0u;
+        host_counts->num_rendered = c->num_rendered;
+        host_counts->num_instances = c->num_instances;
+        host_counts->max_tile_list = c->max_tile_list;
+        host_counts->overflow = overflow ? 1u : 0u;
+        reinterpret_cast<uint32_t*>(host_counts)[4] = c->max_bucket;
+        if (overflow) c->num_units = 0u;   // nothing to blend
+    }
     // longest jobs first in dispatch order: medium lists, then the short ones
     if (blockIdx.x < kMediumSorters) {
         if (overflow) return;
@@ -390,7 +409,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
         const uint32_t nm = v.counts->medium_tiles;
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group<4>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+            sort_tile_group<4>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_total[tile], wave, lane, g, sx,
                                (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
         }
         // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
@@ -400,7 +419,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
             for (uint32_t item = blockIdx.x; item < nb + nl; item += kMediumSorters) {
                 const uint32_t tile = item < nb ? v.big_list[item] : v.large_list[item - nb];
-                sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+                sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_total[tile], g,
                                  (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
             }
         }
@@ -413,7 +432,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
         if (tile < T) {
             if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
             const uint32_t start = v.tile_offset[tile];
-            const uint32_t n = v.tile_offset[tile + 1] - start;
+            const uint32_t n = v.tile_total[tile];
             // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
             const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
             for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
@@ -440,18 +459,18 @@ constexpr uint32_t kBigSorters = 512;
 __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, float4* recs, GeomView g)
 {
     __shared__ SortXchgT<16> sx;
-    if (v.counts->overflow) return;
+    if (frame_overflow(v.counts, v.bucket_cap)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
     for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
         const uint32_t tile = v.big_list[item];
-        sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], wave, lane, g, sx,
+        sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_total[tile], wave, lane, g, sx,
                             (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
     for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
         const uint32_t tile = v.large_list[item];
-        sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_offset[tile + 1] - v.tile_offset[tile], g,
+        sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_total[tile], g,
                          (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
 }
@@ -728,7 +747,8 @@ __global__ void __launch_bounds__(256, 4) k_unit_blend_fused(const DeviceCounts*
 
 // ---- pass C: one wave per tile
 __global__ void __launch_bounds__(256) k_tile_combine(const DeviceCounts* __restrict__ counts,
-                                                     const uint32_t* __restrict__ unit_offset, uint32_t n_tiles, int W,
+                                                     const uint32_t* __restrict__ unit_offset,
+                                                     const uint32_t* __restrict__ tile_total, uint32_t n_tiles, int W,
                                                      int H, int tiles_x, const float* __restrict__ bg,
                                                      const float* __restrict__ unit_out,
                                                      float4* __restrict__ unit_state, float* __restrict__ out_color,
@@ -741,7 +761,7 @@ __global__ void __launch_bounds__(256) k_tile_combine(const DeviceCounts* __rest
     const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
     const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
     const bool inside = px < W && py < H;
-    const uint32_t u0 = unit_offset[tile], u1 = unit_offset[tile + 1];
+    const uint32_t u0 = unit_offset[tile], u1 = u0 + (tile_total[tile] + kUnit - 1) / kUnit;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
     uint32_t ncon = 0;
     bool finished = false;
@@ -1217,11 +1237,11 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
     if (tile >= n_tiles) return;
     // everything the tile needs first is requested in one go (the offset tables are valid even for an overflowed frame)
     const uint32_t overflow = counts->overflow;
-    const uint32_t u0 = v.unit_offset[tile], u1 = v.unit_offset[tile + 1];
-    const uint32_t start = v.tile_offset[tile], n = v.tile_offset[tile + 1] - start;
+    const uint32_t u0 = v.unit_offset[tile];
+    const uint32_t start = v.tile_offset[tile], n = v.tile_total[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (overflow) return;
-    const uint32_t nu = u1 - u0;
+    const uint32_t nu = (n + kUnit - 1) / kUnit;
     const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
     const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -1518,7 +1538,9 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           fused ? b.unit_tseg : nullptr, launch_big ? 0 : 1);  // small_blocks == Q
+                           fused ? b.unit_tseg : nullptr, launch_big ? 0 : 1, h->host_counts_dev);  // small_blocks == Q
+        // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
+        if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
         if (launch_big) hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());
@@ -1545,7 +1567,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
                                b.unit_out);
         }
         hipLaunchKernelGGL(k_tile_combine, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s,
-                           v.counts, v.unit_offset, T, prm.W, prm.H, v.tiles_x,
+                           v.counts, v.unit_offset, v.tile_total, T, prm.W, prm.H, v.tiles_x,
                            in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);
     }
     FR_HIP(hipGetLastError());

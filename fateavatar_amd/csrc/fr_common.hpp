@@ -91,7 +91,7 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t max_tile_list;
     uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
-    uint32_t reserved0;      // (unused)
+    uint32_t max_bucket;     // largest (tile, XCD) list: above ImageView::bucket_cap the key buckets overflowed
     uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
     uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
     uint32_t pad2[6];
@@ -107,19 +107,18 @@ struct ImageView {
     // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
     // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
     // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
-    uint32_t* tile_count;    // [kXcds][tpad] instances counted by XCD x (block-major, counter_index), then one word:
-                             // the largest (tile, XCD) count of the frame (k_tile_totals -> k_scan_tiles, which zeroes it)
+    uint32_t* tile_count;    // [kXcds][tpad] instances counted by XCD x (block-major, counter_index)
     uint64_t* buckets;       // [T][kXcds][bucket_cap] the keys of the instances, written by the counting pass itself:
                              // slot s of (tile, XCD x) is the s-th instance XCD x counted into the tile (handle-owned)
     uint32_t bucket_cap;
     uint32_t* tile_sub;      // [T][kSubWords] start, within the tile's list, of each XCD's sub-list
     uint32_t tpad;           // row pitch of the two counter arrays
-    uint32_t* tile_total;    // [T rounded up to 16] instances per tile (sum over the XCD copies), written by k_tile_totals for the scan
-    uint32_t* tile_offset;   // [T+1] exclusive scan of tile_count
+    uint32_t* tile_total;    // [T rounded up to 16] instances per tile (sum over the XCD copies)
+    uint32_t* tile_offset;   // [T+1] first record of the tile's list (allocated by k_tile_totals, in no particular tile order)
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
     uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
     uint32_t* big_list;      // [T]   ids of tiles with kSortGroupMax < entries <= kSortRegMax
-    uint32_t* unit_offset;   // [T+1] exclusive scan of ceil(tile_count / 64): first blend unit of each tile
+    uint32_t* unit_offset;   // [T+1] first blend unit of each tile (ceil(tile_total / 64) consecutive units, allocated likewise)
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
     int tiles_x, tiles_y;

@@ -145,6 +145,8 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the frame's device counts (cursors of k_tile_totals) start from zero: the image buffer is caller-owned scratch
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DeviceCounts) / 4) reinterpret_cast<uint32_t*>(a.counts)[threadIdx.x] = 0u;
     const int M3 = a.M * 3, sh_stride = M3 | 1;
     const float* my_sh = nullptr;
     // every input of this thread is requested up front (camera, mean, scale, rotation, opacity — and the SH block
@@ -444,15 +446,23 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     if (threadIdx.x == 0) a.g.block_ref_tiles[blockIdx.x] = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3];
 }
 
-// Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts
-// (ceil(count / 64)) by ONE workgroup; also publishes the frame counts to pinned host memory, fills
-// the unit -> tile table and builds the list of tiles too long for the in-register sort.
-// Per-tile work that needs no prefix: add up the eight per-XCD counter copies, write the tile's sub-segment table,
-// and leave tile_count zeroed for the next frame (the emit pass counts tile_over back down itself).  Wide and
-// coalesced (every thread four consecutive tiles, 16 B per load), so that the single-workgroup scan behind it only
-// touches one dense 4-byte-per-tile array.
-__global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
+// Everything between the counting pass and the sort, in ONE wide launch (it used to be a totals kernel plus a
+// single-workgroup scan): per tile, add up the eight per-XCD counter copies, write the sub-list table and leave the
+// counters zeroed for the next frame; then ALLOCATE the tile's record range and blend-unit range.  Nothing needs the
+// tiles' lists in tile order, only each list contiguous, so a workgroup scans its own 1024 tiles in LDS and takes its
+// block of records / units / list entries with one returning atomic per cursor (4 workgroups at 512 x 512): no
+// grid-wide prefix, no second launch.  The frame counts (instances, units, longest list, largest bucket, the
+// reference-semantics num_rendered) are reduced with a few atomics per workgroup; k_tile_sort's first thread turns
+// them into the overflow verdict and the host-visible counts.
+// reference counterparts: InclusiveSum + the blocking count read-back (rasterizer_impl.cu:277-281), identifyTileRanges.
+__global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T, uint64_t capacity,
+                                                     const uint32_t* __restrict__ block_ref_tiles, uint32_t n_blocks)
 {
+    __shared__ uint32_t s_wave[2][4];     // per-wave totals: instances, units
+    __shared__ uint32_t s_base[8];        // workgroup bases: instances, units, medium / big / large list heads
+    __shared__ uint32_t s_heads[3];       // workgroup-local list counters
+    if (threadIdx.x < 3) s_heads[threadIdx.x] = 0;
+    DeviceCounts* c = v.counts;
     // every thread: four consecutive counters = one row of a 4x4-tile block
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
     uint32_t sub[4][kSubWords];
@@ -473,13 +483,65 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
             }
         }
     }
-    // the largest (tile, XCD) count of the frame decides whether the key buckets were large enough
-    for (int off = 32; off > 0; off >>= 1) biggest = max(biggest, (uint32_t)__shfl_down(biggest, off));
-    if ((threadIdx.x & 63) == 0 && biggest) atomicMax(v.tile_count + (size_t)kXcds * v.tpad, biggest);
-    if (i >= v.tpad) return;
     const uint32_t bx = (uint32_t)(v.tiles_x + 3) / 4, blk = i >> 4, row = (i >> 2) & 3u;
     const uint32_t ty = (blk / bx) * 4 + row, tx0 = (blk % bx) * 4;
-    if (ty >= (uint32_t)v.tiles_y) return;   // padding rows of the block grid: never counted into, already zero
+    const bool row_ok = i < v.tpad && ty < (uint32_t)v.tiles_y;   // (padding rows of the block grid are never counted into)
+    uint32_t n_sum = 0, u_sum = 0, longest = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!(row_ok && tx0 + q < (uint32_t)v.tiles_x)) acc[q] = 0;
+        n_sum += acc[q];
+        u_sum += (acc[q] + kUnit - 1) / kUnit;
+        longest = max(longest, acc[q]);
+    }
+    // ---- workgroup scan of (instances, units): wave scan by shuffles, wave totals through LDS
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t n_inc = n_sum, u_inc = u_sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tn = __shfl_up(n_inc, off), tu = __shfl_up(u_inc, off);
+        if (ln >= off) n_inc += tn, u_inc += tu;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        biggest = max(biggest, (uint32_t)__shfl_down(biggest, off));
+        longest = max(longest, (uint32_t)__shfl_down(longest, off));
+    }
+    // reference-semantics num_rendered: this workgroup adds up its slice of the preprocess workgroups' partial sums
+    uint32_t ref = 0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_blocks; k += gridDim.x * 256u) ref += block_ref_tiles[k];
+    for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
+    if (ln == 63) s_wave[0][wv] = n_inc, s_wave[1][wv] = u_inc;
+    if (ln == 0) {
+        if (biggest) atomicMax(&c->max_bucket, biggest);
+        if (longest) atomicMax(&c->max_tile_list, longest);
+        if (ref) atomicAdd(&c->num_rendered, ref);
+    }
+    // list membership of this thread's tiles (workgroup-local rank first, one global atomic per list and workgroup)
+    uint32_t cls[4], lrank[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t n = acc[q];
+        cls[q] = n > (uint32_t)kSortRegMax ? 2u : (n > (uint32_t)kSortGroupMax ? 1u : (n > (uint32_t)kSortWaveMax ? 0u : 3u));
+        lrank[q] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (cls[q] < 3u) lrank[q] = atomicAdd(&s_heads[cls[q]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t wn = s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3];
+        const uint32_t wu = s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
+        s_base[0] = wn ? atomicAdd(&c->num_instances, wn) : 0u;
+        s_base[1] = wu ? atomicAdd(&c->num_units, wu) : 0u;
+        s_base[2] = s_heads[0] ? atomicAdd(&c->medium_tiles, s_heads[0]) : 0u;
+        s_base[3] = s_heads[1] ? atomicAdd(&c->big_tiles, s_heads[1]) : 0u;
+        s_base[4] = s_heads[2] ? atomicAdd(&c->large_tiles, s_heads[2]) : 0u;
+        if (blockIdx.x == 0) c->capacity = (uint32_t)capacity;
+    }
+    __syncthreads();
+    uint32_t n_run = s_base[0] + n_inc - n_sum, u_run = s_base[1] + u_inc - u_sum;
+    for (int w = 0; w < wv; w++) n_run += s_wave[0][w], u_run += s_wave[1][w];
+    if (!row_ok) return;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (tx0 + q >= (uint32_t)v.tiles_x) break;
@@ -489,114 +551,15 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T)
         for (int w4 = 0; w4 < kSubWords / 4; w4++)
             dst[w4] = make_uint4(sub[q][4 * w4], sub[q][4 * w4 + 1], sub[q][4 * w4 + 2], sub[q][4 * w4 + 3]);
         v.tile_total[tile] = acc[q];
+        v.tile_offset[tile] = n_run;
+        v.unit_offset[tile] = u_run;
+        n_run += acc[q];
+        u_run += (acc[q] + kUnit - 1) / kUnit;
+        if (cls[q] == 0u) v.medium_list[s_base[2] + lrank[q]] = tile;
+        else if (cls[q] == 1u) v.big_list[s_base[3] + lrank[q]] = tile;
+        else if (cls[q] == 2u) v.large_list[s_base[4] + lrank[q]] = tile;
     }
     (void)T;
-}
-
-// Exclusive scans of the per-tile instance counts AND of the per-tile blend-unit counts, the lists of tiles the
-// multi-wave sorters take, and the frame counts.  One workgroup.
-__global__ void __launch_bounds__(1024) k_scan_tiles(ImageView v, uint32_t T, uint64_t capacity,
-                                                     const uint32_t* block_ref_tiles, uint32_t n_blocks,
-                                                     fr_counts* host_counts)
-{
-    __shared__ uint32_t s_ref[16];
-    __shared__ uint32_t s_heads[3];
-    if (threadIdx.x < 3) s_heads[threadIdx.x] = 0;
-    __syncthreads();
-    __shared__ uint32_t s_sum[16];
-    __shared__ uint32_t s_usum[16];
-    __shared__ uint32_t s_max[16];
-    const uint32_t tid = threadIdx.x;
-    // every thread owns `per` consecutive tiles, a multiple of 4 (16-byte loads)
-    const uint32_t per = (((T + 1023u) / 1024u) + 3u) & ~3u;
-    const uint32_t b = min(T, tid * per), e = min(T, b + per);
-    uint32_t sum = 0, usum = 0, mx = 0;
-    constexpr int kCache = 2;  // quads of counts kept in registers for the second pass
-    uint4 cache[kCache];
-    for (uint32_t i = b, k = 0; i < e; i += 4, k++) {
-        const uint4 c = *reinterpret_cast<const uint4*>(v.tile_total + i);
-        if (k < (uint32_t)kCache) cache[k] = c;
-        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (i + q >= e) break;
-            const uint32_t n = cc[q];
-            sum += n;
-            usum += (n + kUnit - 1) / kUnit;
-            mx = max(mx, n);
-            // single workgroup: the list heads live in LDS (a global same-address atomic costs ~11 ns apiece)
-            if (n > (uint32_t)kSortRegMax) v.large_list[atomicAdd(&s_heads[0], 1u)] = i + q;
-            else if (n > (uint32_t)kSortGroupMax) v.big_list[atomicAdd(&s_heads[2], 1u)] = i + q;
-            else if (n > (uint32_t)kSortWaveMax) v.medium_list[atomicAdd(&s_heads[1], 1u)] = i + q;
-        }
-    }
-    uint32_t ref = 0;
-    for (uint32_t i = tid; i < n_blocks; i += 1024) ref += block_ref_tiles[i];
-    for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
-    if ((tid & 63) == 0) s_ref[tid >> 6] = ref;
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
-    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
-    // two-level scan: inclusive scan inside each wave (shuffles, no barrier), then over the 16 wave totals
-    uint32_t inc = sum, uinc = usum;
-    const int ln = tid & 63, wv = tid >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off), u = __shfl_up(uinc, off);
-        if (ln >= off) inc += t, uinc += u;
-    }
-    if (ln == 63) s_sum[wv] = inc, s_usum[wv] = uinc;
-    __syncthreads();
-    uint32_t wbase = 0, uwbase = 0, tot = 0, utot = 0;
-    for (int w = 0; w < 16; w++) {
-        if (w < wv) wbase += s_sum[w], uwbase += s_usum[w];
-        tot += s_sum[w], utot += s_usum[w];
-    }
-    const uint32_t total = tot;
-    // a frame is invalid if its instances exceed the record capacity OR some (tile, XCD) list exceeded its key bucket
-    uint32_t* biggest_word = v.tile_count + (size_t)kXcds * v.tpad;
-    const uint32_t biggest = *biggest_word;
-    const bool overflow = (uint64_t)total > capacity || biggest > v.bucket_cap;
-    uint32_t run = wbase + inc - sum, urun = uwbase + uinc - usum;  // exclusive prefixes of this thread's chunk
-    for (uint32_t i = b, k = 0; i < e; i += 4, k++) {
-        const uint4 c = (k < (uint32_t)kCache) ? cache[k < (uint32_t)kCache ? k : 0] : *reinterpret_cast<const uint4*>(v.tile_total + i);
-        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
-        uint32_t o[4], uo[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            o[q] = run, uo[q] = urun;
-            run += cc[q];
-            urun += (cc[q] + kUnit - 1) / kUnit;
-        }
-        if (i + 4 <= e) {
-            *reinterpret_cast<uint4*>(v.tile_offset + i) = make_uint4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<uint4*>(v.unit_offset + i) = make_uint4(uo[0], uo[1], uo[2], uo[3]);
-        } else {
-            for (int q = 0; q < 4 && i + q < e; q++) v.tile_offset[i + q] = o[q], v.unit_offset[i + q] = uo[q];
-        }
-    }
-    if (tid == 1023) {
-        uint32_t m = 0;
-        for (int i = 0; i < 16; i++) m = max(m, s_max[i]);
-        v.tile_offset[T] = total;
-        v.unit_offset[T] = utot;
-        DeviceCounts* c = v.counts;
-        uint32_t nr = 0;
-        for (int i = 0; i < 16; i++) nr += s_ref[i];
-        c->num_rendered = nr;
-        c->large_tiles = s_heads[0];
-        c->medium_tiles = s_heads[1];
-        c->big_tiles = s_heads[2];
-        c->num_instances = total;
-        c->max_tile_list = m;
-        c->overflow = overflow ? 1u : 0u;
-        c->num_units = overflow ? 0u : utot;
-        c->capacity = (uint32_t)capacity;
-        host_counts->num_rendered = c->num_rendered;
-        host_counts->num_instances = total;
-        host_counts->max_tile_list = m;
-        host_counts->overflow = c->overflow;  // made visible to the host by the end-of-kernel release
-        reinterpret_cast<uint32_t*>(host_counts)[4] = biggest;   // (the pinned slot is 64 bytes: word 4 = largest bucket need)
-        *biggest_word = 0u;                                      // zero again for the next frame
-    }
 }
 
 // reference: checkFrustum, rasterizer_impl.cu:54-66
@@ -654,7 +617,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
-    const size_t counter_words = (size_t)kXcds * v.tpad + 16;   // 8 XCD copies + the "largest bucket" word (own line)
+    const size_t counter_words = (size_t)kXcds * v.tpad;   // 8 XCD copies
     if (v.tpad > h->tile_counter_tiles) {   // (tile_counter_tiles holds the largest pitch allocated so far)
         if (h->tile_counters) {
             FR_HIP(hipStreamSynchronize(s));
@@ -666,12 +629,10 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
         h->counters_clean = false;
     }
     if (!h->counters_clean)
-        if ((rc = launch_zero(h->tile_counters, ((size_t)kXcds * h->tile_counter_tiles + 16) * sizeof(uint32_t), s)))
+        if ((rc = launch_zero(h->tile_counters, (size_t)kXcds * h->tile_counter_tiles * sizeof(uint32_t), s)))
             return rc;
     h->counters_clean = false;  // until every stage of this frame has been enqueued
     v.tile_count = h->tile_counters;
-    // NOTE the "largest bucket" word sits behind the copies of THIS frame's pitch (k_tile_totals / k_scan_tiles use
-    // v.tpad); a smaller image after a larger one finds it inside the zeroed allocation all the same.
 
     // key buckets: handle-owned, [tiles][8 XCDs][bucket_cap].  They grow when the tile grid grows, and their capacity
     // doubles when the last frame that reported back needed more (word 4 of the pinned count slot): that frame was
@@ -720,13 +681,14 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     }
     {
         StageScope sc(h, ST_SCAN, s);
-        hipLaunchKernelGGL(k_tile_totals, dim3((v.tpad + 1023) / 1024), dim3(256), 0, s, v, T);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, v, T, cap, g.block_ref_tiles,
-                           (uint32_t)((P + 255) / 256), h->host_counts_dev);
+        if (P <= 0) {   // (k_preprocess_fwd, which zeroes the frame's device counts, did not run)
+            if ((rc = launch_zero(v.counts, sizeof(DeviceCounts), s))) return rc;
+        }
+        hipLaunchKernelGGL(k_tile_totals, dim3((v.tpad + 1023) / 1024), dim3(256), 0, s, v, T, cap, g.block_ref_tiles,
+                           (uint32_t)((P + 255) / 256));
     }
     FR_HIP(hipGetLastError());
     const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
-    if (!no_wait) FR_HIP(hipEventRecord(h->counts_ready, s));
     if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
     if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
     h->counters_clean = true;
