@@ -528,15 +528,13 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T, ui
     for (int q = 0; q < 4; q++)
         if (cls[q] < 3u) lrank[q] = atomicAdd(&s_heads[cls[q]], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t wn = s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3];
-        const uint32_t wu = s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
-        s_base[0] = wn ? atomicAdd(&c->num_instances, wn) : 0u;
-        s_base[1] = wu ? atomicAdd(&c->num_units, wu) : 0u;
-        s_base[2] = s_heads[0] ? atomicAdd(&c->medium_tiles, s_heads[0]) : 0u;
-        s_base[3] = s_heads[1] ? atomicAdd(&c->big_tiles, s_heads[1]) : 0u;
-        s_base[4] = s_heads[2] ? atomicAdd(&c->large_tiles, s_heads[2]) : 0u;
-        if (blockIdx.x == 0) c->capacity = (uint32_t)capacity;
+    if (threadIdx.x < 5) {   // five returning atomics, one per lane: a single round trip, not five in a row
+        const uint32_t k = threadIdx.x;
+        const uint32_t amount = k < 2 ? s_wave[k][0] + s_wave[k][1] + s_wave[k][2] + s_wave[k][3] : s_heads[k - 2];
+        uint32_t* cursor = k == 0 ? &c->num_instances : k == 1 ? &c->num_units : k == 2 ? &c->medium_tiles
+                           : k == 3 ? &c->big_tiles : &c->large_tiles;
+        s_base[k] = amount ? atomicAdd(cursor, amount) : 0u;
+        if (blockIdx.x == 0 && k == 0) c->capacity = (uint32_t)capacity;
     }
     __syncthreads();
     uint32_t n_run = s_base[0] + n_inc - n_sum, u_run = s_base[1] + u_inc - u_sum;
