@@ -28,11 +28,13 @@
  *   - Scratch is three caller-owned byte buffers sized by fr_*_bytes() instead of
  *     std::function<char*(size_t)> resize callbacks: the caller's allocator stays in
  *     charge (torch caching allocator in the Python host).  The only device memory the
- *     library owns is a few hundred KB of per-tile counters inside the fr_handle,
- *     allocated when an image size is first seen.
+ *     library owns lives in the fr_handle: per-tile counters, the key buckets the counting
+ *     pass writes into (tiles x 8 x capacity keys; 34 MB at 512 x 512) and the gradient
+ *     accumulators of the blend backward (64 B per Gaussian), all allocated when a size is
+ *     first seen and grown on demand.
  *   - The binning buffer has a CAPACITY.  fr_forward never blocks the GPU on the
  *     instance count (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:281):
- *     it enqueues the whole frame, then reads the counts the scan kernel wrote to pinned
+ *     it enqueues the whole frame, then reads the counts the sort kernel wrote to pinned
  *     host memory.  If the capacity was too small it returns FR_ERR_BINNING_CAPACITY and
  *     the required size; the caller regrows and calls again.
  *   - Work is enqueued on the stream passed in, not on the legacy default stream.
@@ -59,10 +61,11 @@ extern "C" {
 #define FR_ERR_UNSUPPORTED 4
 
 /* Per-device context: pinned count slot, event, and the per-tile binning counters (device memory, kept zero
- * between frames so that a frame needs no zeroing launch).  Calls on one handle must not overlap: neither on the host
- * (one thread at a time) nor on the device (two fr_forward calls of the same handle must be ordered by the stream(s)
- * they are enqueued on).  The counters grow with the tile grid (hipMalloc — not while the stream is being captured into a
- * hipGraph: run one eager frame of that image size first). */
+ * between frames so that a frame needs no zeroing launch), the key buckets and the gradient accumulators.  Calls on
+ * one handle must not overlap on the host (one thread at a time); on the device, frames enqueued on one stream are
+ * ordered by it and a frame on another stream first waits for the previous frame's event.  The handle's device memory
+ * grows with the tile grid / Gaussian count / longest per-XCD tile sub-list (hipMalloc — not while the stream is being
+ * captured into a hipGraph: run one eager frame of that size first). */
 typedef struct fr_handle fr_handle;
 
 /* Optional fused side outputs: per-Gaussian values the caller's step otherwise derives
@@ -130,7 +133,7 @@ typedef struct fr_grads {
     float* dL_drotations; /* [P,4] */
 } fr_grads;
 
-/* What the scan stage reports for a frame. */
+/* What the binning stages report for a frame. */
 typedef struct fr_counts {
     uint32_t num_rendered;   /* reference semantics: sum over Gaussians of 16x16 tiles touched */
     uint32_t num_instances;  /* (8x8 tile, Gaussian) instances this implementation bins and sorts */
@@ -146,7 +149,8 @@ const char* fr_version(void);
 /* Stage timing.  While enabled, every kernel launch of fr_forward / fr_backward is bracketed by HIP
  * events on the stream it is launched on; fr_profile_read sums the elapsed time of one stage over all
  * launches since fr_profile_enable(h, 1) (the stream must have been synchronised by the caller).
- * stage: 0 preprocess_fwd, 1 scan, 2 emit, 3 tile_sort, 4 blend_fwd, 5 blend_bwd, 6 preprocess_bwd. */
+ * stage: 0 preprocess_fwd (+ key binning), 1 scan (per-tile totals and range allocation), 2 emit (no launch any more:
+ * the preprocess kernel writes the keys), 3 tile_sort, 4 blend_fwd, 5 blend_bwd, 6 preprocess_bwd. */
 int fr_profile_enable(fr_handle* h, int32_t on);
 int fr_profile_read(fr_handle* h, int32_t stage, double* total_ms, uint32_t* launches);
 
