@@ -218,3 +218,35 @@ def test_opacity_reset_keeps_the_captured_step_valid(gpu_device):
     assert (ts._graph is not None)
     assert float((res[True][0] - res[False][0]).abs().max()) < 2e-3
     assert torch.allclose(res[True][1], res[False][1], rtol=2e-2, atol=1e-9)
+
+
+def test_rccl_exchange_path_runs_on_this_gpu(gpu_device):
+    """The data-parallel exchange of bench.py / TrainStep on the REAL backend: a one-rank RCCL ("nccl") process group
+    on this GPU runs the asynchronous all-reduce(AVG) with its two exchange buffers (bench.GradExchange) and the
+    blocking sum; with one rank the reductions are identities, what is checked is that the RCCL calls, the AVG probe
+    and the stream ordering work on this stack (the 8-GPU run is the driver's)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "from fateavatar_amd import dp\n"
+        "import bench\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "g = torch.arange(1 << 20, dtype=torch.float32, device='cuda')\n"
+        "x = bench.GradExchange(g)\n"
+        "for k in range(5):\n"
+        "    g.add_(1.0)\n"
+        "    x.submit(g)\n"
+        "x.drain(); torch.cuda.synchronize()\n"
+        "assert torch.equal(x.latest(), g), 'exchange buffer does not hold the last gradient'\n"
+        "assert dp._collective_avg_ok(g) in (True, False)\n"
+        "s = dp.allreduce_sum_(g.clone()); assert torch.equal(s, g)\n"
+        "print('rccl-ok', dist.get_backend(), '.'.join(map(str, torch.cuda.nccl.version())), dp._avg_supported)\n"
+        "dist.destroy_process_group()\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert "rccl-ok nccl" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
