@@ -1,11 +1,15 @@
 // Per-tile stages for gfx950: depth sort of each 8x8 tile's list, front-to-back alpha blend
 // (forward) and back-to-front gradient pass (backward).
 //
-// Execution model: ONE 64-lane wavefront per 8x8-pixel tile, one pixel per lane, no
-// workgroup barriers anywhere.  The sort runs in registers (bitonic network across lanes and
-// registers).  It leaves, per tile, a contiguous array of 48-byte splat RECORDS in blend
-// order; both blend kernels walk that array with wave-uniform addresses, so the record
-// fetches are scalar loads (SMEM -> SGPRs) and the VALU only does per-pixel math.
+// Execution model: 8x8-pixel tiles = one 64-lane wavefront, one pixel per lane.  The sort runs in registers
+// (bitonic network across lanes and registers) and leaves, per tile, a contiguous array of 48-byte splat RECORDS in
+// blend order, cut into UNITS of 64 records — the independent work items of the blend kernels.
+//   * default blend path (sparse): k_unit_blend_local + k_tile_finish (forward), k_unit_blend_bwd_sparse (backward) walk
+//     only the (pixel, record) pairs named by the records' footprint masks — see the section headers below;
+//   * all-pairs path (round 1; FR_BLEND_FWD=dense / FR_BLEND_BWD=dense): k_unit_tseg + k_unit_blend + k_tile_combine and
+//     k_unit_blend_bwd stream every record past every pixel with wave-uniform LDS reads and reduce the gradient
+//     partials across the wave (reduce_scatter_36).  Kept as the reference implementation the sparse kernels were
+//     validated against on the GPU, and for scenes whose splats cover whole tiles.
 #include "fr_common.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
