@@ -114,7 +114,8 @@ class HipEngine:
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
         # replicated Gaussians (same seed on every rank), one view per rank
-        self.scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1))
+        self.scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1),
+                                       scale=args.scale, opacity=args.opacity)
         s = self.scene
         self.pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, s.sh_degree, self.dev,
                                 fused_activations=args.fused_activations)
@@ -257,6 +258,8 @@ def main():
     ap.add_argument("--P", type=int, default=100_000)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=None, help="splat scale (default: the template's NN spacing at P)")
+    ap.add_argument("--opacity", type=float, default=0.1, help="splat opacity (the metric's scene: 0.1)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
@@ -385,9 +388,10 @@ def main():
         cpu = None
         if args.cpu_seconds > 0 and world == 1 and eng.scene is not None:
             cpu = cpu_baseline(eng.scene, args.cpu_seconds)
-        cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) else
-                    "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024)
-                    else "custom size (not the metric's configuration)")
+        stock = args.scale is None and args.opacity == 0.1
+        cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) and stock else
+                    "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024) and stock
+                    else f"custom scene (scale {args.scale}, opacity {args.opacity}; not the metric's configuration)")
         line = {
             "metric": "render+backward frames/sec at 512^2, 100k Gaussians", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

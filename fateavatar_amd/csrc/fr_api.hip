@@ -106,6 +106,12 @@ int fr_create(fr_handle** out)
     h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
     // the sparse backward reads the footprint masks the sparse forward leaves in the records
     if (h->dense_blend_fwd || !h->no_fused_blend) h->dense_blend_fwd = h->dense_blend_bwd = true;
+    const char* pf = getenv("FR_DENSE_PAIRS_FWD");
+    const char* pb = getenv("FR_DENSE_PAIRS_BWD");
+    h->dense_pairs_fwd = pf ? (uint32_t)strtoul(pf, nullptr, 10) : kDensePairsFwd;
+    h->dense_pairs_bwd = pb ? (uint32_t)strtoul(pb, nullptr, 10) : kDensePairsBwd;
+    const char* ph = getenv("FR_DEBUG_PAIR_HIST");
+    h->debug_pair_hist = ph && ph[0] == '1';
     *out = reinterpret_cast<fr_handle*>(h);
     return FR_OK;
 }

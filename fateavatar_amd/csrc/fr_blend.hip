@@ -878,39 +878,13 @@ __device__ __forceinline__ int bitrev6(int l)
     return ((l & 1) << 5) | ((l & 2) << 3) | ((l & 4) << 1) | ((l & 8) >> 1) | ((l & 16) >> 3) | ((l & 32) >> 5);
 }
 
-__global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                       void* binning, int W, int H, const float* __restrict__ bg,
-                                                       const float* __restrict__ dL_dpix, float* __restrict__ accum)
+// All 64 x 64 pairs of one staged unit, back to front, four records at a time: every lane (= pixel) evaluates the four
+// records, the 36 partial sums are reduce-scattered over the wave and 36 lanes issue one atomic each.  T / A enter as
+// the state behind the unit (see k_unit_blend_bwd); lanes with lim <= 0 carry T = A = 0.
+__device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_rec, int m, int lim, float fx, float fy, float T,
+                                                   float A, float T_final, float bg_dot_dpixel, float dpr, float dpg,
+                                                   float dpb, float* __restrict__ accum, int lane, int vv, int own_u, int own_c)
 {
-    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
-    // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
-    const int vv = bitrev6((int)(threadIdx.x & 63));
-    const int own_u = vv / 9, own_c = vv - own_u * 9;
-    FR_UNIT_LOOP_BEGIN
-    const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
-    const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
-    const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
-    // nothing at or behind the deepest contributor of any pixel of the tile can matter
-    if (!__any(last > ui.base)) continue;
-
-    stage_unit(s_rec, b.recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
-    const float fx = (float)ui.px, fy = (float)ui.py;
-    const float T_final = ui.inside ? v.final_T[pix] : 0.f;
-    const float4 st = b.unit_state[(size_t)u * kUnit + lane];
-    float T = st.w;
-    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
-    if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
-    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
-    // The reference's accum_rec (colour blended behind the current Gaussian, backward.cu:515) only ever enters
-    // through its dot product with dL/dpixel, and its recurrence is linear: carry that scalar instead of three
-    // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
-    const int m = (int)ui.m;
-    const int lim = (int)last - (int)ui.base;  // records of this unit at or behind the pixel's last contributor do nothing
-    // a lane with nothing to do in this unit (pixel terminated earlier, or outside the image) must carry FINITE
-    // state: its alpha is forced to 0 below, and 0 * NaN would still poison the wave reduction
-    float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;
-    if (lim <= 0) T = 0.f;
-
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
         float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup];
         bool ok[kGroup];
@@ -964,6 +938,42 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
             atomic_add_f32(accum + (size_t)id * kAccumStride + own_c, total);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                       void* binning, int W, int H, const float* __restrict__ bg,
+                                                       const float* __restrict__ dL_dpix, float* __restrict__ accum)
+{
+    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
+    // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
+    const int vv = bitrev6((int)(threadIdx.x & 63));
+    const int own_u = vv / 9, own_c = vv - own_u * 9;
+    FR_UNIT_LOOP_BEGIN
+    const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
+    const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
+    const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
+    // nothing at or behind the deepest contributor of any pixel of the tile can matter
+    if (!__any(last > ui.base)) continue;
+
+    stage_unit(s_rec, b.recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+    const float T_final = ui.inside ? v.final_T[pix] : 0.f;
+    const float4 st = b.unit_state[(size_t)u * kUnit + lane];
+    float T = st.w;
+    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
+    if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
+    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
+    // The reference's accum_rec (colour blended behind the current Gaussian, backward.cu:515) only ever enters
+    // through its dot product with dL/dpixel, and its recurrence is linear: carry that scalar instead of three
+    // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
+    const int m = (int)ui.m;
+    const int lim = (int)last - (int)ui.base;  // records of this unit at or behind the pixel's last contributor do nothing
+    // a lane with nothing to do in this unit (pixel terminated earlier, or outside the image) must carry FINITE
+    // state: its alpha is forced to 0 below, and 0 * NaN would still poison the wave reduction
+    float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;
+    if (lim <= 0) T = 0.f;
+
+    bwd_unit_all_pairs(s_rec, m, lim, fx, fy, T, A, T_final, bg_dot_dpixel, dpr, dpg, dpb, accum, lane, vv, own_u, own_c);
     }
 }
 
@@ -1133,12 +1143,60 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
     return o;
 }
 
+// Units in which many of the 64 x 64 pairs pass are cheaper in the all-pairs form (wave-uniform record reads, four
+// independent alpha evaluations in flight, no divergent walk): measured break-even around a fifth of the pairs.
+
+// walk_unit_fwd from T = 1 over ALL records of the staged unit
+template <bool TERMINATE>
+__device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restrict__ rec, uint32_t m, bool inside, float fx,
+                                                          float fy, uint32_t base)
+{
+    WalkOut o;
+    o.Cr = o.Cg = o.Cb = 0.f;
+    o.T = 1.f;
+    o.last = 0u;
+    o.term = false;
+    for (uint32_t j = 0; j < m; j += kGroup) {
+        float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
+        bool ok[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {   // (records beyond m are zero padding: alpha = 0)
+            const float4 q0 = rec[(j + k) * kRecQuads + 0];
+            const float4 q1 = rec[(j + k) * kRecQuads + 1];
+            const float q2x = rec[(j + k) * kRecQuads + 2].x;
+            const float dx = q0.x - fx, dy = q0.y - fy;
+            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+            ok[k] = inside && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+            cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            bool c = ok[k];
+            const float test_T = o.T * (1.f - alpha[k]);
+            if (TERMINATE) {
+                const bool fin = c && !o.term && (test_T < 0.0001f);
+                o.term = o.term || fin;
+                c = c && !o.term;
+            }
+            const float w = c ? alpha[k] * o.T : 0.f;
+            o.Cr += cr[k] * w;
+            o.Cg += cg[k] * w;
+            o.Cb += cb[k] * w;
+            o.T = c ? test_T : o.T;
+            o.last = c ? (base + j + (uint32_t)k + 1u) : o.last;
+        }
+        if (TERMINATE && __all(o.term || !inside)) break;
+    }
+    return o;
+}
+
 // ---- launch 1: every unit is an independent wave (grid-stride), blended locally
-__global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_unit_blend_local(DeviceCounts* __restrict__ counts,
                                                          const uint4* __restrict__ unit_tile,
                                                          const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
                                                          int H, int tiles_x, float* __restrict__ g_tseg,
-                                                         float* __restrict__ g_out)
+                                                         float* __restrict__ g_out, uint32_t dense_pairs, int pair_hist)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
@@ -1168,7 +1226,21 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(const DeviceCounts* __
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
-        const WalkOut o = walk_unit_fwd<false>(rec, Bp, 1.0f, (float)ui.px, (float)ui.py, ui.base);
+        // how many pairs the masks name decides the form of this unit's loop (the backward makes the same choice)
+        const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)__popc(fm.x) + (uint32_t)__popc(fm.y)), 63);
+        if (pair_hist && lane == 0)
+            atomicAdd(&counts->pair_hist[npairs <= 500 ? 0 : npairs <= 1000 ? 1 : npairs <= 1500 ? 2 : npairs <= 2500 ? 3 : 4], 1u);
+        // The first unit of a tile is entered with T = 1 exactly, so it is blended with the reference's termination test
+        // here and k_tile_finish takes it as final (bit 31 of `last`: the pixel terminated).  Behind an opaque surface
+        // that is where nearly every pixel ends.
+        const bool first = ui.base == 0u;
+        const float fx = (float)ui.px, fy = (float)ui.py;
+        WalkOut o;
+        if (npairs > dense_pairs)
+            o = first ? blend_unit_dense_local<true>(rec, ui.m, ui.inside, fx, fy, 0u) : blend_unit_dense_local<false>(rec, ui.m, ui.inside, fx, fy, ui.base);
+        else
+            o = first ? walk_unit_fwd<true>(rec, Bp, 1.0f, fx, fy, 0u) : walk_unit_fwd<false>(rec, Bp, 1.0f, fx, fy, ui.base);
+        if (o.term) o.last |= 0x80000000u;
         g_tseg[(size_t)u * kUnit + lane] = o.T;
         float* out = g_out + (size_t)u * 5 * kUnit + lane;
         out[0] = o.Cr;
@@ -1196,7 +1268,10 @@ __device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr
 {
     // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
     const bool dead = !inside || finished || (Tin < 0.0001f);
-    const bool crosses = !dead && (Tin * tl < 0.0001f);
+    // (unit 0 was blended WITH the termination test by k_unit_blend_local: its result is final)
+    const bool crosses = !dead && k != 0u && (Tin * tl < 0.0001f);
+    if (k == 0u && !dead) finished = (last_in >> 31) != 0u;
+    last_in &= 0x7FFFFFFFu;
     FinishUnit o;
     o.cr = dead ? 0.f : Tin * cr, o.cg = dead ? 0.f : Tin * cg, o.cb = dead ? 0.f : Tin * cb;
     o.To = dead ? Tin : Tin * tl;
@@ -1260,12 +1335,14 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
         const float fx = (float)px, fy = (float)py;
         float Tin = 1.0f;
         bool finished = false;
-        if (nu <= (uint32_t)kFinishRegs) {
+        const bool long_tile = nu > (uint32_t)kFinishRegs;
+        uint32_t k_end = nu;   // units [k_end, nu) lie behind the last contributor of every pixel: the backward skips them
+        for (uint32_t base = 0; base < nu; base += (uint32_t)kFinishRegs) {
             float tl[kFinishRegs], cr[kFinishRegs], cg[kFinishRegs], cb[kFinishRegs];
             uint32_t ls[kFinishRegs];
 #pragma unroll
             for (int k = 0; k < kFinishRegs; k++) {
-                const uint32_t kk = (uint32_t)k < nu ? (uint32_t)k : 0u;   // (clamped: the loads stay unconditional)
+                const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
                 const float* out = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
                 tl[k] = g_tseg[(size_t)(u0 + kk) * kUnit + lane];
                 cr[k] = out[0], cg[k] = out[kUnit], cb[k] = out[2 * kUnit];
@@ -1274,41 +1351,60 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
             FinishUnit f[kFinishRegs];
 #pragma unroll
             for (int k = 0; k < kFinishRegs; k++) {
-                if ((uint32_t)k < nu) {
-                    f[k] = finish_unit((uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs, tmasks, n,
-                                       rec, lane, fx, fy);
+                if (base + (uint32_t)k < nu) {
+                    f[k] = finish_unit(base + (uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs,
+                                       tmasks, n, rec, lane, fx, fy);
                     Cr += f[k].cr, Cg += f[k].cg, Cb += f[k].cb;
                 }
             }
-            // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at
-            // the unit's far boundary (= what the reference's accum_rec recurrence yields there); guard: k_tile_combine
-            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+            if (!long_tile) {
+                // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at
+                // the unit's far boundary (= what the reference's accum_rec recurrence yields there); guard: k_tile_combine
+                float Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
-            for (int k = kFinishRegs - 1; k >= 0; k--) {
-                if ((uint32_t)k < nu) {
-                    const float inv = (f[k].To >= 0.0001f) ? __builtin_amdgcn_rcpf(f[k].To) : 0.f;
-                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, f[k].To);
-                    Sr += f[k].cr, Sg += f[k].cg, Sb += f[k].cb;
+                for (int k = kFinishRegs - 1; k >= 0; k--) {
+                    if ((uint32_t)k < nu) {
+                        const float inv = (f[k].To >= 0.0001f) ? __builtin_amdgcn_rcpf(f[k].To) : 0.f;
+                        unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, f[k].To);
+                        Sr += f[k].cr, Sg += f[k].cg, Sb += f[k].cb;
+                    }
+                }
+            } else {
+                // long tile: the final contributions are parked in the partial array for the suffix pass below
+#pragma unroll
+                for (int k = 0; k < kFinishRegs; k++) {
+                    if (base + (uint32_t)k < nu) {
+                        float* out = g_out + (size_t)(u0 + base + (uint32_t)k) * 5 * kUnit + lane;
+                        out[0] = f[k].cr, out[kUnit] = f[k].cg, out[2 * kUnit] = f[k].cb, out[3 * kUnit] = f[k].To;
+                    }
+                }
+                // every pixel terminated (or outside the image): nothing further back is blended, and the backward never
+                // reads the entry state of those units (their base is at or behind every pixel's last contributor)
+                if (__all(!inside || finished || Tin < 0.0001f)) {
+                    k_end = min(nu, base + (uint32_t)kFinishRegs);
+                    break;
                 }
             }
-        } else {   // long tile: one unit at a time, the final contributions parked in the partial array
-            for (uint32_t k = 0; k < nu; k++) {
-                float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
-                const FinishUnit f = finish_unit(k, g_tseg[(size_t)(u0 + k) * kUnit + lane], out[0], out[kUnit], out[2 * kUnit],
-                                                 __float_as_uint(out[4 * kUnit]), inside, Tin, finished, Tf, ncon, trecs, tmasks, n, rec,
-                                                 lane, fx, fy);
-                out[0] = f.cr, out[kUnit] = f.cg, out[2 * kUnit] = f.cb, out[3 * kUnit] = f.To;
-                Cr += f.cr, Cg += f.cg, Cb += f.cb;
-            }
+        }
+        if (long_tile) {
             float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-            for (uint32_t k = nu; k-- > 0;) {
-                const float* out = g_out + (size_t)(u0 + k) * 5 * kUnit + lane;
-                const float To = out[3 * kUnit];
-                const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
-                unit_state[(size_t)(u0 + k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
-                Sr += out[0];
-                Sg += out[kUnit];
-                Sb += out[2 * kUnit];
+            for (uint32_t base = (k_end - 1u) & ~(uint32_t)(kFinishRegs - 1); ; base -= (uint32_t)kFinishRegs) {
+                float cr[kFinishRegs], cg[kFinishRegs], cb[kFinishRegs], To[kFinishRegs];
+#pragma unroll
+                for (int k = 0; k < kFinishRegs; k++) {
+                    const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
+                    const float* out = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+                    cr[k] = out[0], cg[k] = out[kUnit], cb[k] = out[2 * kUnit], To[k] = out[3 * kUnit];
+                }
+#pragma unroll
+                for (int k = kFinishRegs - 1; k >= 0; k--) {
+                    if (base + (uint32_t)k < k_end) {
+                        const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
+                        unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                        Sr += cr[k], Sg += cg[k], Sb += cb[k];
+                    }
+                }
+                if (base == 0) break;
             }
         }
     }
@@ -1323,7 +1419,8 @@ __global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restr
 
 __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                               void* binning, int W, int H, const float* __restrict__ bg,
-                                                              const float* __restrict__ dL_dpix, float* __restrict__ accum)
+                                                              const float* __restrict__ dL_dpix, float* __restrict__ accum,
+                                                              uint32_t dense_pairs)
 {
     __shared__ SparseLds s_all[kWavesPerWG];
     const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
@@ -1337,6 +1434,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     // which (record-in-septet, component) this lane flushes: lanes 0..62 = 7 records x 9 components
     const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;
+    // the same for the all-pairs form (bwd_unit_all_pairs): 4 records x 9 components after its reduce-scatter
+    const int vv = bitrev6(lane);
+    const int own_u = vv / 9, own_c = vv - own_u * 9;
     for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
         const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
         const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
@@ -1371,6 +1471,16 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel (see k_unit_blend_bwd)
         const float tile_x0 = (float)((int)(ui.tile % (uint32_t)v.tiles_x) * kTile);
         const float tile_y0 = (float)((int)(ui.tile / (uint32_t)v.tiles_x) * kTile);
+        // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
+        // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
+        if ((uint32_t)__builtin_amdgcn_readlane((int)cum, 63) > dense_pairs) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bwd_unit_all_pairs(S.rec, (int)ui.m, lim, fx, fy, T, A, T_final, (bg0 * dpr + bg1 * dpg) + bg2 * dpb, dpr, dpg, dpb,
+                               accum, lane, vv, own_u, own_c);
+            __builtin_amdgcn_wave_barrier();   // (S.rec is restaged by the next unit)
+            continue;
+        }
         S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
         const float rxl = rr.q0.x - tile_x0, ryl = rr.q0.y - tile_y0;           // own record centre, tile-local
 
@@ -1555,7 +1665,8 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
         if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
         hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
+                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
+                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0);
         hipLaunchKernelGGL(k_tile_finish, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
                            (const float4*)b.recs, (const uint2*)b.masks, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H,
                            in.background, out_color);
@@ -1590,7 +1701,7 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     if (!h->dense_blend_bwd && next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
         // the graded kernel, timed the way a profiler times it: events taken from the dispatch itself
         hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts, v,
-                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum);
+                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
     } else {
         StageScope sc(h, ST_BLEND_BWD, s);
         if (h->dense_blend_bwd)
@@ -1598,7 +1709,7 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
                                prm.H, in.background, dL_dpix, g.accum);
         else
             hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning,
-                               prm.W, prm.H, in.background, dL_dpix, g.accum);
+                               prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
     }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");

@@ -15,6 +15,10 @@ constexpr int kRefTile = 16;  // the reference's tile edge (config.h:16-17): rad
 constexpr int kAccumStride = 16;  // floats per Gaussian in the gradient accumulator (one 64-B line)
 constexpr int kXcds = 8;          // binning counters are privatised per XCD (indexed by HW_REG_XCC_ID & 7)
 constexpr int kSubWords = 8;      // per-tile sub-list table: start (within the tile's list) of each XCD's sub-list
+// Units in which many of the 64 x 64 (pixel, record) pairs pass are cheaper in the all-pairs form (wave-uniform record
+// reads, independent alpha evaluations in flight, no divergent walk).
+constexpr uint32_t kDensePairsFwd = 1000;  // local forward blend: all-pairs loop above this many mask bits per unit
+constexpr uint32_t kDensePairsBwd = 1000;  // backward: the same choice inside k_unit_blend_bwd_sparse
 constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
 constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)
@@ -94,7 +98,8 @@ struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t max_bucket;     // largest (tile, XCD) list: above ImageView::bucket_cap the key buckets overflowed
     uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
     uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
-    uint32_t pad2[6];
+    uint32_t pad2;
+    uint32_t pair_hist[5];   // FR_DEBUG_PAIR_HIST=1 only: units by pairs named (<= 500, <= 1000, <= 1500, <= 2500, more)
     uint32_t num_units;      // total number of blend units (64-record segments of tile lists)
     uint32_t capacity;       // binning capacity of this frame (the backward re-derives the binning layout from it)
 };
@@ -232,6 +237,8 @@ struct fr_handle_impl {
     bool no_fused_blend = true;  // default; FR_FUSED_BLEND=1 in the environment selects the experimental one-launch
                                  // k_unit_blend_fused instead of k_unit_tseg + k_unit_blend
     bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
+    uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
+    bool debug_pair_hist = false;
     bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];

@@ -43,6 +43,9 @@ def bwd(r):
 for _ in range(5):
     r = fwd(); bwd(r)
 torch.cuda.synchronize()
+if os.environ.get("FR_DEBUG_PAIR_HIST") == "1":  # DeviceCounts sits at the head of the image buffer (fr_common.hpp)
+    w = r[5][:64].view(torch.int32).cpu().numpy()
+    print(f"units={w[14]} has_dense={w[8]} units by pairs named <=500/<=1000/<=1500/<=2500/more: {w[9:14].tolist()}")
 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
 tf = tb = 0.0
 t0 = time.perf_counter()
