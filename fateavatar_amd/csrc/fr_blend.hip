@@ -1250,6 +1250,197 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(DeviceCounts* __restri
     }
 }
 
+// ---- the same blend with the chain resolved INSIDE the unit kernel (decoupled look-back)
+// k_tile_finish walks a tile's units one after the other and re-walks a unit wherever a pixel crosses the termination
+// threshold inside it: behind an opaque surface that is a serial string of re-walks per tile (30 of its 40 us on the
+// bench scene at opacity 0.9).  Here every unit publishes its per-pixel product as soon as it has it, reads the
+// products of the units in front of it in its tile (normally already there: they started at the same time), and so
+// knows its own entering transmittance while its records are still in LDS and its walk sets still in registers: the
+// crossing pixels are re-walked on the spot, by thousands of waves in parallel.  What is left per tile is a plain
+// gather (k_tile_gather).
+//   hand-off: MI355X_MICROARCH.md's data-tagged form — the 4-byte product is its own flag (zeroed by k_tile_sort,
+//   valid once non-zero; clamped to >= 1e-30, which still means "dead" to every reader), written and polled with
+//   relaxed agent-scope accesses, no fences.
+//   progress: a unit only waits for units with SMALLER indices, a workgroup takes exactly its four units and exits
+//   (no grid-stride loop), and workgroups are dispatched in index order: the unfinished workgroup with the smallest
+//   index never waits for one that has not been dispatched, so it finishes and frees its slot whatever else holds
+//   compute units.  The spin is bounded anyway.
+// A pixel is dead in a unit iff the product in front of it is below 1e-4 (products only shrink).  A pixel predicted to
+// cross whose exact walk stops short of the test (the two products differ in the last bits, right at 1e-4) is dead
+// behind this unit all the same — and that is what the reference computes too: its next contributor would trip the
+// test without being blended, leaving T, the colour and n_contrib as they are.
+constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
+
+__global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __restrict__ counts,
+                                                           const uint4* __restrict__ unit_tile,
+                                                           const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
+                                                           int H, int tiles_x, float* g_tseg, float* __restrict__ g_out,
+                                                           uint32_t dense_pairs, int pair_hist)
+{
+    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4* rec = s_rec_all[wave_in_wg];
+    const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
+    if (u >= counts->num_units) return;
+    const TransposeConsts tc = transpose_consts(lane);
+    const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
+    RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+    // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in `masks` for the backward
+    uint2 fm = make_uint2(0u, 0u);
+    if (ui.base + (uint32_t)lane < ui.n) {
+        fm = footprint_mask(rr.q0.x, rr.q0.y, rr.q0.z, rr.q0.w, rr.q1.x, rr.q1.y,
+                            (float)((int)(ui.tile % (uint32_t)tiles_x) * kTile), (float)((int)(ui.tile / (uint32_t)tiles_x) * kTile));
+        rr.q2.z = __uint_as_float(fm.x), rr.q2.w = __uint_as_float(fm.y);
+        masks[(size_t)ui.start + ui.base + (uint32_t)lane] = fm;
+    }
+    rec[lane * kRecQuads + 0] = rr.q0;
+    rec[lane * kRecQuads + 1] = rr.q1;
+    rec[lane * kRecQuads + 2] = rr.q2;
+    const uint2 bt = transpose_bits64(fm, lane, tc);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
+    const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)__popc(fm.x) + (uint32_t)__popc(fm.y)), 63);
+    if (pair_hist && lane == 0)
+        atomicAdd(&counts->pair_hist[npairs <= 500 ? 0 : npairs <= 1000 ? 1 : npairs <= 1500 ? 2 : npairs <= 2500 ? 3 : 4], 1u);
+    const float fx = (float)ui.px, fy = (float)ui.py;
+    // ---- local blend from T = 1, no termination test
+    const WalkOut o = npairs > dense_pairs ? blend_unit_dense_local<false>(rec, ui.m, ui.inside, fx, fy, ui.base)
+                                           : walk_unit_fwd<false>(rec, Bp, 1.0f, fx, fy, ui.base);
+    if (ui.base + kUnit < ui.n)   // (nobody reads the last unit's product)
+        __hip_atomic_store(g_tseg + (size_t)u * kUnit + lane, fmaxf(o.T, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- transmittance entering the unit: the products of the units in front, in list order
+    float Tin = 1.0f;
+    for (uint32_t p = u - ui.seg; p < u; p += 4) {
+        float pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)   // (requested together; clamped: the loads stay unconditional)
+            pv[k] = __hip_atomic_load(g_tseg + (size_t)min(p + (uint32_t)k, u - 1u) * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (p + (uint32_t)k < u) {
+                for (uint32_t spins = 0; !__all(pv[k] != 0.f) && spins < (1u << 22); spins++) {
+                    __builtin_amdgcn_s_sleep(2);
+                    pv[k] = __hip_atomic_load(g_tseg + (size_t)(p + (uint32_t)k) * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                Tin *= pv[k];
+            }
+        }
+    }
+
+    // ---- the unit's final contribution
+    const bool dead = !ui.inside || (Tin < 0.0001f);
+    const bool crosses = !dead && (Tin * o.T < 0.0001f);
+    float Cr = dead ? 0.f : Tin * o.Cr, Cg = dead ? 0.f : Tin * o.Cg, Cb = dead ? 0.f : Tin * o.Cb;
+    float To = dead ? Tin : Tin * o.T;
+    uint32_t last = dead ? 0u : o.last;
+    if (__any(crosses)) {   // the records are still staged, the walk sets still in registers
+        const WalkOut x = walk_unit_fwd<true>(rec, crosses ? Bp : 0ull, Tin, fx, fy, ui.base);
+        if (crosses) Cr = x.Cr, Cg = x.Cg, Cb = x.Cb, To = x.T, last = x.last;
+    }
+    float* out = g_out + (size_t)u * 5 * kUnit + lane;
+    out[0] = Cr;
+    out[kUnit] = Cg;
+    out[2 * kUnit] = Cb;
+    out[3 * kUnit] = To;
+    out[4 * kUnit] = __uint_as_float(last | (dead ? kDeadBit : 0u));
+}
+
+// one wave per tile: the image, and the backward entry state of every unit (see k_tile_combine), from the units' final
+// contributions.  Pure loads and adds: the partials of kFinishRegs units are requested together.
+__global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                    const float* __restrict__ g_out, float4* __restrict__ unit_state, int W,
+                                                    int H, const float* __restrict__ bg, float* __restrict__ out_color)
+{
+    constexpr int R = 8;
+    const uint32_t n_tiles = (uint32_t)v.tiles_x * v.tiles_y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * kWavesPerWG + wave;
+    if (tile >= n_tiles) return;
+    const uint32_t overflow = counts->overflow;
+    const uint32_t u0 = v.unit_offset[tile];
+    const uint32_t n = v.tile_total[tile];
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    if (overflow) return;
+    const uint32_t nu = (n + kUnit - 1) / kUnit;
+    const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
+    const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
+    uint32_t ncon = 0;
+    uint32_t k_end = nu;   // units [k_end, nu) are dead for every pixel: the backward never reads their state
+    for (uint32_t base = 0; base < nu; base += R) {
+        float cr[R], cg[R], cb[R], To[R];
+        uint32_t lw[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
+            const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+            cr[k] = o[0], cg[k] = o[kUnit], cb[k] = o[2 * kUnit], To[k] = o[3 * kUnit];
+            lw[k] = __float_as_uint(o[4 * kUnit]);
+        }
+        bool all_dead = false;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            if (base + (uint32_t)k < nu) {
+                const bool dead = (lw[k] & kDeadBit) != 0u;
+                Cr += cr[k], Cg += cg[k], Cb += cb[k];   // (a dead pixel's contribution is stored as 0)
+                if (!dead) {
+                    Tf = To[k];
+                    if (lw[k] & ~kDeadBit) ncon = lw[k] & ~kDeadBit;
+                }
+                all_dead = __all(dead);
+            }
+        }
+        if (nu <= (uint32_t)R) {   // short tile: the suffix pass runs on the registers
+            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+            for (int k = R - 1; k >= 0; k--) {
+                if ((uint32_t)k < nu) {
+                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // guard: k_tile_combine
+                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
+                }
+            }
+        } else if (all_dead) {
+            k_end = min(nu, base + (uint32_t)R);
+            break;
+        }
+    }
+    if (nu > (uint32_t)R) {
+        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+        for (uint32_t base = (k_end - 1u) & ~(uint32_t)(R - 1);; base -= R) {
+            float cr[R], cg[R], cb[R], To[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
+                const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+                cr[k] = o[0], cg[k] = o[kUnit], cb[k] = o[2 * kUnit], To[k] = o[3 * kUnit];
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; k--) {
+                if (base + (uint32_t)k < k_end) {
+                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
+                    unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
+                }
+            }
+            if (base == 0) break;
+        }
+    }
+    if (inside) {
+        v.final_T[pix] = Tf;
+        v.n_contrib[pix] = ncon;
+        out_color[pix] = Cr + Tf * bg0;
+        out_color[HW + pix] = Cg + Tf * bg1;
+        out_color[2 * HW + pix] = Cb + Tf * bg2;
+    }
+}
+
 // ---- launch 2: one wave per tile chains its units (running transmittance), re-walks a unit for the pixels that
 // terminate inside it, writes the image and the backward entry state of every unit.  The kernel executes almost no
 // arithmetic: it is a chain of dependent memory round trips, so the partials of up to kFinishRegs units are requested
@@ -1653,14 +1844,23 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           fused ? b.unit_tseg : nullptr, launch_big ? 0 : 1, h->host_counts_dev);  // small_blocks == Q
+                           (fused || (!h->dense_blend_fwd && h->chained_blend_fwd)) ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
+                           h->host_counts_dev);  // small_blocks == Q
         // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
         if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
         if (launch_big) hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
-    if (!h->dense_blend_fwd) {
+    if (!h->dense_blend_fwd && h->chained_blend_fwd) {
+        StageScope sc(h, ST_BLEND_FWD, s);
+        // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
+        hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
+                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0);
+        hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
+                           b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
+    } else if (!h->dense_blend_fwd) {
         StageScope sc(h, ST_BLEND_FWD, s);
         uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
         if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
