@@ -113,28 +113,31 @@ __device__ __forceinline__ void stage_wave_rows(float* dst, int stride, const fl
 // Can any pixel centre of 8x8 tile (tx, ty) lie inside the alpha >= 1/255 footprint of a Gaussian?  The footprint is
 // the ellipse q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2 around `ctr`; the minimum of the convex q over the tile's
 // pixel rectangle is at the centre if that is inside, otherwise on an edge FACING the centre (walking from the
-// minimiser towards the centre decreases q and can only leave the rectangle through such an edge).  Evaluated in
-// double from the float geometry, so that every pass that asks (k_preprocess_fwd counts and writes the instance in one go) takes the same
-// decision; the slack for the blend kernels' fp32 arithmetic is inside tau2.
+// minimiser towards the centre decreases q and can only leave the rectangle through such an edge).
+// fp32 throughout (the double version was over half of this kernel's instruction stream): the answer only has to be
+// CONSERVATIVE — a tile kept without need costs one instance whose pixels all fail the blend kernels' exact test, a
+// tile dropped wrongly would lose contributions — so q is compared against tau2 plus a bound on its own rounding
+// error (a few ulp of the sum of the magnitudes of its terms; q evaluated at a slightly misplaced point of the edge is
+// only larger than the minimum by the square of the misplacement).
 __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, const float2 ctr, uint32_t tx, uint32_t ty)
 {
     if (!(conic_tau2.w < 3.0e38f)) return true;
-    const double A = conic_tau2.x, B = conic_tau2.y, C = conic_tau2.z, t2 = conic_tau2.w;
-    const double lox = (double)(tx * kTile) - (double)ctr.x, hix = lox + (double)(kTile - 1);
-    const double loy = (double)(ty * kTile) - (double)ctr.y, hiy = loy + (double)(kTile - 1);
-    const double qx = lox > 0.0 ? lox : (hix < 0.0 ? hix : 0.0);
-    const double qy = loy > 0.0 ? loy : (hiy < 0.0 ? hiy : 0.0);
-    if (qx == 0.0 && qy == 0.0) return true;
-    double qmin = 1.0e300;
-    if (qx != 0.0) {  // edge dx = qx: best dy = -b qx / c, clamped to the edge
-        const double dy = fmin(fmax(-B * qx / C, loy), hiy);
-        qmin = A * qx * qx + 2.0 * B * qx * dy + C * dy * dy;
-    }
-    if (qy != 0.0) {
-        const double dx = fmin(fmax(-B * qy / A, lox), hix);
-        qmin = fmin(qmin, A * dx * dx + 2.0 * B * dx * qy + C * qy * qy);
-    }
-    return qmin <= t2;
+    const float A = conic_tau2.x, B = conic_tau2.y, C = conic_tau2.z, t2 = conic_tau2.w;
+    const float lox = (float)(tx * kTile) - ctr.x, hix = lox + (float)(kTile - 1);
+    const float loy = (float)(ty * kTile) - ctr.y, hiy = loy + (float)(kTile - 1);
+    const float qx = lox > 0.f ? lox : (hix < 0.f ? hix : 0.f);
+    const float qy = loy > 0.f ? loy : (hiy < 0.f ? hiy : 0.f);
+    if (qx == 0.f && qy == 0.f) return true;
+    // edge dx = qx: best dy = -b qx / c, clamped to the edge;  edge dy = qy: best dx = -b qy / a
+    const float dy = fminf(fmaxf(-B * qx * __builtin_amdgcn_rcpf(C), loy), hiy);
+    const float dx = fminf(fmaxf(-B * qy * __builtin_amdgcn_rcpf(A), lox), hix);
+    const float ax = A * qx * qx, bx = 2.f * B * qx * dy, cx = C * dy * dy;
+    const float ay = A * dx * dx, by = 2.f * B * dx * qy, cy = C * qy * qy;
+    const float q1 = (ax + bx) + cx, m1 = (ax + fabsf(bx)) + cx;
+    const float q2 = (ay + by) + cy, m2 = (ay + fabsf(by)) + cy;
+    const bool in1 = qx != 0.f && q1 <= t2 + (4.0e-6f * m1 + 1.0e-4f);
+    const bool in2 = qy != 0.f && q2 <= t2 + (4.0e-6f * m2 + 1.0e-4f);
+    return in1 || in2;
 }
 
 constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
@@ -308,22 +311,27 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             int py0 = ry0 * kRefTile, py1 = min(ry1 * kRefTile, a.H) - 1;
             if (!(opacity >= 1.0f / 255.0f)) break;  // alpha = opacity * G <= opacity < 1/255 everywhere
             {
-                const double A = conic_a, B = conic_b, C = conic_c;
-                const double dq = A * C - B * B;
-                if (dq > 0.0 && A > 0.0 && C > 0.0 && dq < 1e300) {
-                    const double cond = A * C / dq;                       // 1 / (1 - rho^2)
-                    double tau = log(255.0 * (double)opacity);            // alpha >= 1/255  <=>  power >= -tau
-                    tau = tau * (1.0 + 1.6e-5 * cond + 1e-5) + 1e-4;      // fp32 evaluation slack of `power`
-                    const double ex = sqrt(2.0 * tau * C / dq) * (1.0 + 1e-6) + 1e-3;
-                    const double ey = sqrt(2.0 * tau * A / dq) * (1.0 + 1e-6) + 1e-3;
-                    // integer pixel coordinates p with |p - centre| <= extent (extent already carries the slack)
-                    const double x_lo = ceil((double)pix_x - ex), x_hi = floor((double)pix_x + ex);
-                    const double y_lo = ceil((double)pix_y - ey), y_hi = floor((double)pix_y + ey);
-                    if (x_lo > (double)px0) px0 = (int)fmin(x_lo, (double)px1 + 1.0);
-                    if (x_hi < (double)px1) px1 = (int)fmax(x_hi, (double)px0 - 1.0);
-                    if (y_lo > (double)py0) py0 = (int)fmin(y_lo, (double)py1 + 1.0);
-                    if (y_hi < (double)py1) py1 = (int)fmax(y_hi, (double)py0 - 1.0);
-                    cull = make_float4(conic_a, conic_b, conic_c, (float)(2.0 * tau * (1.0 + 2e-7)));
+                // fp32, conservative (see footprint_touches_tile).  dq = ac - b^2 the accurate way (Kahan): with a plain
+                // a * c - b * b its relative error grows with the conditioning 1 / (1 - rho^2) of the conic.
+                const float A = conic_a, B = conic_b, C = conic_c;
+                const float bb = B * B;
+                const float dq = __builtin_fmaf(A, C, -bb) - __builtin_fmaf(B, B, -bb);
+                if (dq > 0.f && A > 0.f && C > 0.f && dq < 3.0e38f) {
+                    const float inv_dq = 1.0f / dq;
+                    const float cond = A * C * inv_dq;                      // 1 / (1 - rho^2)
+                    float tau = logf(255.0f * opacity);                     // alpha >= 1/255  <=>  power >= -tau
+                    tau = tau * (1.0f + 1.6e-5f * cond + 1e-5f) + 1e-4f;    // fp32 evaluation slack of `power`
+                    const float ex = sqrtf(2.0f * tau * C * inv_dq) * (1.0f + 1e-5f) + 2e-3f;
+                    const float ey = sqrtf(2.0f * tau * A * inv_dq) * (1.0f + 1e-5f) + 2e-3f;
+                    // integer pixel coordinates p with |p - centre| <= extent (extent already carries the slack; the
+                    // float sums below round by at most 1e-4 pixel at 4096 pixels, far inside it)
+                    const float x_lo = ceilf(pix_x - ex), x_hi = floorf(pix_x + ex);
+                    const float y_lo = ceilf(pix_y - ey), y_hi = floorf(pix_y + ey);
+                    if (x_lo > (float)px0) px0 = (int)fminf(x_lo, (float)px1 + 1.0f);
+                    if (x_hi < (float)px1) px1 = (int)fmaxf(x_hi, (float)px0 - 1.0f);
+                    if (y_lo > (float)py0) py0 = (int)fminf(y_lo, (float)py1 + 1.0f);
+                    if (y_hi < (float)py1) py1 = (int)fmaxf(y_hi, (float)py0 - 1.0f);
+                    cull = make_float4(conic_a, conic_b, conic_c, 2.0f * tau * (1.0f + 1e-6f));
                 }
             }
             ctr = make_float2(pix_x, pix_y);
