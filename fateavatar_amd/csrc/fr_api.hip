@@ -103,6 +103,7 @@ int fr_create(fr_handle** out)
     const char* bf = getenv("FR_BLEND_FWD");
     h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
     h->chained_blend_fwd = !(bf && strcmp(bf, "finish") == 0);
+    h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
     const char* bb = getenv("FR_BLEND_BWD");
     h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
     // the sparse backward reads the footprint masks the sparse forward leaves in the records

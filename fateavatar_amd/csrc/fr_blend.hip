@@ -389,7 +389,8 @@ constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lis
 
 __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
                                                    GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg,
-                                                   int take_long_lists, fr_counts* host_counts)
+                                                   int take_long_lists, fr_counts* host_counts, uint32_t* unit_done,
+                                                   float* empty_color, const float* __restrict__ bg, int W, int H)
 {
     __shared__ SortXchgT<4> sx;
     const bool overflow = frame_overflow(v.counts, v.bucket_cap);
@@ -445,6 +446,20 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             // hand-off words of k_unit_blend_fused: a unit's per-pixel product is valid once it is non-zero
             if (unit_tseg)
                 for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
+            if (unit_done)
+                for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
+                    if (u0 + k < unit_cap) unit_done[u0 + k] = 0u;
+            // a tile without instances has no blend unit to write its pixels (gather-in-chain mode): background here
+            if (empty_color && n == 0) {
+                const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
+                const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
+                if (px < W && py < H) {
+                    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+                    v.final_T[pix] = 1.0f;
+                    v.n_contrib[pix] = 0u;
+                    empty_color[pix] = bg[0], empty_color[HW + pix] = bg[1], empty_color[2 * HW + pix] = bg[2];
+                }
+            }
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
                 const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
                 const KeySrc ks = key_src(v, tile);
@@ -1250,6 +1265,100 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(DeviceCounts* __restri
     }
 }
 
+constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
+
+// a unit's final row as written by another workgroup of the SAME launch (agent-scope load), or of an earlier one
+template <bool COHERENT>
+__device__ __forceinline__ float load_row(const float* p)
+{
+    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+// One wave, one tile: the image, and the backward entry state of every unit (see k_tile_combine), from the units' final
+// contributions.  Pure loads and adds: the rows of 8 units are requested together.
+template <bool COHERENT>
+__device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, uint32_t u0, uint32_t nu, const float* g_out,
+                                            float4* __restrict__ unit_state, int W, int H, float bg0, float bg1, float bg2,
+                                            float* __restrict__ out_color, int lane)
+{
+    constexpr int R = 8;
+    const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
+    const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
+    uint32_t ncon = 0;
+    uint32_t k_end = nu;   // units [k_end, nu) are dead for every pixel: the backward never reads their state
+    for (uint32_t base = 0; base < nu; base += R) {
+        float cr[R], cg[R], cb[R], To[R];
+        uint32_t lw[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
+            const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+            cr[k] = load_row<COHERENT>(o), cg[k] = load_row<COHERENT>(o + kUnit), cb[k] = load_row<COHERENT>(o + 2 * kUnit);
+            To[k] = load_row<COHERENT>(o + 3 * kUnit);
+            lw[k] = __float_as_uint(load_row<COHERENT>(o + 4 * kUnit));
+        }
+        bool all_dead = false;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            if (base + (uint32_t)k < nu) {
+                const bool dead = (lw[k] & kDeadBit) != 0u;
+                Cr += cr[k], Cg += cg[k], Cb += cb[k];   // (a dead pixel's contribution is stored as 0)
+                if (!dead) {
+                    Tf = To[k];
+                    if (lw[k] & ~kDeadBit) ncon = lw[k] & ~kDeadBit;
+                }
+                all_dead = __all(dead);
+            }
+        }
+        if (nu <= (uint32_t)R) {   // short tile: the suffix pass runs on the registers
+            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+            for (int k = R - 1; k >= 0; k--) {
+                if ((uint32_t)k < nu) {
+                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // guard: k_tile_combine
+                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
+                }
+            }
+        } else if (all_dead) {
+            k_end = min(nu, base + (uint32_t)R);
+            break;
+        }
+    }
+    if (nu > (uint32_t)R) {
+        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+        for (uint32_t base = (k_end - 1u) & ~(uint32_t)(R - 1);; base -= R) {
+            float cr[R], cg[R], cb[R], To[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
+                const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
+                cr[k] = load_row<COHERENT>(o), cg[k] = load_row<COHERENT>(o + kUnit), cb[k] = load_row<COHERENT>(o + 2 * kUnit);
+                To[k] = load_row<COHERENT>(o + 3 * kUnit);
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; k--) {
+                if (base + (uint32_t)k < k_end) {
+                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
+                    unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
+                }
+            }
+            if (base == 0) break;
+        }
+    }
+    if (inside) {
+        v.final_T[pix] = Tf;
+        v.n_contrib[pix] = ncon;
+        out_color[pix] = Cr + Tf * bg0;
+        out_color[HW + pix] = Cg + Tf * bg1;
+        out_color[2 * HW + pix] = Cb + Tf * bg2;
+    }
+}
+
 // ---- the same blend with the chain resolved INSIDE the unit kernel (decoupled look-back)
 // k_tile_finish walks a tile's units one after the other and re-walks a unit wherever a pixel crosses the termination
 // threshold inside it: behind an opaque surface that is a serial string of re-walks per tile (30 of its 40 us on the
@@ -1269,13 +1378,14 @@ __global__ void __launch_bounds__(256) k_unit_blend_local(DeviceCounts* __restri
 // cross whose exact walk stops short of the test (the two products differ in the last bits, right at 1e-4) is dead
 // behind this unit all the same — and that is what the reference computes too: its next contributor would trip the
 // test without being blended, leaving T, the colour and n_contrib as they are.
-constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
 
 __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __restrict__ counts,
                                                            const uint4* __restrict__ unit_tile,
                                                            const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
-                                                           int H, int tiles_x, float* g_tseg, float* __restrict__ g_out,
-                                                           uint32_t dense_pairs, int pair_hist)
+                                                           int H, int tiles_x, float* g_tseg, float* g_out,
+                                                           uint32_t dense_pairs, int pair_hist, uint32_t* unit_done,
+                                                           const ImageView v, float4* __restrict__ unit_state,
+                                                           const float* __restrict__ bg, float* __restrict__ out_color)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
@@ -1341,20 +1451,45 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
         if (crosses) Cr = x.Cr, Cg = x.Cg, Cb = x.Cb, To = x.T, last = x.last;
     }
     float* out = g_out + (size_t)u * 5 * kUnit + lane;
-    out[0] = Cr;
-    out[kUnit] = Cg;
-    out[2 * kUnit] = Cb;
-    out[3 * kUnit] = To;
-    out[4 * kUnit] = __uint_as_float(last | (dead ? kDeadBit : 0u));
+    const uint32_t lw = last | (dead ? kDeadBit : 0u);
+    if (!unit_done) {   // the gather is a launch of its own
+        out[0] = Cr;
+        out[kUnit] = Cg;
+        out[2 * kUnit] = Cb;
+        out[3 * kUnit] = To;
+        out[4 * kUnit] = __uint_as_float(lw);
+        return;
+    }
+    // ---- gather in the chain: the tile's LAST unit adds everything up once the others have delivered.  The rows are
+    // written at agent scope (write-through), the wave waits until they are, and only then raises the unit's flag.
+    __hip_atomic_store(out, Cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + kUnit, Cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 2 * kUnit, Cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 3 * kUnit, To, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 4 * kUnit, __uint_as_float(lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ui.base + kUnit < ui.n) {
+        if (lane == 0) __hip_atomic_store(unit_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint32_t u0 = u - ui.seg;
+    for (uint32_t p = u0; p < u; p += 64) {
+        const uint32_t q = min(p + (uint32_t)lane, u - 1u);
+        uint32_t d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spins = 0; !__all(d != 0u) && spins < (1u << 22); spins++) {
+            __builtin_amdgcn_s_sleep(2);
+            d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("" ::: "memory");
+    gather_tile<true>(v, ui.tile, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
 }
 
-// one wave per tile: the image, and the backward entry state of every unit (see k_tile_combine), from the units' final
-// contributions.  Pure loads and adds: the partials of kFinishRegs units are requested together.
+// the gather as its own launch (FR_BLEND_FWD=gather): one wave per tile
 __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                     const float* __restrict__ g_out, float4* __restrict__ unit_state, int W,
                                                     int H, const float* __restrict__ bg, float* __restrict__ out_color)
 {
-    constexpr int R = 8;
     const uint32_t n_tiles = (uint32_t)v.tiles_x * v.tiles_y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1365,80 +1500,7 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
     const uint32_t n = v.tile_total[tile];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (overflow) return;
-    const uint32_t nu = (n + kUnit - 1) / kUnit;
-    const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
-    const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
-    uint32_t ncon = 0;
-    uint32_t k_end = nu;   // units [k_end, nu) are dead for every pixel: the backward never reads their state
-    for (uint32_t base = 0; base < nu; base += R) {
-        float cr[R], cg[R], cb[R], To[R];
-        uint32_t lw[R];
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
-            const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
-            cr[k] = o[0], cg[k] = o[kUnit], cb[k] = o[2 * kUnit], To[k] = o[3 * kUnit];
-            lw[k] = __float_as_uint(o[4 * kUnit]);
-        }
-        bool all_dead = false;
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            if (base + (uint32_t)k < nu) {
-                const bool dead = (lw[k] & kDeadBit) != 0u;
-                Cr += cr[k], Cg += cg[k], Cb += cb[k];   // (a dead pixel's contribution is stored as 0)
-                if (!dead) {
-                    Tf = To[k];
-                    if (lw[k] & ~kDeadBit) ncon = lw[k] & ~kDeadBit;
-                }
-                all_dead = __all(dead);
-            }
-        }
-        if (nu <= (uint32_t)R) {   // short tile: the suffix pass runs on the registers
-            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-#pragma unroll
-            for (int k = R - 1; k >= 0; k--) {
-                if ((uint32_t)k < nu) {
-                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // guard: k_tile_combine
-                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
-                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
-                }
-            }
-        } else if (all_dead) {
-            k_end = min(nu, base + (uint32_t)R);
-            break;
-        }
-    }
-    if (nu > (uint32_t)R) {
-        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-        for (uint32_t base = (k_end - 1u) & ~(uint32_t)(R - 1);; base -= R) {
-            float cr[R], cg[R], cb[R], To[R];
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
-                const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
-                cr[k] = o[0], cg[k] = o[kUnit], cb[k] = o[2 * kUnit], To[k] = o[3 * kUnit];
-            }
-#pragma unroll
-            for (int k = R - 1; k >= 0; k--) {
-                if (base + (uint32_t)k < k_end) {
-                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
-                    unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
-                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
-                }
-            }
-            if (base == 0) break;
-        }
-    }
-    if (inside) {
-        v.final_T[pix] = Tf;
-        v.n_contrib[pix] = ncon;
-        out_color[pix] = Cr + Tf * bg0;
-        out_color[HW + pix] = Cg + Tf * bg1;
-        out_color[2 * HW + pix] = Cb + Tf * bg2;
-    }
+    gather_tile<false>(v, tile, u0, (n + kUnit - 1) / kUnit, g_out, unit_state, W, H, bg0, bg1, bg2, out_color, lane);
 }
 
 // ---- launch 2: one wave per tile chains its units (running transmittance), re-walks a unit for the pixels that
@@ -1836,6 +1898,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         h->fused_grid = (per_cu >= 3 && cus > 0) ? (uint32_t)((per_cu - 1) * cus) : 1u;  // 1 = do not use the fused kernel
     }
     const bool fused = h->fused_grid > 1 && !(h->no_fused_blend);
+    const bool chained = !h->dense_blend_fwd && h->chained_blend_fwd;
     const uint32_t fgrid = unit_wgs < h->fused_grid ? unit_wgs : h->fused_grid;
     {
         StageScope sc(h, ST_SORT, s);
@@ -1844,8 +1907,10 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           (fused || (!h->dense_blend_fwd && h->chained_blend_fwd)) ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
-                           h->host_counts_dev);  // small_blocks == Q
+                           (fused || chained) ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
+                           h->host_counts_dev,  // small_blocks == Q
+                           (chained && h->gather_in_chain) ? b.unit_done : nullptr,
+                           (chained && h->gather_in_chain) ? out_color : nullptr, in.background, prm.W, prm.H);
         // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
         if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
         if (launch_big) hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
@@ -1857,9 +1922,11 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
         hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
                            (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
-                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0);
-        hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
-                           b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
+                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0, h->gather_in_chain ? b.unit_done : nullptr, v,
+                           b.unit_state, in.background, out_color);
+        if (!h->gather_in_chain)
+            hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
+                               v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
     } else if (!h->dense_blend_fwd) {
         StageScope sc(h, ST_BLEND_FWD, s);
         uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;

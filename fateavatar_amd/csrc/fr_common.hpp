@@ -174,6 +174,7 @@ struct BinningView {
     float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
     uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_local writes it, the backward reads it)
     uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile, segment, list start, list length)
+    uint32_t* unit_done;  // [unit_cap] k_unit_blend_chained: the unit's final contribution is in memory (zeroed by k_tile_sort)
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
     float* unit_out;      // [unit_cap*5*64] forward partials per pixel: Cr, Cg, Cb, T_out, (last | done<<31)
     float4* unit_state;   // [unit_cap*64]   backward entry state per pixel: colour behind the unit / T_out, T_out
@@ -188,6 +189,7 @@ struct BinningView {
         b.keys = carve<uint64_t>(p, cap);
         b.masks = carve<uint2>(p, cap);
         b.unit_tile = carve<uint4>(p, b.unit_cap);
+        b.unit_done = carve<uint32_t>(p, b.unit_cap);
         b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
         b.unit_out = carve<float>(p, b.unit_cap * 5 * kUnit);
         b.unit_state = carve<float4>(p, b.unit_cap * kUnit);
@@ -239,6 +241,7 @@ struct fr_handle_impl {
     bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
+    bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
     bool chained_blend_fwd = true;  // FR_BLEND_FWD=finish: k_unit_blend_local + k_tile_finish instead of k_unit_blend_chained + k_tile_gather
     bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
