@@ -98,16 +98,13 @@ int fr_create(fr_handle** out)
     FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
-    const char* fb = getenv("FR_FUSED_BLEND");  // experimental one-launch k_unit_blend_fused (measured: no gain yet)
-    h->no_fused_blend = !(fb && fb[0] == '1');
     const char* bf = getenv("FR_BLEND_FWD");
     h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
-    h->chained_blend_fwd = !(bf && strcmp(bf, "finish") == 0);
     h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
     const char* bb = getenv("FR_BLEND_BWD");
     h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
     // the sparse backward reads the footprint masks the sparse forward leaves in the records
-    if (h->dense_blend_fwd || !h->no_fused_blend) h->dense_blend_fwd = h->dense_blend_bwd = true;
+    if (h->dense_blend_fwd) h->dense_blend_bwd = true;
     const char* pf = getenv("FR_DENSE_PAIRS_FWD");
     const char* pb = getenv("FR_DENSE_PAIRS_BWD");
     h->dense_pairs_fwd = pf ? (uint32_t)strtoul(pf, nullptr, 10) : kDensePairsFwd;

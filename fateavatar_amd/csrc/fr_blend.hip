@@ -4,8 +4,9 @@
 // Execution model: 8x8-pixel tiles = one 64-lane wavefront, one pixel per lane.  The sort runs in registers
 // (bitonic network across lanes and registers) and leaves, per tile, a contiguous array of 48-byte splat RECORDS in
 // blend order, cut into UNITS of 64 records — the independent work items of the blend kernels.
-//   * default blend path (sparse): k_unit_blend_local + k_tile_finish (forward), k_unit_blend_bwd_sparse (backward) walk
-//     only the (pixel, record) pairs named by the records' footprint masks — see the section headers below;
+//   * default blend path (sparse): k_unit_blend_chained (forward, ONE launch) and k_unit_blend_bwd_sparse (backward) walk
+//     only the (pixel, record) pairs named by the records' footprint masks, and switch to all-pairs loops for the
+//     units in which most pairs are named — see the section headers below;
 //   * all-pairs path (round 1; FR_BLEND_FWD=dense / FR_BLEND_BWD=dense): k_unit_tseg + k_unit_blend + k_tile_combine and
 //     k_unit_blend_bwd stream every record past every pixel with wave-uniform LDS reads and reduce the gradient
 //     partials across the wave (reduce_scatter_36).  Kept as the reference implementation the sparse kernels were
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
             for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
                 if (u0 + k < unit_cap) unit_tile[u0 + k] = make_uint4(tile, k, start, n);
-            // hand-off words of k_unit_blend_fused: a unit's per-pixel product is valid once it is non-zero
+            // hand-off words of k_unit_blend_chained: a unit's per-pixel product is valid once it is non-zero
             if (unit_tseg)
                 for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
             if (unit_done)
@@ -674,87 +675,6 @@ __global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restri
             T = c ? test_T : T;
             last = c ? (ui.base + j + k + 1u) : last;
         }
-    }
-    float* o = unit_out + (size_t)u * 5 * kUnit + lane;
-    o[0] = Cr;
-    o[kUnit] = Cg;
-    o[2 * kUnit] = Cb;
-    o[3 * kUnit] = T;
-    o[4 * kUnit] = __uint_as_float(last | (term ? 0x80000000u : 0u));
-    }
-}
-
-// ---- passes A + B in one launch (EXPERIMENTAL, off by default: FR_FUSED_BLEND=1).  Measured at config 2 and on
-// the opaque stress scene: no faster than the two lean launches (128 VGPRs for the 64 stored alphas halve the
-// occupancy, which costs what the second alpha evaluation saved).  Kept for the next tuning round.  Every unit evaluates its 64 alphas ONCE (kept in registers), publishes the
-// per-pixel product of (1 - alpha) for the units behind it in the tile, picks up the products of the units in front
-// of it, and blends.  The hand-off follows MI355X_MICROARCH.md's data-tagged form: the 4-byte product itself is the
-// flag (zeroed by k_tile_sort, valid once non-zero; products are clamped to >= 1e-30, which still means "dead"),
-// written and polled with relaxed agent-scope accesses (sc1: L2 write-through / L1 bypass), no fences.  A unit only
-// ever waits for units with SMALLER indices; the grid is sized to be fully resident (launch_sort_and_blend), so the
-// unfinished unit with the smallest index always belongs to a running wave: no deadlock.  The spin is bounded
-// anyway (a wrong image is better than a hung device).
-__global__ void __launch_bounds__(256, 4) k_unit_blend_fused(const DeviceCounts* __restrict__ counts,
-                                                         const uint4* __restrict__ unit_tile,
-                                                         const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                         float* unit_tseg, float* __restrict__ unit_out)
-{
-    FR_UNIT_LOOP_BEGIN
-    const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
-    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
-    const float fx = (float)ui.px, fy = (float)ui.py;
-    const bool has_next = ui.base + kUnit < ui.n;
-
-    // ---- alphas of the unit (0 where the reference's tests reject the pair), and their running product
-    float al[kUnit];
-    float prod = 1.0f;
-#pragma unroll
-    for (int j = 0; j < kUnit; j++) {
-        const float4 q0 = s_rec[j * kRecQuads + 0];
-        const float2 q1 = *reinterpret_cast<const float2*>(&s_rec[j * kRecQuads + 1]);
-        const float dx = q0.x - fx, dy = q0.y - fy;
-        const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-        const float alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
-        const bool ok = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        al[j] = ok ? alpha : 0.f;
-        prod *= 1.f - al[j];
-    }
-    if (has_next)
-        __hip_atomic_store(unit_tseg + (size_t)u * kUnit + lane, fmaxf(prod, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // ---- transmittance entering the unit: products of the units in front (usually already published)
-    float T = 1.0f;
-    for (uint32_t p = u - ui.seg; p < u; p++) {
-        float v = __hip_atomic_load(unit_tseg + (size_t)p * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spins = 0; !__all(v != 0.f) && spins < (1u << 22); spins++) {
-            __builtin_amdgcn_s_sleep(2);
-            v = __hip_atomic_load(unit_tseg + (size_t)p * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        T *= v;
-    }
-
-    // ---- the reference's loop (forward.cu:330-361) over the stored alphas
-    bool dead = !ui.inside || (T < 0.0001f);
-    bool term = false;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f;
-    uint32_t last = 0;
-#pragma unroll
-    for (int j = 0; j < kUnit; j++) {
-        if ((j & (kGroup - 1)) == 0 && ((uint32_t)j >= ui.m || __all(dead))) break;
-        const float2 c01 = *reinterpret_cast<const float2*>(&s_rec[j * kRecQuads + 1].z);
-        const float c2 = s_rec[j * kRecQuads + 2].x;
-        bool c = !dead && (al[j] > 0.f);
-        const float test_T = T * (1.f - al[j]);
-        const bool fin = c && (test_T < 0.0001f);
-        term = term || fin;
-        dead = dead || fin;
-        c = c && !fin;
-        const float w = c ? al[j] * T : 0.f;
-        Cr += c01.x * w;
-        Cg += c01.y * w;
-        Cb += c2 * w;
-        T = c ? test_T : T;
-        last = c ? (ui.base + (uint32_t)j + 1u) : last;
     }
     float* o = unit_out + (size_t)u * 5 * kUnit + lane;
     o[0] = Cr;
@@ -1084,19 +1004,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
     return x;
 }
 
-// ================================================================== sparse forward: two launches per frame
+// ================================================================== sparse forward: one launch per frame
 // k_unit_tseg + k_unit_blend + k_tile_combine above evaluate all 64 x 64 (pixel, record) pairs of a unit, twice, in
 // three launches.  The sparse forward walks only the pairs the records' footprint masks name (see the sparse backward
-// below), and walks them ONCE: compositing is linear in the transmittance entering a unit, so
-//   k_unit_blend_local  every unit, as an independent wave, blends its records LOCALLY (T starts at 1, no termination
-//                       test): partial colour, product of (1 - alpha), last blended record
-//   k_tile_finish       one wave per tile chains the units: T_in of a unit = running transmittance; the local result is
-//                       scaled by it.  Only a pixel whose transmittance crosses the reference's 1e-4 threshold INSIDE a
-//                       unit (T_in >= 1e-4 > T_in * product; at most one unit per pixel) is walked again, from T_in, with
-//                       the reference's termination test.  Then: image, final T, contributor count, and every unit's
-//                       backward entry state.
-// (A one-launch variant, one workgroup per tile with barriers between the phases, was measured too: 30.7 us at config 2,
-// bound by the latency chain of its heaviest tiles; the unit-parallel split below has no such tail.)
+// below), and walks them ONCE: compositing is linear in the transmittance entering a unit, so every unit, as an
+// independent wave, first blends its records LOCALLY (T starts at 1, no termination test: partial colour, product of
+// (1 - alpha), last blended record), then learns the transmittance entering it from the products of the units in front
+// of it and scales.  Only a pixel whose transmittance crosses the reference's 1e-4 threshold INSIDE the unit
+// (T_in >= 1e-4 > T_in * product; at most one unit per pixel) is walked again, from T_in, with the reference's
+// termination test.  See k_unit_blend_chained for how the units of a tile talk to each other inside one launch.
+// Tried on the way here and dropped: one workgroup per tile with barriers between the phases (30.7 us at config 2, bound
+// by the latency chain of its heaviest tiles); local blend + a per-tile finishing kernel that chains the units and
+// re-walks the crossing ones itself (25 us at config 2 in two launches, but a serial string of re-walks per tile behind
+// an opaque surface: 64 us at opacity 0.9 against 33 us now).
 
 struct WalkOut {
     float Cr, Cg, Cb, T;
@@ -1206,65 +1126,6 @@ __device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restri
     return o;
 }
 
-// ---- launch 1: every unit is an independent wave (grid-stride), blended locally
-__global__ void __launch_bounds__(256) k_unit_blend_local(DeviceCounts* __restrict__ counts,
-                                                         const uint4* __restrict__ unit_tile,
-                                                         const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
-                                                         int H, int tiles_x, float* __restrict__ g_tseg,
-                                                         float* __restrict__ g_out, uint32_t dense_pairs, int pair_hist)
-{
-    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4* rec = s_rec_all[wave_in_wg];
-    const TransposeConsts tc = transpose_consts(lane);
-    const uint32_t nu = counts->num_units;
-    const uint32_t wave_stride = gridDim.x * kWavesPerWG;
-    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
-        const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
-        __builtin_amdgcn_wave_barrier();   // the previous unit's records are dead
-        RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
-        // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in `masks` for k_tile_finish
-        // and the backward.  (Computed here, not in the sort kernels: their waves sit on the frame's critical path
-        // with one tile each, these are thousands of independent ones.)
-        uint2 fm = make_uint2(0u, 0u);
-        if (ui.base + (uint32_t)lane < ui.n) {
-            fm = footprint_mask(rr.q0.x, rr.q0.y, rr.q0.z, rr.q0.w, rr.q1.x, rr.q1.y,
-                                (float)((int)(ui.tile % (uint32_t)tiles_x) * kTile), (float)((int)(ui.tile / (uint32_t)tiles_x) * kTile));
-            rr.q2.z = __uint_as_float(fm.x), rr.q2.w = __uint_as_float(fm.y);
-            masks[(size_t)ui.start + ui.base + (uint32_t)lane] = fm;
-        }
-        rec[lane * kRecQuads + 0] = rr.q0;
-        rec[lane * kRecQuads + 1] = rr.q1;
-        rec[lane * kRecQuads + 2] = rr.q2;
-        const uint2 bt = transpose_bits64(fm, lane, tc);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
-        // how many pairs the masks name decides the form of this unit's loop (the backward makes the same choice)
-        const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)__popc(fm.x) + (uint32_t)__popc(fm.y)), 63);
-        if (pair_hist && lane == 0)
-            atomicAdd(&counts->pair_hist[npairs <= 500 ? 0 : npairs <= 1000 ? 1 : npairs <= 1500 ? 2 : npairs <= 2500 ? 3 : 4], 1u);
-        // The first unit of a tile is entered with T = 1 exactly, so it is blended with the reference's termination test
-        // here and k_tile_finish takes it as final (bit 31 of `last`: the pixel terminated).  Behind an opaque surface
-        // that is where nearly every pixel ends.
-        const bool first = ui.base == 0u;
-        const float fx = (float)ui.px, fy = (float)ui.py;
-        WalkOut o;
-        if (npairs > dense_pairs)
-            o = first ? blend_unit_dense_local<true>(rec, ui.m, ui.inside, fx, fy, 0u) : blend_unit_dense_local<false>(rec, ui.m, ui.inside, fx, fy, ui.base);
-        else
-            o = first ? walk_unit_fwd<true>(rec, Bp, 1.0f, fx, fy, 0u) : walk_unit_fwd<false>(rec, Bp, 1.0f, fx, fy, ui.base);
-        if (o.term) o.last |= 0x80000000u;
-        g_tseg[(size_t)u * kUnit + lane] = o.T;
-        float* out = g_out + (size_t)u * 5 * kUnit + lane;
-        out[0] = o.Cr;
-        out[kUnit] = o.Cg;
-        out[2 * kUnit] = o.Cb;
-        out[4 * kUnit] = __uint_as_float(o.last);
-    }
-}
-
 constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
 
 // a unit's final row as written by another workgroup of the SAME launch (agent-scope load), or of an earlier one
@@ -1359,14 +1220,12 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
     }
 }
 
-// ---- the same blend with the chain resolved INSIDE the unit kernel (decoupled look-back)
-// k_tile_finish walks a tile's units one after the other and re-walks a unit wherever a pixel crosses the termination
-// threshold inside it: behind an opaque surface that is a serial string of re-walks per tile (30 of its 40 us on the
-// bench scene at opacity 0.9).  Here every unit publishes its per-pixel product as soon as it has it, reads the
-// products of the units in front of it in its tile (normally already there: they started at the same time), and so
-// knows its own entering transmittance while its records are still in LDS and its walk sets still in registers: the
-// crossing pixels are re-walked on the spot, by thousands of waves in parallel.  What is left per tile is a plain
-// gather (k_tile_gather).
+// ---- the blend with the unit chain resolved INSIDE the unit kernel (decoupled look-back)
+// Every unit publishes its per-pixel product as soon as it has it, reads the products of the units in front of it in
+// its tile (normally already there: they started at the same time), and so knows its own entering transmittance while
+// its records are still in LDS and its walk sets still in registers: the crossing pixels are re-walked on the spot, by
+// thousands of waves in parallel.  What is left per tile is a plain gather (gather_tile), done by the tile's LAST unit
+// once the others have delivered their rows (or by k_tile_gather as a launch of its own: FR_BLEND_FWD=gather).
 //   hand-off: MI355X_MICROARCH.md's data-tagged form — the 4-byte product is its own flag (zeroed by k_tile_sort,
 //   valid once non-zero; clamped to >= 1e-30, which still means "dead" to every reader), written and polled with
 //   relaxed agent-scope accesses, no fences.
@@ -1501,173 +1360,6 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (overflow) return;
     gather_tile<false>(v, tile, u0, (n + kUnit - 1) / kUnit, g_out, unit_state, W, H, bg0, bg1, bg2, out_color, lane);
-}
-
-// ---- launch 2: one wave per tile chains its units (running transmittance), re-walks a unit for the pixels that
-// terminate inside it, writes the image and the backward entry state of every unit.  The kernel executes almost no
-// arithmetic: it is a chain of dependent memory round trips, so the partials of up to kFinishRegs units are requested
-// together and stay in registers (one round trip, not one per unit, and no re-read for the suffix pass).
-constexpr int kFinishRegs = 8;
-
-struct FinishUnit {
-    float cr, cg, cb, To;
-};
-
-// one unit of the chain: scale the local result by the transmittance entering it, re-walk the crossing pixels
-__device__ __forceinline__ FinishUnit finish_unit(uint32_t k, float tl, float cr, float cg, float cb, uint32_t last_in,
-                                                  bool inside, float& Tin, bool& finished, float& Tf, uint32_t& ncon,
-                                                  const float4* __restrict__ trecs, const uint2* __restrict__ tmasks,
-                                                  uint32_t n, float4* rec, int lane, float fx, float fy)
-{
-    // T_in < 1e-4: an earlier unit already terminated this pixel, nothing here can be blended
-    const bool dead = !inside || finished || (Tin < 0.0001f);
-    // (unit 0 was blended WITH the termination test by k_unit_blend_local: its result is final)
-    const bool crosses = !dead && k != 0u && (Tin * tl < 0.0001f);
-    if (k == 0u && !dead) finished = (last_in >> 31) != 0u;
-    last_in &= 0x7FFFFFFFu;
-    FinishUnit o;
-    o.cr = dead ? 0.f : Tin * cr, o.cg = dead ? 0.f : Tin * cg, o.cb = dead ? 0.f : Tin * cb;
-    o.To = dead ? Tin : Tin * tl;
-    uint32_t last = dead ? 0u : last_in;
-    if (__any(crosses)) {   // (a pixel crosses the threshold in at most one unit)
-        const TransposeConsts tc = transpose_consts(lane);
-        __builtin_amdgcn_wave_barrier();
-        const RecRegs rr = fetch_record(trecs, k * kUnit + (uint32_t)lane, n);
-        const uint2 fm = (k * kUnit + (uint32_t)lane < n) ? tmasks[k * kUnit + (uint32_t)lane] : make_uint2(0u, 0u);
-        rec[lane * kRecQuads + 0] = rr.q0;
-        rec[lane * kRecQuads + 1] = rr.q1;
-        rec[lane * kRecQuads + 2] = rr.q2;
-        const uint2 bt = transpose_bits64(fm, lane, tc);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const u64 Bp = crosses ? (((u64)bt.y << 32) | bt.x) : 0ull;
-        const WalkOut x = walk_unit_fwd<true>(rec, Bp, Tin, fx, fy, k * kUnit);
-        if (crosses) {
-            o.cr = x.Cr, o.cg = x.Cg, o.cb = x.Cb, o.To = x.T, last = x.last;
-            finished = x.term;
-        }
-    }
-    if (!dead) {
-        Tf = o.To;
-        if (last) ncon = last;
-    }
-    // what enters the next unit: the product of the units' products (the exact value where the unit was re-walked)
-    Tin = dead ? Tin : o.To;
-    return o;
-}
-
-__global__ void __launch_bounds__(256) k_tile_finish(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                    const float4* __restrict__ recs, const uint2* __restrict__ masks,
-                                                    const float* __restrict__ g_tseg,
-                                                    float* __restrict__ g_out, float4* __restrict__ unit_state, int W, int H,
-                                                    const float* __restrict__ bg, float* __restrict__ out_color)
-{
-    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
-    const uint32_t n_tiles = (uint32_t)v.tiles_x * v.tiles_y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = blockIdx.x * kWavesPerWG + wave;
-    if (tile >= n_tiles) return;
-    // everything the tile needs first is requested in one go (the offset tables are valid even for an overflowed frame)
-    const uint32_t overflow = counts->overflow;
-    const uint32_t u0 = v.unit_offset[tile];
-    const uint32_t start = v.tile_offset[tile], n = v.tile_total[tile];
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    if (overflow) return;
-    const uint32_t nu = (n + kUnit - 1) / kUnit;
-    const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
-    const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
-    uint32_t ncon = 0;
-    if (nu != 0) {
-        float4* rec = s_rec_all[wave];
-        const float4* trecs = recs + (size_t)start * kRecQuads;
-        const uint2* tmasks = masks + start;
-        const float fx = (float)px, fy = (float)py;
-        float Tin = 1.0f;
-        bool finished = false;
-        const bool long_tile = nu > (uint32_t)kFinishRegs;
-        uint32_t k_end = nu;   // units [k_end, nu) lie behind the last contributor of every pixel: the backward skips them
-        for (uint32_t base = 0; base < nu; base += (uint32_t)kFinishRegs) {
-            float tl[kFinishRegs], cr[kFinishRegs], cg[kFinishRegs], cb[kFinishRegs];
-            uint32_t ls[kFinishRegs];
-#pragma unroll
-            for (int k = 0; k < kFinishRegs; k++) {
-                const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
-                const float* out = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
-                tl[k] = g_tseg[(size_t)(u0 + kk) * kUnit + lane];
-                cr[k] = out[0], cg[k] = out[kUnit], cb[k] = out[2 * kUnit];
-                ls[k] = __float_as_uint(out[4 * kUnit]);
-            }
-            FinishUnit f[kFinishRegs];
-#pragma unroll
-            for (int k = 0; k < kFinishRegs; k++) {
-                if (base + (uint32_t)k < nu) {
-                    f[k] = finish_unit(base + (uint32_t)k, tl[k], cr[k], cg[k], cb[k], ls[k], inside, Tin, finished, Tf, ncon, trecs,
-                                       tmasks, n, rec, lane, fx, fy);
-                    Cr += f[k].cr, Cg += f[k].cg, Cb += f[k].cb;
-                }
-            }
-            if (!long_tile) {
-                // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the transmittance at
-                // the unit's far boundary (= what the reference's accum_rec recurrence yields there); guard: k_tile_combine
-                float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-#pragma unroll
-                for (int k = kFinishRegs - 1; k >= 0; k--) {
-                    if ((uint32_t)k < nu) {
-                        const float inv = (f[k].To >= 0.0001f) ? __builtin_amdgcn_rcpf(f[k].To) : 0.f;
-                        unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, f[k].To);
-                        Sr += f[k].cr, Sg += f[k].cg, Sb += f[k].cb;
-                    }
-                }
-            } else {
-                // long tile: the final contributions are parked in the partial array for the suffix pass below
-#pragma unroll
-                for (int k = 0; k < kFinishRegs; k++) {
-                    if (base + (uint32_t)k < nu) {
-                        float* out = g_out + (size_t)(u0 + base + (uint32_t)k) * 5 * kUnit + lane;
-                        out[0] = f[k].cr, out[kUnit] = f[k].cg, out[2 * kUnit] = f[k].cb, out[3 * kUnit] = f[k].To;
-                    }
-                }
-                // every pixel terminated (or outside the image): nothing further back is blended, and the backward never
-                // reads the entry state of those units (their base is at or behind every pixel's last contributor)
-                if (__all(!inside || finished || Tin < 0.0001f)) {
-                    k_end = min(nu, base + (uint32_t)kFinishRegs);
-                    break;
-                }
-            }
-        }
-        if (long_tile) {
-            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-            for (uint32_t base = (k_end - 1u) & ~(uint32_t)(kFinishRegs - 1); ; base -= (uint32_t)kFinishRegs) {
-                float cr[kFinishRegs], cg[kFinishRegs], cb[kFinishRegs], To[kFinishRegs];
-#pragma unroll
-                for (int k = 0; k < kFinishRegs; k++) {
-                    const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
-                    const float* out = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
-                    cr[k] = out[0], cg[k] = out[kUnit], cb[k] = out[2 * kUnit], To[k] = out[3 * kUnit];
-                }
-#pragma unroll
-                for (int k = kFinishRegs - 1; k >= 0; k--) {
-                    if (base + (uint32_t)k < k_end) {
-                        const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
-                        unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
-                        Sr += cr[k], Sg += cg[k], Sb += cb[k];
-                    }
-                }
-                if (base == 0) break;
-            }
-        }
-    }
-    if (inside) {
-        v.final_T[pix] = Tf;
-        v.n_contrib[pix] = ncon;
-        out_color[pix] = Cr + Tf * bg0;
-        out_color[HW + pix] = Cg + Tf * bg1;
-        out_color[2 * HW + pix] = Cb + Tf * bg2;
-    }
 }
 
 __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCounts* __restrict__ counts, const ImageView v,
@@ -1887,19 +1579,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     const uint32_t unit_wgs = (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG);
     const uint32_t unit_grid = unit_wgs < kUnitGrid ? unit_wgs : kUnitGrid;
     int rc;
-    // k_unit_blend_fused waits for other workgroups inside the launch: its grid must be fully resident.  One less
-    // per CU than the occupancy query says (the query can be one too high when a kernel uses > 80 SGPRs).
-    if (h->fused_grid == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        FR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_unit_blend_fused, 64 * kWavesPerWG, 0));
-        FR_HIP(hipGetDevice(&dev));
-        FR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        per_cu = per_cu > 8 ? 8 : per_cu;
-        h->fused_grid = (per_cu >= 3 && cus > 0) ? (uint32_t)((per_cu - 1) * cus) : 1u;  // 1 = do not use the fused kernel
-    }
-    const bool fused = h->fused_grid > 1 && !(h->no_fused_blend);
-    const bool chained = !h->dense_blend_fwd && h->chained_blend_fwd;
-    const uint32_t fgrid = unit_wgs < h->fused_grid ? unit_wgs : h->fused_grid;
+    const bool chained = !h->dense_blend_fwd;   // the sparse forward: k_unit_blend_chained
     {
         StageScope sc(h, ST_SORT, s);
         // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
@@ -1907,7 +1587,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           (fused || chained) ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
+                           chained ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
                            h->host_counts_dev,  // small_blocks == Q
                            (chained && h->gather_in_chain) ? b.unit_done : nullptr,
                            (chained && h->gather_in_chain) ? out_color : nullptr, in.background, prm.W, prm.H);
@@ -1917,7 +1597,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
-    if (!h->dense_blend_fwd && h->chained_blend_fwd) {
+    if (chained) {
         StageScope sc(h, ST_BLEND_FWD, s);
         // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
         hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
@@ -1927,28 +1607,13 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         if (!h->gather_in_chain)
             hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
                                v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
-    } else if (!h->dense_blend_fwd) {
-        StageScope sc(h, ST_BLEND_FWD, s);
-        uint32_t g1 = unit_wgs < 1024u ? unit_wgs : 1024u;
-        if (const char* e = getenv("FR_FWD_GRID")) g1 = (uint32_t)atoi(e);   // (tuning experiments)
-        hipLaunchKernelGGL(k_unit_blend_local, dim3(g1), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
-                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0);
-        hipLaunchKernelGGL(k_tile_finish, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts, v,
-                           (const float4*)b.recs, (const uint2*)b.masks, b.unit_tseg, b.unit_out, b.unit_state, prm.W, prm.H,
-                           in.background, out_color);
     } else {
         StageScope sc(h, ST_BLEND_FWD, s);
-        if (fused) {
-            hipLaunchKernelGGL(k_unit_blend_fused, dim3(fgrid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                               (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out);
-        } else {
-            hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                               v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
-            hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                               v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg,
-                               b.unit_out);
-        }
+        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                           v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
+        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
+                           v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg,
+                           b.unit_out);
         hipLaunchKernelGGL(k_tile_combine, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s,
                            v.counts, v.unit_offset, v.tile_total, T, prm.W, prm.H, v.tiles_x,
                            in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);

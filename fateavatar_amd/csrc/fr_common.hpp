@@ -235,14 +235,10 @@ struct fr_handle_impl {
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
-    uint32_t fused_grid = 0;     // resident-grid size of k_unit_blend_fused (0 = not queried yet, 1 = kernel not usable)
-    bool no_fused_blend = true;  // default; FR_FUSED_BLEND=1 in the environment selects the experimental one-launch
-                                 // k_unit_blend_fused instead of k_unit_tseg + k_unit_blend
     bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
-    bool chained_blend_fwd = true;  // FR_BLEND_FWD=finish: k_unit_blend_local + k_tile_finish instead of k_unit_blend_chained + k_tile_gather
     bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];

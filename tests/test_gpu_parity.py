@@ -731,9 +731,12 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
     assert not torch.equal(va[0], va[1])
 
 
-def test_experimental_fused_blend_kernel_stays_correct(gpu_device):
-    """FR_FUSED_BLEND=1 (one-launch k_unit_blend_fused with the in-launch look-back) is off by default; it must keep
-    matching the oracle for as long as it stays in the tree.  Run in a subprocess: the switch is read at handle creation."""
+@pytest.mark.parametrize("mode", ["FR_BLEND_FWD=gather", "FR_BLEND_FWD=dense", "FR_BLEND_BWD=dense",
+                                  "FR_DENSE_PAIRS_FWD=0,FR_DENSE_PAIRS_BWD=0", "FR_DENSE_PAIRS_FWD=9999,FR_DENSE_PAIRS_BWD=9999"])
+def test_selectable_blend_paths_stay_correct(gpu_device, mode):
+    """The blend kernels the environment can select (the gather as its own launch, round 1's all-pairs
+    kernels, and the per-unit all-pairs / sparse choice forced either way) must keep matching the oracle for as long as
+    they stay in the tree.  Run in a subprocess: the switches are read at handle creation."""
     import os
     import subprocess
     import sys
@@ -742,16 +745,23 @@ def test_experimental_fused_blend_kernel_stays_correct(gpu_device):
         "import numpy as np, torch\n"
         "from fateavatar_amd import scenes\n"
         "from tests import util\n"
-        "from tests.test_gpu_parity import _check_forward\n"
+        "from tests.test_gpu_parity import _check_forward, _check_backward\n"
         "dev = torch.device('cuda:0')\n"
+        "rng = np.random.default_rng(0)\n"
         "for s in (scenes.head_scene(P=20000, res=256, sh_degree=1, seed=0, opacity=0.5),\n"
         "          scenes.random_scene(4000, 64, 64, sh_degree=0, seed=5, opacity_lo=0.6, opacity_hi=0.99, scale_lo=0.02, scale_hi=0.08)):\n"
-        "    o = util.oracle_forward(s); h = util.HipFrame(s, dev); _check_forward(o, h, 'fused')\n"
+        "    o = util.oracle_forward(s); h = util.HipFrame(s, dev); _check_forward(o, h, 'mode')\n"
         "    assert h.counts.max_tile_list > 64\n"
-        "print('fused-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, FR_FUSED_BLEND="1")
+        "    H, W = s.camera.image_height, s.camera.image_width\n"
+        "    dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)\n"
+        "    _check_backward(o, h, dpix, 'mode')\n"
+        "print('mode-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ)
+    for kv in mode.split(","):
+        k, v = kv.split("=")
+        env[k] = v
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert "fused-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "mode-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_long_lists_without_the_big_sorter_launch(gpu_device):
