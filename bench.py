@@ -374,7 +374,7 @@ def main():
                 if os.path.exists(cpath):   # written by tools/pmc.sh + tools/pmcstats.py from rocprofv3 --pmc passes
                     try:
                         cj = json.load(open(cpath))
-                        if cj.get("P") == args.P and cj.get("res") == args.res:
+                        if cj.get("P") == args.P and cj.get("res") == args.res and args.scale is None and args.opacity == 0.1:
                             traffic, src = cj.get("hbm_bytes_per_launch"), "profiles/blend_bwd_counters.json (" + str(cj.get("collected")) + ")"
                             if cj.get("sq_insts_valu_per_launch"):
                                 # wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)

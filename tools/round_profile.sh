@@ -6,6 +6,8 @@ O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-seconds 6 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
+python $R/bench.py --opacity 0.9 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_opaque.json 2>> $O/${tag}_bench.err
+python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_dense.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
 FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${tag}_bench_2ranks_gloo_1gpu.json 2>> $O/${tag}_bench.err
