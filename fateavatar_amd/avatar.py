@@ -29,6 +29,7 @@ from .model import TorchCamera
 from .optim import FusedAdam
 from .rasterizer import GradOut
 from .render import render
+from .loss import l1_loss_and_grad
 from .train import TrainStep
 
 # config/fateavatar.yaml:34-39 (group names of train/optim.py:15-21)
@@ -151,6 +152,7 @@ class AvatarStep(TrainStep):
         self.verts = canonical_verts.to(self.dev, torch.float32).clone().contiguous()   # static input of the captured step
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
+        self._dimage = torch.zeros_like(self.gt)   # dL/dimage of the step
         self.out = None
         self.use_graph = bool(use_graph)
         self._graph, self._eager_steps, self.overflows = None, 0, 0
@@ -168,14 +170,16 @@ class AvatarStep(TrainStep):
                                        pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
         frame = _BoundFrame(xyz, pc, rot, scl, (self.xyz_gradient_accum, self.denom))
         out = render(self.cam, frame, self.bg)
-        loss = torch.nn.functional.l1_loss(out["render"], self.gt)
-        loss.backward()
-        self.loss.copy_(loss.detach())
+        _, g = l1_loss_and_grad(out["render"], self.gt, loss_out=self.loss, grad_out=self._dimage)   # see TrainStep
+        out["render"].backward(g)
         self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
 
     def step(self, camera: TorchCamera, posed_verts: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
-        self.verts.copy_(posed_verts, non_blocking=True)
+        self._extra_inputs = [(self.verts, posed_verts)]
         return super().step(camera, gt_image)
+
+    def _load_inputs(self, camera, gt_image, extra=()):
+        super()._load_inputs(camera, gt_image, extra=self._extra_inputs)
 
     # ---- maintenance (train/iteration.py:62-86)
     def maintain(self, global_step: int, cfg: Optional[dict] = None) -> dict:
@@ -260,7 +264,7 @@ class AvatarStep(TrainStep):
         # 'optimizer' and 'densification' are additions a seamless resume needs; the reference saves neither
         return {"global_step": self.adam.step_count, "model": model,
                 "optimizer": {"exp_avg": self.adam.exp_avg.clone(), "exp_avg_sq": self.adam.exp_avg_sq.clone(),
-                              "state": self.adam.state.clone()},
+                              "state": self.adam.state[:4].clone()},
                 "densification": {"xyz_gradient_accum": self.xyz_gradient_accum.clone(), "denom": self.denom.clone()}}
 
     @torch.no_grad()
@@ -289,7 +293,8 @@ class AvatarStep(TrainStep):
         if opt is not None:
             self.adam.exp_avg.copy_(opt["exp_avg"])
             self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
-            self.adam.state.copy_(opt["state"])
+            self.adam.state.zero_()
+            self.adam.state[:4].copy_(opt["state"][:4])
         if dens is not None:
             self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])
             self.denom.copy_(dens["denom"])

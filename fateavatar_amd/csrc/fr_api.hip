@@ -305,4 +305,26 @@ int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, flo
     return launch_adam(*cfg, param, grad, exp_avg, exp_avg_sq, n, state, static_cast<hipStream_t>(stream));
 }
 
+size_t fr_l1_workspace_bytes(void) { return 17 * 128 + 1024 * sizeof(float); }
+
+int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, float* loss, void* workspace, void* stream)
+{
+    if (n > 0 && (!img || !gt || !loss || !workspace)) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad: null array");
+    if ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(grad)) & 15)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad: arrays must be 16-byte aligned");
+    return launch_l1_loss_grad(n, img, gt, grad, loss, workspace, static_cast<hipStream_t>(stream));
+}
+
+int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src, const uint64_t* count, void* stream)
+{
+    if (n_segments < 0 || n_segments > FR_COPY_MAX_SEGMENTS || (n_segments > 0 && (!dst || !src || !count)))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_multi_copy: 0..FR_COPY_MAX_SEGMENTS segments");
+    unsigned long long cnt[FR_COPY_MAX_SEGMENTS];
+    for (int i = 0; i < n_segments; i++) {
+        if (count[i] > 0 && (!dst[i] || !src[i])) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_multi_copy: null segment");
+        cnt[i] = count[i];
+    }
+    return launch_multi_copy(n_segments, dst, src, cnt, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -10,6 +10,21 @@
 
 namespace fr {
 
+// "Which workgroup of this launch finishes last?" with TWO levels of wrapping counters: atomics on one address are
+// served one at a time (about 10 ns each on MI355X: a single counter costs 8 us for 768 workgroups, 75 us for 8192), so
+// a workgroup counts itself into one of kDoneGroups counters and only the last of each group into the final one.
+// The counters sit in separate 128-byte lines: the L2 serves atomics on one LINE one at a time, too.
+// `c`: (kDoneGroups + 1) x kDoneStride zeroed words, left zeroed.  Call from one thread per workgroup.
+constexpr unsigned kDoneGroups = 16, kDoneStride = 32;
+__device__ __forceinline__ bool last_workgroup(unsigned* c)
+{
+    const unsigned groups = gridDim.x < kDoneGroups ? gridDim.x : kDoneGroups;
+    const unsigned g = blockIdx.x % groups;
+    const unsigned members = (gridDim.x - g + groups - 1u) / groups;   // workgroups b with b % groups == g
+    if (atomicInc(c + g * kDoneStride, members - 1u) != members - 1u) return false;  // (wraps back to 0)
+    return atomicInc(c + kDoneGroups * kDoneStride, groups - 1u) == groups - 1u;
+}
+
 struct AdamArgs {
     int n_seg;
     unsigned long long seg_end[FR_ADAM_MAX_SEGMENTS];
@@ -19,18 +34,11 @@ struct AdamArgs {
     float beta1, beta2, omb1, omb2, eps, grad_scale;  // omb = 1 - beta, rounded from double
 };
 
-// state = {step, 1 - beta1^step, 1 - beta2^step, -}: advanced on the device so that the host passes nothing that
-// changes from step to step (graph replay).  The bias corrections c_t = 1 - beta^t are carried by the recurrence
-// c_{t+1} = (1 - beta) + beta c_t (all terms positive: no cancellation; 1 - 0.999f alone is off by 1.3e-5).
-__global__ void k_adam_advance(float* state, float beta1, float omb1, float beta2, float omb2)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        state[0] += 1.0f;
-        state[1] = omb1 + beta1 * state[1];
-        state[2] = omb2 + beta2 * state[2];
-    }
-}
-
+// state = {step, 1 - beta1^step, 1 - beta2^step, -, ..., done-counters from word 32}: advanced on the device so that the host passes
+// nothing that changes from step to step (graph replay).  The bias corrections c_t = 1 - beta^t are carried by the recurrence
+// c_{t+1} = (1 - beta) + beta c_t (all terms positive: no cancellation; 1 - 0.999f alone is off by 1.3e-5).  Every
+// workgroup of k_adam derives this step's corrections from the OLD state; the workgroup that finishes last
+// (last_workgroup) stores the new one — no launch of its own for three floats.
 __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, float lr_over_bc1, float inv_sqrt_bc2,
                                           const AdamArgs& a)
 {
@@ -44,9 +52,10 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
 
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ param, const float4* __restrict__ grad,
                                               float4* __restrict__ exp_avg, float4* __restrict__ exp_avg_sq,
-                                              unsigned long long n, const float* __restrict__ state)
+                                              unsigned long long n, float* state)
 {
-    const float bc1 = state[1], bc2 = state[2];
+    const float step_new = state[0] + 1.0f;
+    const float bc1 = a.omb1 + a.beta1 * state[1], bc2 = a.omb2 + a.beta2 * state[2];
     const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const unsigned long long n4 = n / 4, stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += stride) {
@@ -79,6 +88,12 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ p
             for (int k = 0; k < 4 && e0 + k < n; k++) adam_one(ps[e0 + k], gs[e0 + k], ms[e0 + k], vs[e0 + k], lr[k], inv_sqrt_bc2, a);
         }
     }
+    // every thread of this workgroup has read the old state (above) before the barrier; the last workgroup to get here
+    // knows that all have
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (last_workgroup(reinterpret_cast<unsigned*>(state + 32))) state[0] = step_new, state[1] = bc1, state[2] = bc2;
+    }
 }
 
 int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
@@ -96,13 +111,120 @@ int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, floa
     }
     a.beta1 = (float)cfg.beta1, a.beta2 = (float)cfg.beta2, a.eps = (float)cfg.eps, a.grad_scale = cfg.grad_scale;
     a.omb1 = (float)(1.0 - cfg.beta1), a.omb2 = (float)(1.0 - cfg.beta2);
-    hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, s, state, a.beta1, a.omb1, a.beta2, a.omb2);
     const unsigned long long quads = (n + 3) / 4;
     unsigned long long blocks = (quads + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, reinterpret_cast<float4*>(param),
                        reinterpret_cast<const float4*>(grad), reinterpret_cast<float4*>(exp_avg),
                        reinterpret_cast<float4*>(exp_avg_sq), n, state);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- L1 image loss and its gradient, one launch
+// reference: nn.L1Loss(reduction='mean') on the rendered image (model/loss.py:92) followed by loss.backward() — in
+// PyTorch eight launch-bound elementwise / reduction kernels (sub, abs, mean, fill, sign, mul, ...: 41 us of a 205 us
+// optimisation step at 512 x 512).  Here: grad = sign(img - gt) / n and per-workgroup partial sums of |img - gt| in one
+// pass; the workgroup that finishes last adds the partials up in index order (deterministic) and stores the loss.
+constexpr unsigned kL1MaxBlocks = 1024;
+
+__global__ void __launch_bounds__(256) k_l1_loss_grad(const float* __restrict__ img, const float* __restrict__ gt,
+                                                      float* __restrict__ grad, unsigned long long n, float inv_n,
+                                                      float* partial, unsigned* counter, float* __restrict__ loss)
+{
+    __shared__ float s_red[4];
+    __shared__ bool s_last;
+    const unsigned long long n4 = n / 4, stride = (unsigned long long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(img)[i], b = reinterpret_cast<const float4*>(gt)[i];
+        const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc += fabsf(d[k]);
+            g[k] = d[k] > 0.f ? inv_n : (d[k] < 0.f ? -inv_n : 0.f);   // torch.sign: 0 at 0
+        }
+        if (grad) reinterpret_cast<float4*>(grad)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - 4 * n4)) {   // tail of a length that is not a multiple of 4
+        const unsigned long long e = 4 * n4 + threadIdx.x;
+        const float d = img[e] - gt[e];
+        acc += fabsf(d);
+        if (grad) grad[e] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // write-through store, wait for it, then count this workgroup in (see k_unit_blend_chained on the hand-off)
+        __hip_atomic_store(partial + blockIdx.x, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = last_workgroup(counter);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float t = 0.f;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+        t += __hip_atomic_load(partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_n;
+}
+
+int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
+                        hipStream_t s)
+{
+    if (n == 0) return FR_OK;
+    unsigned long long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > kL1MaxBlocks ? kL1MaxBlocks : blocks);
+    unsigned* counter = static_cast<unsigned*>(workspace);
+    float* partial = reinterpret_cast<float*>(counter + (kDoneGroups + 1) * kDoneStride);
+    hipLaunchKernelGGL(k_l1_loss_grad, dim3((unsigned)blocks), dim3(256), 0, s, img, gt, grad, n, (float)(1.0 / (double)n),
+                       partial, counter, loss);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
+// ---------------------------------------------------------------- several small device-to-device copies, one launch
+// The per-frame inputs of a captured step (camera block, posed vertices, target image) are copied into the buffers the
+// graph was captured with: as separate copies each is a launch-bound 5 us dispatch.
+struct CopyArgs {
+    int n;
+    float* dst[FR_COPY_MAX_SEGMENTS];
+    const float* src[FR_COPY_MAX_SEGMENTS];
+    unsigned long long count[FR_COPY_MAX_SEGMENTS];   // floats
+};
+
+__global__ void __launch_bounds__(256) k_multi_copy(CopyArgs a)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int sg = 0; sg < a.n; sg++) {
+        const unsigned long long n = a.count[sg];
+        const bool wide = ((reinterpret_cast<uintptr_t>(a.dst[sg]) | reinterpret_cast<uintptr_t>(a.src[sg])) & 15) == 0;
+        const unsigned long long n4 = wide ? n / 4 : 0;
+        for (unsigned long long i = t0; i < n4; i += stride)
+            reinterpret_cast<float4*>(a.dst[sg])[i] = reinterpret_cast<const float4*>(a.src[sg])[i];
+        for (unsigned long long e = 4 * n4 + t0; e < n; e += stride) a.dst[sg][e] = a.src[sg][e];
+    }
+}
+
+int launch_multi_copy(int n_seg, float* const* dst, const float* const* src, const unsigned long long* count, hipStream_t s)
+{
+    CopyArgs a;
+    a.n = n_seg;
+    unsigned long long most = 0;
+    for (int i = 0; i < FR_COPY_MAX_SEGMENTS; i++) {
+        a.dst[i] = i < n_seg ? dst[i] : nullptr, a.src[i] = i < n_seg ? src[i] : nullptr, a.count[i] = i < n_seg ? count[i] : 0ull;
+        most = a.count[i] > most ? a.count[i] : most;
+    }
+    if (most == 0) return FR_OK;
+    unsigned long long blocks = (most / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)blocks), dim3(256), 0, s, a);
     FR_HIP(hipGetLastError());
     return FR_OK;
 }

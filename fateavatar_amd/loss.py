@@ -1,0 +1,72 @@
+"""Image loss of the optimisation step.
+
+reference: `nn.L1Loss(reduction='mean')` on the rendered image (model/loss.py:92) followed by `loss.backward()` — eight
+launch-bound PyTorch kernels between the rasterizer's forward and its backward.  `l1_loss_and_grad` produces the loss
+and the gradient autograd would hand to the rasterizer (`sign(img - gt) / n`, for a unit upstream gradient) in one
+launch of the HIP library (`fr_l1_loss_grad`, include/fr_rasterizer.h); the caller continues with
+`render.backward(grad)`.  There is no CPU path."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_workspace = {}   # device index -> zeroed scratch (the kernel leaves it zeroed)
+
+
+def l1_loss_and_grad(img: torch.Tensor, gt: torch.Tensor, loss_out: Optional[torch.Tensor] = None,
+                     grad_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mean |img - gt| (0-dim device tensor) and its gradient with respect to `img`.  `loss_out` / `grad_out`: write into
+    these tensors instead of fresh ones (buffers of a captured step)."""
+    if not (img.is_cuda and gt.is_cuda):
+        raise RuntimeError("l1_loss_and_grad needs device tensors (there is no CPU path)")
+    if img.shape != gt.shape:
+        raise RuntimeError(f"l1_loss_and_grad: shapes differ: {tuple(img.shape)} vs {tuple(gt.shape)}")
+    img = img.detach()
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        img = img.float().contiguous()
+    if gt.dtype != torch.float32 or not gt.is_contiguous():
+        gt = gt.float().contiguous()
+    dev = img.device
+    grad = grad_out if grad_out is not None else torch.empty_like(img)
+    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=dev)
+    if grad.shape != img.shape or grad.dtype != torch.float32 or not grad.is_contiguous() or loss.numel() != 1:
+        raise RuntimeError("l1_loss_and_grad: bad output buffers")
+    L = _lib.lib()
+    ws = _workspace.get(dev.index)
+    if ws is None:
+        ws = _workspace[dev.index] = torch.zeros((L.fr_l1_workspace_bytes(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.fr_l1_loss_grad(img.numel(), img.data_ptr(), gt.data_ptr(), grad.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream)
+    if rc != _lib.FR_OK:
+        raise RuntimeError(f"fr_l1_loss_grad failed: {_lib.last_error()}")
+    return loss, grad
+
+
+def multi_copy(pairs) -> None:
+    """`dst.copy_(src)` for up to four (dst, src) pairs of contiguous float32 device tensors in ONE launch
+    (`fr_multi_copy`): the per-frame inputs of a captured step."""
+    import ctypes as C
+    pairs = [(d, s) for d, s in pairs if d.numel()]
+    if not pairs:
+        return
+    if len(pairs) > 4:
+        raise RuntimeError("multi_copy: at most four pairs")
+    dev = pairs[0][0].device
+    for d, s in pairs:
+        if not (d.is_cuda and s.is_cuda and d.device == dev and s.device == dev):
+            raise RuntimeError("multi_copy needs tensors of one device")
+        if d.dtype != torch.float32 or s.dtype != torch.float32 or not d.is_contiguous() or not s.is_contiguous() or \
+                d.numel() != s.numel():
+            raise RuntimeError("multi_copy: contiguous float32 tensors of equal size")
+    n = len(pairs)
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    cnt = (C.c_uint64 * n)(*[d.numel() for d, _ in pairs])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().fr_multi_copy(n, dst, src, cnt, torch.cuda.current_stream(dev).cuda_stream)
+    if rc != _lib.FR_OK:
+        raise RuntimeError(f"fr_multi_copy failed: {_lib.last_error()}")

@@ -169,7 +169,10 @@ class TorchCamera:
 
     def copy_from(self, other: "TorchCamera") -> None:
         """Overwrite the matrices in place (same intrinsics): lets a captured HIP graph render a new view."""
+        self.check_same_intrinsics(other)
+        self._packed.copy_(other._packed, non_blocking=True)
+
+    def check_same_intrinsics(self, other: "TorchCamera") -> None:
         if (other.image_height, other.image_width, other.FoVx, other.FoVy) != \
                 (self.image_height, self.image_width, self.FoVx, self.FoVy):
             raise ValueError("copy_from needs a camera with the same image size and field of view")
-        self._packed.copy_(other._packed, non_blocking=True)

@@ -34,7 +34,8 @@ class FusedAdam:
         self.param, self.grad = flat_param, flat_grad
         self.exp_avg = torch.zeros_like(flat_param)
         self.exp_avg_sq = torch.zeros_like(flat_param)
-        self.state = torch.zeros(4, dtype=torch.float32, device=flat_param.device)  # step, 1 - beta1^t, 1 - beta2^t, -
+        # step, 1 - beta1^t, 1 - beta2^t, -, kernel bookkeeping (FR_ADAM_STATE_FLOATS)
+        self.state = torch.zeros(_lib.FR_ADAM_STATE_FLOATS, dtype=torch.float32, device=flat_param.device)
         cfg = _lib.fr_adam_config()
         cfg.n_segments = len(segments)
         end = 0

@@ -21,6 +21,7 @@ from typing import Optional
 import torch
 
 from . import dp
+from .loss import l1_loss_and_grad, multi_copy
 from .model import FlatGaussians, TorchCamera
 from .optim import FusedAdam
 from .render import render
@@ -51,6 +52,7 @@ class TrainStep:
         self.cam = camera
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
+        self._dimage = torch.zeros_like(self.gt)   # dL/dimage of the step
         self.out = None
         self.use_graph = bool(use_graph)
         self._graph = None       # render .. backward (.. Adam when world == 1)
@@ -61,9 +63,10 @@ class TrainStep:
     def _forward_backward(self):
         self.pc.begin_step()                                   # zero_grad(set_to_none=True), iteration.py:48-49
         out = render(self.cam, self.pc, self.bg)               # activations + rasterizer (fused)
-        loss = torch.nn.functional.l1_loss(out["render"], self.gt)   # nn.L1Loss(reduction='mean'), loss.py:92
-        loss.backward()                                        # rasterizer backward; stats fused (fr_aux)
-        self.loss.copy_(loss.detach())
+        # nn.L1Loss(reduction='mean') (loss.py:92) + loss.backward(): the loss and the gradient autograd would hand to the
+        # rasterizer in one launch, written straight into the step's buffers; then the rasterizer backward (stats fused)
+        _, g = l1_loss_and_grad(out["render"], self.gt, loss_out=self.loss, grad_out=self._dimage)
+        out["render"].backward(g)
         # keep the step's outputs WITHOUT their autograd graph: a graph kept alive across steps keeps its
         # AccumulateGrad nodes (and the stream they were created on) alive, which breaks a later stream capture
         self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
@@ -97,9 +100,7 @@ class TrainStep:
 
     def step(self, camera: TorchCamera, gt_image: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's frame.  Returns the (device) loss scalar of the step."""
-        if camera is not self.cam:
-            self.cam.copy_from(camera)
-        self.gt.copy_(gt_image, non_blocking=True)
+        self._load_inputs(camera, gt_image)
         if self.use_graph and self._graph is None and self._eager_steps >= 2:
             self._capture()
         if self._graph is not None:
@@ -113,6 +114,20 @@ class TrainStep:
             dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
             self.adam.step()
         return self.loss
+
+    def _load_inputs(self, camera: TorchCamera, gt_image: torch.Tensor, extra=()) -> None:
+        """The frame's inputs go into the buffers the step was captured with — camera block, target image and whatever
+        a subclass adds — in one launch when they are device tensors already."""
+        pairs = list(extra)
+        if camera is not self.cam:
+            self.cam.check_same_intrinsics(camera)
+            pairs.append((self.cam._packed, camera._packed))
+        pairs.append((self.gt, gt_image))
+        if all(s.is_cuda and s.dtype == torch.float32 and s.is_contiguous() and s.shape == d.shape for d, s in pairs):
+            multi_copy(pairs)
+        else:
+            for d, s in pairs:
+                d.copy_(s, non_blocking=True)
 
     def _poll_overflow(self):
         """The scan kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
@@ -187,7 +202,7 @@ class TrainStep:
                  "_rotation": pc._rotation.detach().clone()}
         return {"global_step": self.adam.step_count, "model": model,
                 "optimizer": {"exp_avg": self.adam.exp_avg.clone(), "exp_avg_sq": self.adam.exp_avg_sq.clone(),
-                              "state": self.adam.state.clone()},
+                              "state": self.adam.state[:4].clone()},
                 "densification": {"xyz_gradient_accum": self.xyz_gradient_accum.clone(), "denom": self.denom.clone()}}
 
     @torch.no_grad()
@@ -205,7 +220,8 @@ class TrainStep:
         if opt is not None:
             self.adam.exp_avg.copy_(opt["exp_avg"])
             self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
-            self.adam.state.copy_(opt["state"])
+            self.adam.state.zero_()
+            self.adam.state[:4].copy_(opt["state"][:4])
         dens = sd.get("densification")
         if dens is not None:
             self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])

@@ -180,12 +180,13 @@ int fr_backward(fr_handle* h, const fr_params* prm, const fr_inputs* in, const i
  * Gaussian parameter groups of train/optim.py:11-37: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
  * The buffer is cut into up to FR_ADAM_MAX_SEGMENTS consecutive segments, each with its own learning rate (the
  * reference's param groups); param / grad / exp_avg / exp_avg_sq are device arrays of n floats with the same
- * layout.  `state` is a device array of 4 floats owned by the caller, zero-initialised once: {step, 1 - beta1^step,
- * 1 - beta2^step, unused}; every call first advances it on the device (so the call is hipGraph-capturable: nothing
- * step-dependent is a kernel argument) and then applies
+ * layout.  `state` is a device array of FR_ADAM_STATE_FLOATS floats owned by the caller, zero-initialised once: {step,
+ * 1 - beta1^step, 1 - beta2^step, unused, ..., kernel bookkeeping from word 32 on that is zero between calls}; every call
+ * advances it on the device (so the call is hipGraph-capturable: nothing step-dependent is a kernel argument) and applies
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
  * with g = grad_scale * grad (grad_scale: e.g. 1/world_size after a SUM all-reduce). */
 #define FR_ADAM_MAX_SEGMENTS 16
+#define FR_ADAM_STATE_FLOATS 576
 typedef struct fr_adam_config {
     int32_t n_segments;
     uint64_t segment_end[FR_ADAM_MAX_SEGMENTS]; /* exclusive end offset (in floats) of each segment, ascending; last == n */
@@ -201,6 +202,20 @@ typedef struct fr_adam_config {
 } fr_adam_config;
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  uint64_t n, float* state, void* hip_stream);
+
+/* ---- the image loss of the optimisation step (reference nn.L1Loss(reduction='mean') on the rendered
+ * image, model/loss.py:92, followed by loss.backward()): loss = mean |img - gt| and grad = sign(img - gt) / n (what
+ * autograd hands to the rasterizer's backward for a unit upstream gradient) in ONE launch.  `grad` may be NULL.
+ * `workspace`: fr_l1_workspace_bytes() bytes of device memory, zeroed ONCE by the caller (the kernel leaves it zeroed);
+ * `loss`: one device float.  All arrays on the device, n floats each. */
+size_t fr_l1_workspace_bytes(void);
+int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
+                    void* hip_stream);
+
+/* ---- up to FR_COPY_MAX_SEGMENTS device-to-device copies of float arrays in one launch (the per-frame inputs of a
+ * captured step: camera block, posed vertices, target image).  Segments must not overlap each other. */
+#define FR_COPY_MAX_SEGMENTS 4
+int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src, const uint64_t* count, void* hip_stream);
 
 /* ---- FateAvatar's mesh binding (reference model/fateavatar.py:225-258 with
  * volume_rendering/mesh_compute.py:27-59 and pytorch3d's matrix_to_quaternion / quaternion_multiply): from the posed

@@ -1,0 +1,72 @@
+"""The step helpers around the rasterizer: fused L1 loss + gradient, one-launch input copies."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(3, 512, 512), (3, 37, 53), (1, 1, 3), (3, 1024, 1024)])
+def test_l1_loss_and_grad_matches_autograd(gpu_device, shape):
+    """reference: nn.L1Loss(reduction='mean') + backward (model/loss.py:92).  Loss to 1e-6 relative (different summation
+    order), gradient exactly sign(img - gt) / n — including 0 where the two agree."""
+    from fateavatar_amd.loss import l1_loss_and_grad
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    img = torch.rand(shape, generator=g).to(gpu_device)
+    gt = torch.rand(shape, generator=g).to(gpu_device)
+    gt.view(-1)[::7] = img.view(-1)[::7]          # exact ties: sign(0) = 0
+    ref_in = img.clone().requires_grad_(True)
+    ref = torch.nn.functional.l1_loss(ref_in, gt)
+    ref.backward()
+    for _ in range(3):                             # the workspace must come back zeroed: repeat
+        loss, grad = l1_loss_and_grad(img, gt)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-9
+        assert torch.equal(grad, ref_in.grad)
+    # into caller-owned buffers
+    lo, go = torch.zeros((), device=gpu_device), torch.zeros_like(img)
+    l2, g2 = l1_loss_and_grad(img, gt, loss_out=lo, grad_out=go)
+    assert l2.data_ptr() == lo.data_ptr() and g2.data_ptr() == go.data_ptr() and torch.equal(go, ref_in.grad)
+
+
+def test_l1_gradient_drives_the_rasterizer_backward(gpu_device):
+    """render.backward(grad) with the fused gradient = l1_loss(render, gt).backward(): same parameter gradients."""
+    from fateavatar_amd import scenes
+    from fateavatar_amd.loss import l1_loss_and_grad
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    s = scenes.head_scene(P=5000, res=128, sh_degree=1, seed=2, opacity=0.5)
+    cam = TorchCamera(s.camera, gpu_device)
+    gt = torch.rand((3, 128, 128), device=gpu_device)
+    bg = torch.ones(3, device=gpu_device)
+    grads = []
+    for fused in (False, True):
+        pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, s.sh_degree, gpu_device)
+        pc.begin_step()
+        out = render(cam, pc, bg)
+        if fused:
+            _, g = l1_loss_and_grad(out["render"], gt)
+            out["render"].backward(g)
+        else:
+            torch.nn.functional.l1_loss(out["render"], gt).backward()
+        grads.append(pc.collect_grads().clone())
+    assert float(grads[0].abs().max()) > 0
+    # (the blend backward sums with float atomics: two runs agree to rounding, not bit for bit)
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-9)
+
+
+def test_multi_copy(gpu_device):
+    from fateavatar_amd.loss import multi_copy
+    rng = np.random.default_rng(0)
+    sizes = [35, 3 * 64 * 64, 5023 * 3, 1]
+    src = [torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(gpu_device) for n in sizes]
+    dst = [torch.zeros(n, device=gpu_device) for n in sizes]
+    multi_copy(list(zip(dst, src)))
+    for d, s in zip(dst, src):
+        assert torch.equal(d, s)
+    # unaligned views fall back to scalar copies inside the kernel
+    big = torch.zeros(1000, device=gpu_device)
+    multi_copy([(big[1:36], src[0])])
+    assert torch.equal(big[1:36], src[0]) and float(big[0]) == 0 and float(big[36]) == 0
+    with pytest.raises(RuntimeError):
+        multi_copy([(dst[0], src[1])])
