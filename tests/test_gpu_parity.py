@@ -764,6 +764,31 @@ def test_selectable_blend_paths_stay_correct(gpu_device, mode):
     assert "mode-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_forward_chain_makes_progress_while_other_work_holds_the_cus(gpu_device):
+    """k_unit_blend_chained resolves each tile's unit chain INSIDE one launch (units wait for the products of the units
+    in front of them).  Its progress argument needs no residency: a workgroup only waits for lower-numbered ones and
+    exits when done.  Render long-list frames while a side stream keeps every CU busy with large GEMMs: the frames must
+    complete (the test would hang otherwise) and match the oracle."""
+    import torch
+    s = scenes.random_scene(6000, 96, 96, sh_degree=0, seed=17, spread=0.01, scale_lo=0.004, scale_hi=0.01,
+                            opacity_lo=0.05, opacity_hi=0.4)
+    o = util.oracle_forward(s)
+    side = torch.cuda.Stream(device=gpu_device)
+    a = torch.randn((4096, 4096), device=gpu_device)
+    stop_after = 40
+    with torch.cuda.stream(side):
+        for _ in range(stop_after):
+            a = torch.nn.functional.normalize(a @ a, dim=1)
+    frames = []
+    for _ in range(12):
+        frames.append(util.HipFrame(s, gpu_device))
+    torch.cuda.synchronize()
+    assert frames[0].counts.max_tile_list > 8 * 64       # chains of more than eight units
+    for k in (0, 5, 11):
+        _check_forward(o, frames[k], f"busy-{k}")
+    assert torch.isfinite(a).all()
+
+
 def test_long_lists_without_the_big_sorter_launch(gpu_device):
     """The big-list sorter is only launched when the previous frame had a list longer than 1024; a frame whose long
     lists come as a surprise is sorted by the slow path inside k_tile_sort and must be just as correct.  Frame order:
