@@ -97,7 +97,10 @@ def _check_backward(o, h, dpix, name):
             continue
         fr = util.frac_close(got[keep], ref[keep], 1e-4, 1e-6 * scale)
         rl = util.rel_l2(got[keep], ref[keep])
-        assert fr >= 0.999 and rl <= 2e-4, (name, k, fr, rl, n_flips, int(skip.sum()))
+        # (0.1 % of the entries, but never fewer than three: a scene of 100 Gaussians has 400 quaternion entries, and an
+        # entry that is the small difference of large terms misses a 1e-4 relative test in fp32 either way)
+        n_off = round((1.0 - fr) * got[keep].size)
+        assert (fr >= 0.999 or n_off <= 3) and rl <= 2e-4, (name, k, fr, rl, n_flips, int(skip.sum()))
         # Gaussians that share a pixel with a threshold flip: same sign and size, not garbage
         if skip.any():
             assert util.rel_l2(got[skip], ref[skip]) <= 0.2, (name, k, "flip-affected rows")
