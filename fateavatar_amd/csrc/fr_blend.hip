@@ -1127,6 +1127,8 @@ __device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restri
 }
 
 constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
+constexpr uint32_t kChainSpins = 1u << 22;   // bound of every in-launch wait (seconds): a wait that runs out sets word 6
+                                             // of the pinned count slot and the next fr_* call fails loudly
 
 // a unit's final row as written by another workgroup of the SAME launch (agent-scope load), or of an earlier one
 template <bool COHERENT>
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
 //   progress: a unit only waits for units with SMALLER indices, a workgroup takes exactly its four units and exits
 //   (no grid-stride loop), and workgroups are dispatched in index order: the unfinished workgroup with the smallest
 //   index never waits for one that has not been dispatched, so it finishes and frees its slot whatever else holds
-//   compute units.  The spin is bounded anyway.
+//   compute units.  Every wait is bounded anyway, and one that runs out is reported (kChainSpins).
 // A pixel is dead in a unit iff the product in front of it is below 1e-4 (products only shrink).  A pixel predicted to
 // cross whose exact walk stops short of the test (the two products differ in the last bits, right at 1e-4) is dead
 // behind this unit all the same — and that is what the reference computes too: its next contributor would trip the
@@ -1244,7 +1246,8 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
                                                            int H, int tiles_x, float* g_tseg, float* g_out,
                                                            uint32_t dense_pairs, int pair_hist, uint32_t* unit_done,
                                                            const ImageView v, float4* __restrict__ unit_state,
-                                                           const float* __restrict__ bg, float* __restrict__ out_color)
+                                                           const float* __restrict__ bg, float* __restrict__ out_color,
+                                                           uint32_t* __restrict__ host_words)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
@@ -1290,10 +1293,12 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (p + (uint32_t)k < u) {
-                for (uint32_t spins = 0; !__all(pv[k] != 0.f) && spins < (1u << 22); spins++) {
+                uint32_t spins = 0;
+                for (; !__all(pv[k] != 0.f) && spins < kChainSpins; spins++) {
                     __builtin_amdgcn_s_sleep(2);
                     pv[k] = __hip_atomic_load(g_tseg + (size_t)(p + (uint32_t)k) * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (spins == kChainSpins && lane == 0) host_words[6] = 1u;   // never seen; fr_* calls report it (fr_api.hip)
                 Tin *= pv[k];
             }
         }
@@ -1321,6 +1326,8 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
     }
     // ---- gather in the chain: the tile's LAST unit adds everything up once the others have delivered.  The rows are
     // written at agent scope (write-through), the wave waits until they are, and only then raises the unit's flag.
+    // (Measured against this form: the four values as ONE 16-byte sc1 buffer store per pixel — the same time; the last
+    // unit keeping its own row in registers instead of storing and re-reading it — 1 to 3.5 us SLOWER at config 2.)
     __hip_atomic_store(out, Cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(out + kUnit, Cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(out + 2 * kUnit, Cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1335,10 +1342,12 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
     for (uint32_t p = u0; p < u; p += 64) {
         const uint32_t q = min(p + (uint32_t)lane, u - 1u);
         uint32_t d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spins = 0; !__all(d != 0u) && spins < (1u << 22); spins++) {
+        uint32_t spins = 0;
+        for (; !__all(d != 0u) && spins < kChainSpins; spins++) {
             __builtin_amdgcn_s_sleep(2);
             d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (spins == kChainSpins && lane == 0) host_words[6] = 1u;
     }
     asm volatile("" ::: "memory");
     gather_tile<true>(v, ui.tile, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
@@ -1603,7 +1612,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
                            (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
                            h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0, h->gather_in_chain ? b.unit_done : nullptr, v,
-                           b.unit_state, in.background, out_color);
+                           b.unit_state, in.background, out_color, reinterpret_cast<uint32_t*>(h->host_counts_dev));
         if (!h->gather_in_chain)
             hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
                                v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
