@@ -109,6 +109,7 @@ int fr_create(fr_handle** out)
     const char* pb = getenv("FR_DENSE_PAIRS_BWD");
     h->dense_pairs_fwd = pf ? (uint32_t)strtoul(pf, nullptr, 10) : kDensePairsFwd;
     h->dense_pairs_bwd = pb ? (uint32_t)strtoul(pb, nullptr, 10) : kDensePairsBwd;
+    if (const char* cs = getenv("FR_CHAIN_SPINS")) h->chain_spins = (uint32_t)strtoul(cs, nullptr, 10);
     const char* ph = getenv("FR_DEBUG_PAIR_HIST");
     h->debug_pair_hist = ph && ph[0] == '1';
     *out = reinterpret_cast<fr_handle*>(h);
@@ -167,8 +168,6 @@ size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H)
     return BinningView::bytes((size_t)capacity, (size_t)v.tiles_x * v.tiles_y);
 }
 
-static int chain_timeout_check(fr_handle_impl* h);
-
 int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
                void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts, void* stream)
 {
@@ -176,7 +175,6 @@ int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* 
     if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
     int rc = check_frame(prm, in, true);
     if (rc) return rc;
-    if ((rc = chain_timeout_check(h))) return rc;
     if (!out_color || !image || (prm->P > 0 && (!radii || !geometry)) || (binning_capacity > 0 && !binning))
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "null output / scratch pointer");
     if (binning_capacity >= (1ull << 32)) return fail_msg(FR_ERR_UNSUPPORTED, "binning capacity must be < 2^32 instances");
@@ -184,21 +182,10 @@ int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* 
                           static_cast<hipStream_t>(stream));
 }
 
-// word 6 of the pinned count slot: an in-launch wait of k_unit_blend_chained ran out (fr_blend.hip, kChainSpins) — the
-// frame that set it is wrong.  Sticky until reported once.
-static int chain_timeout_check(fr_handle_impl* h)
-{
-    uint32_t* w = reinterpret_cast<uint32_t*>(h->host_counts);
-    if (!w[6]) return FR_OK;
-    w[6] = 0u;
-    return fail_msg(FR_ERR_HIP, "a blend unit waited in vain for the units in front of it (k_unit_blend_chained): an earlier frame is incomplete");
-}
-
 int fr_read_counts(fr_handle* hh, fr_counts* counts)
 {
     fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
     if (!h || !counts) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument");
-    if (int rc = chain_timeout_check(h)) return rc;
     *counts = *h->host_counts;
     return FR_OK;   // (valid once the frame's stream has been synchronised: the caller's responsibility)
 }
@@ -210,7 +197,6 @@ int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const 
     if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
     int rc = check_frame(prm, in, false);
     if (rc) return rc;
-    if ((rc = chain_timeout_check(h))) return rc;
     if (prm->P == 0) return FR_OK;
     if (!radii || !geometry || !image || !binning || !dL_dpix || !grads)
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "null pointer");

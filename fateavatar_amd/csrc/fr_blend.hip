@@ -1127,8 +1127,6 @@ __device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restri
 }
 
 constexpr uint32_t kDeadBit = 0x80000000u;   // in a unit's `last` word: the pixel entered the unit below 1e-4
-constexpr uint32_t kChainSpins = 1u << 22;   // bound of every in-launch wait (seconds): a wait that runs out sets word 6
-                                             // of the pinned count slot and the next fr_* call fails loudly
 
 // a unit's final row as written by another workgroup of the SAME launch (agent-scope load), or of an earlier one
 template <bool COHERENT>
@@ -1231,14 +1229,118 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
 //   hand-off: MI355X_MICROARCH.md's data-tagged form — the 4-byte product is its own flag (zeroed by k_tile_sort,
 //   valid once non-zero; clamped to >= 1e-30, which still means "dead" to every reader), written and polled with
 //   relaxed agent-scope accesses, no fences.
-//   progress: a unit only waits for units with SMALLER indices, a workgroup takes exactly its four units and exits
-//   (no grid-stride loop), and workgroups are dispatched in index order: the unfinished workgroup with the smallest
-//   index never waits for one that has not been dispatched, so it finishes and frees its slot whatever else holds
-//   compute units.  Every wait is bounded anyway, and one that runs out is reported (kChainSpins).
+//   progress: a unit only waits for units with SMALLER indices and a workgroup takes exactly its four units and exits
+//   (no grid-stride loop), so with workgroups dispatched in index order — what the hardware does — the unfinished
+//   workgroup with the smallest index never waits for an undispatched one, whatever else holds compute units.  The
+//   kernel does not RELY on that: every wait is a bounded poll (fr_handle_impl::chain_spins), and a unit whose poll
+//   runs out computes the missing product or row itself from the other unit's records (unit_product_from_memory,
+//   unit_row_from_memory).  Termination and the image are independent of dispatch order, timing and placement.
 // A pixel is dead in a unit iff the product in front of it is below 1e-4 (products only shrink).  A pixel predicted to
 // cross whose exact walk stops short of the test (the two products differ in the last bits, right at 1e-4) is dead
 // behind this unit all the same — and that is what the reference computes too: its next contributor would trip the
 // test without being blended, leaving T, the colour and n_contrib as they are.
+
+// ---- what a unit does when a wait runs out: it computes what it was waiting for itself, from memory.
+// The chain never depends on another workgroup making progress: every wait is a bounded poll with this behind it, so
+// the launch finishes, and finishes with the same image, under ANY dispatch order or placement (cdna_hip_programming.md
+// Guideline 16: "results must not depend on dispatch order, timing or workgroup -> XCD placement").  These loops read a
+// unit's records straight from memory with wave-uniform addresses (no LDS: the caller's own records live there) in the
+// same order and with the same expressions as the fast paths, so a helper and the owner of a unit store the same words.
+// `-m gpu` runs whole frames with the poll bound set to zero (FR_CHAIN_SPINS=0): every hand-off takes this path.
+struct UnitRow {
+    float cr, cg, cb, To;
+    uint32_t lw;
+};
+
+__device__ __forceinline__ void pair_alpha_from_memory(const float4* __restrict__ r, float fx, float fy, bool inside, float& alpha,
+                                                       bool& ok, float& c0, float& c1, float& c2)
+{
+    const float4 q0 = r[0], q1 = r[1];
+    const float dx = q0.x - fx, dy = q0.y - fy;
+    const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+    alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+    ok = inside && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+    c0 = q1.z, c1 = q1.w, c2 = r[2].x;
+}
+
+// per-pixel product of (1 - alpha) over unit p's blendable records: what unit p publishes
+__device__ float unit_product_from_memory(const uint4* __restrict__ unit_tile, const float4* __restrict__ recs, uint32_t p, float fx,
+                                          float fy, bool inside)
+{
+    const uint4 d = unit_tile[p];
+    const uint32_t base = d.y * kUnit, m = min((uint32_t)kUnit, d.w - base);
+    const float4* r = recs + (size_t)(d.z + base) * kRecQuads;
+    float t = 1.0f;
+    for (uint32_t j = 0; j < m; j++) {
+        float alpha, c0, c1, c2;
+        bool ok;
+        pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+        t = ok ? t * (1.f - alpha) : t;
+    }
+    return fmaxf(t, 1e-30f);
+}
+
+// unit q's final row given the transmittance entering it
+__device__ UnitRow unit_row_from_memory(const uint4* __restrict__ unit_tile, const float4* __restrict__ recs, uint32_t q, float Tin,
+                                        float fx, float fy, bool inside)
+{
+    const uint4 d = unit_tile[q];
+    const uint32_t base = d.y * kUnit, m = min((uint32_t)kUnit, d.w - base);
+    const float4* r = recs + (size_t)(d.z + base) * kRecQuads;
+    float t = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f;
+    uint32_t last = 0u;
+    for (uint32_t j = 0; j < m; j++) {   // the local blend (walk_unit_fwd<false> from T = 1)
+        float alpha, c0, c1, c2;
+        bool ok;
+        pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+        const float w = ok ? alpha * t : 0.f;
+        cr += c0 * w, cg += c1 * w, cb += c2 * w;
+        t = ok ? t * (1.f - alpha) : t;
+        last = ok ? (base + j + 1u) : last;
+    }
+    const bool dead = !inside || (Tin < 0.0001f);
+    const bool crosses = !dead && (Tin * t < 0.0001f);
+    UnitRow o;
+    o.cr = dead ? 0.f : Tin * cr, o.cg = dead ? 0.f : Tin * cg, o.cb = dead ? 0.f : Tin * cb;
+    o.To = dead ? Tin : Tin * t;
+    uint32_t lw = dead ? 0u : last;
+    if (__any(crosses)) {   // walk_unit_fwd<true> from Tin for the crossing pixels
+        float T = Tin, xr = 0.f, xg = 0.f, xb = 0.f;
+        uint32_t xl = 0u;
+        bool term = false;
+        for (uint32_t j = 0; j < m; j++) {
+            float alpha, c0, c1, c2;
+            bool ok;
+            pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+            bool c = ok && crosses;
+            const float test_T = T * (1.f - alpha);
+            const bool fin = c && !term && (test_T < 0.0001f);
+            term = term || fin;
+            c = c && !term;
+            const float w = c ? alpha * T : 0.f;
+            xr += c0 * w, xg += c1 * w, xb += c2 * w;
+            T = c ? test_T : T;
+            xl = c ? (base + j + 1u) : xl;
+        }
+        if (crosses) o.cr = xr, o.cg = xg, o.cb = xb, o.To = T, lw = xl;
+    }
+    o.lw = lw | (dead ? kDeadBit : 0u);
+    return o;
+}
+
+// the product unit p published — or, if it has not appeared after `spins` polls, computed here
+__device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __restrict__ unit_tile, const float4* __restrict__ recs,
+                                               uint32_t p, float first, uint32_t spins, int lane, float fx, float fy, bool inside)
+{
+    float v = first;
+    uint32_t k = 0;
+    for (; !__all(v != 0.f) && k < spins; k++) {
+        __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(g_tseg + (size_t)p * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!__all(v != 0.f)) v = unit_product_from_memory(unit_tile, recs, p, fx, fy, inside);
+    return v;
+}
 
 __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __restrict__ counts,
                                                            const uint4* __restrict__ unit_tile,
@@ -1247,7 +1349,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
                                                            uint32_t dense_pairs, int pair_hist, uint32_t* unit_done,
                                                            const ImageView v, float4* __restrict__ unit_state,
                                                            const float* __restrict__ bg, float* __restrict__ out_color,
-                                                           uint32_t* __restrict__ host_words)
+                                                           uint32_t chain_spins)
 {
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
@@ -1291,17 +1393,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
         for (int k = 0; k < 4; k++)   // (requested together; clamped: the loads stay unconditional)
             pv[k] = __hip_atomic_load(g_tseg + (size_t)min(p + (uint32_t)k, u - 1u) * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (p + (uint32_t)k < u) {
-                uint32_t spins = 0;
-                for (; !__all(pv[k] != 0.f) && spins < kChainSpins; spins++) {
-                    __builtin_amdgcn_s_sleep(2);
-                    pv[k] = __hip_atomic_load(g_tseg + (size_t)(p + (uint32_t)k) * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (spins == kChainSpins && lane == 0) host_words[6] = 1u;   // never seen; fr_* calls report it (fr_api.hip)
-                Tin *= pv[k];
-            }
-        }
+        for (int k = 0; k < 4; k++)
+            if (p + (uint32_t)k < u)
+                Tin *= chain_product(g_tseg, unit_tile, recs, p + (uint32_t)k, pv[k], chain_spins, lane, fx, fy, ui.inside);
     }
 
     // ---- the unit's final contribution
@@ -1342,12 +1436,30 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
     for (uint32_t p = u0; p < u; p += 64) {
         const uint32_t q = min(p + (uint32_t)lane, u - 1u);
         uint32_t d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        for (; !__all(d != 0u) && spins < kChainSpins; spins++) {
+        for (uint32_t spins = 0; !__all(d != 0u) && spins < chain_spins; spins++) {
             __builtin_amdgcn_s_sleep(2);
             d = __hip_atomic_load(unit_done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (spins == kChainSpins && lane == 0) host_words[6] = 1u;
+        // rows that have not arrived: this wave writes them itself (see unit_row_from_memory: the same words their
+        // owners store, whenever those get to it), front to back so that each one's entering transmittance is known
+        u64 missing = __ballot(d == 0u && p + (uint32_t)lane < u);
+        while (missing) {
+            const uint32_t qq = p + (uint32_t)__builtin_ctzll(missing);
+            missing &= missing - 1ull;
+            float tin = 1.0f;
+            for (uint32_t pp = u0; pp < qq; pp++)
+                tin *= chain_product(g_tseg, unit_tile, recs, pp,
+                                     __hip_atomic_load(g_tseg + (size_t)pp * kUnit + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0u,
+                                     lane, fx, fy, ui.inside);
+            const UnitRow rr = unit_row_from_memory(unit_tile, recs, qq, tin, fx, fy, ui.inside);
+            float* o2 = g_out + (size_t)qq * 5 * kUnit + lane;
+            __hip_atomic_store(o2, rr.cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o2 + kUnit, rr.cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o2 + 2 * kUnit, rr.cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o2 + 3 * kUnit, rr.To, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o2 + 4 * kUnit, __uint_as_float(rr.lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("" ::: "memory");
     gather_tile<true>(v, ui.tile, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
@@ -1612,7 +1724,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
                            (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
                            h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0, h->gather_in_chain ? b.unit_done : nullptr, v,
-                           b.unit_state, in.background, out_color, reinterpret_cast<uint32_t*>(h->host_counts_dev));
+                           b.unit_state, in.background, out_color, h->chain_spins);
         if (!h->gather_in_chain)
             hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
                                v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);

@@ -238,6 +238,7 @@ struct fr_handle_impl {
     bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
+    uint32_t chain_spins = 1u << 16;   // polls before a blend unit stops waiting for another one and computes its product / row itself (FR_CHAIN_SPINS)
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
     bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events

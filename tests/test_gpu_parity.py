@@ -735,11 +735,14 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
 
 
 @pytest.mark.parametrize("mode", ["FR_BLEND_FWD=gather", "FR_BLEND_FWD=dense", "FR_BLEND_BWD=dense",
-                                  "FR_DENSE_PAIRS_FWD=0,FR_DENSE_PAIRS_BWD=0", "FR_DENSE_PAIRS_FWD=9999,FR_DENSE_PAIRS_BWD=9999"])
+                                  "FR_DENSE_PAIRS_FWD=0,FR_DENSE_PAIRS_BWD=0", "FR_DENSE_PAIRS_FWD=9999,FR_DENSE_PAIRS_BWD=9999",
+                                  "FR_CHAIN_SPINS=0", "FR_CHAIN_SPINS=3"])
 def test_selectable_blend_paths_stay_correct(gpu_device, mode):
     """The blend kernels the environment can select (the gather as its own launch, round 1's all-pairs
     kernels, and the per-unit all-pairs / sparse choice forced either way) must keep matching the oracle for as long as
-    they stay in the tree.  Run in a subprocess: the switches are read at handle creation."""
+    they stay in the tree.  FR_CHAIN_SPINS=0 / 3: the units of the one-launch forward give up waiting for each other at
+    once (after three polls) and compute the missing products and rows themselves — the path that makes the launch
+    independent of dispatch order.  Run in a subprocess: the switches are read at handle creation."""
     import os
     import subprocess
     import sys
