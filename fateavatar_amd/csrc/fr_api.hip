@@ -98,6 +98,9 @@ int fr_create(fr_handle** out)
     FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
+    FR_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
     const char* bf = getenv("FR_BLEND_FWD");
     h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
     h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
@@ -122,6 +125,9 @@ int fr_destroy(fr_handle* hh)
     if (!h) return FR_OK;
     (void)hipEventDestroy(h->counts_ready);
     if (h->frame_done) (void)hipEventDestroy(h->frame_done);
+    if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+    if (h->side_join) (void)hipEventDestroy(h->side_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     for (int st = 0; st < ST_COUNT; st++)
         for (size_t i = 0; i < h->ev[st].start.size(); i++) {
             (void)hipEventDestroy(h->ev[st].start[i]);

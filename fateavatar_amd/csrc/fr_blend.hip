@@ -480,14 +480,17 @@ constexpr uint32_t kBigSorters = 512;
 __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, float4* recs, GeomView g)
 {
     __shared__ SortXchgT<16> sx;
+    SortXchgT<8>& sx8 = *reinterpret_cast<SortXchgT<8>*>(&sx);   // (lists up to 2048: half the network)
     if (frame_overflow(v.counts, v.bucket_cap)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
     for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
         const uint32_t tile = v.big_list[item];
-        sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_total[tile], wave, lane, g, sx,
-                            (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+        const uint32_t n = v.tile_total[tile];
+        const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
+        if (n <= 2048u) sort_tile_group<8>(key_src(v, tile), recs, v.tile_offset[tile], n, wave, lane, g, sx8, tx0, ty0);
+        else sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], n, wave, lane, g, sx, tx0, ty0);
     }
     for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
         const uint32_t tile = v.large_list[item];
@@ -1706,6 +1709,14 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
         // longer than 1024 (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
         const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
+        // ... and then NEXT TO k_tile_sort, on the handle's side stream: its few long lists take as long as all the
+        // short ones together (config 5: 48 us against 65), the two kernels touch different tiles
+        if (launch_big) {
+            FR_HIP(hipEventRecord(h->side_fork, s));
+            FR_HIP(hipStreamWaitEvent(h->side_stream, h->side_fork, 0));
+            hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, h->side_stream, v, (u64*)b.keys, b.recs, g);
+            FR_HIP(hipEventRecord(h->side_join, h->side_stream));
+        }
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
                            chained ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
@@ -1714,7 +1725,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
                            (chained && h->gather_in_chain) ? out_color : nullptr, in.background, prm.W, prm.H);
         // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
         if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
-        if (launch_big) hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, s, v, (u64*)b.keys, b.recs, g);
+        if (launch_big) FR_HIP(hipStreamWaitEvent(s, h->side_join, 0));
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;

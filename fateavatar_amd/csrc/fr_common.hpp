@@ -233,6 +233,10 @@ struct fr_handle_impl {
     // behind the last kernel that touches the counters of the previous frame (not while a stream is being captured:
     // a capture is ordered by its own stream, and replays of the graph are ordered by whoever launches them).
     hipEvent_t frame_done = nullptr;
+    // the big-list sorter (lists > 1024, only launched for frames that have had one) runs NEXT TO k_tile_sort on this
+    // stream: fork after the totals kernel, join before the blend (captured as a parallel branch in a HIP graph)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
