@@ -273,9 +273,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
 
             // ---- colour (forward.cu:20-71)
             float col[3];
+            float raw_sum = 0.f;   // of the colour BEFORE the clamp at 0 (fmaxf would turn a NaN into 0)
             uint8_t clamp_bits = 0;
             if (a.colors_precomp) {
                 col[0] = a.colors_precomp[3 * idx], col[1] = a.colors_precomp[3 * idx + 1], col[2] = a.colors_precomp[3 * idx + 2];
+                raw_sum = (col[0] + col[1]) + col[2];
             } else {
                 float dx = p_orig.x - cam.campos[0], dy = p_orig.y - cam.campos[1], dz = p_orig.z - cam.campos[2];
                 const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
                     const float v = sh_channel(sh, c, a.D, dx, dy, dz);
                     if (v < 0) clamp_bits |= (uint8_t)(1u << c);
                     col[c] = fmaxf(v, 0.0f);
+                    raw_sum += v;
                 }
             }
 
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             // rotation, opacity or colour) is DROPPED like a culled one — radius 0, no instances, zero gradient rows —
             // instead of spreading NaN over the image and every gradient as the reference's arithmetic would.
             {
-                const float chk = (((pix_x + pix_y) + (conic_a + conic_b + conic_c)) + (col[0] + col[1] + col[2])) + (opacity + p_view.z);
+                const float chk = (((pix_x + pix_y) + (conic_a + conic_b + conic_c)) + raw_sum) + (opacity + p_view.z);
                 if (!(fabsf(chk) < 3.0e38f)) break;
             }
             radius_out = mr;

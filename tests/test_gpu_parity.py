@@ -818,20 +818,23 @@ def test_long_lists_without_the_big_sorter_launch(gpu_device):
 
 
 def test_non_finite_gaussians_are_dropped_not_propagated(gpu_device):
-    """Contract: a Gaussian with a non-finite opacity, scale or position is dropped — no instance, no
-    contribution, zero gradient rows — instead of poisoning the image as the reference's arithmetic would; every other
-    Gaussian renders exactly as if the bad ones were not there."""
+    """Contract: a Gaussian with a non-finite opacity, scale, position or SH coefficient is dropped — no
+    instance, no contribution, radius 0, zero gradient rows — instead of poisoning the image as the reference's
+    arithmetic would; every other Gaussian renders exactly as if the bad ones were not there."""
     s = scenes.random_scene(1500, 64, 80, sh_degree=1, seed=31)
     bad = np.zeros(s.P, bool)
-    bad[[3, 400, 777, 1200]] = True
+    bad[[3, 400, 777, 1200, 55, 910]] = True
     clean = scenes.GaussianScene(s.means3D[~bad], s.scales[~bad], s.rotations[~bad], s.opacities[~bad], s.shs[~bad],
                                  s.sh_degree, s.bg, s.camera)
     s.opacities[3, 0] = np.nan
     s.scales[400, 1] = np.inf
     s.means3D[777, 0] = np.nan
     s.opacities[1200, 0] = -np.inf
+    s.shs[55, 2, 1] = np.nan
+    s.shs[910, 0, 0] = np.inf
     h = util.HipFrame(s, gpu_device)
     hc = util.HipFrame(clean, gpu_device)
+    assert (h.radii.cpu().numpy()[bad] == 0).all()
     col = h.color.cpu().numpy()
     assert np.isfinite(col).all()
     np.testing.assert_array_equal(col, hc.color.cpu().numpy())

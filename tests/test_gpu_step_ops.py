@@ -21,7 +21,7 @@ def test_l1_loss_and_grad_matches_autograd(gpu_device, shape):
     for _ in range(3):                             # the workspace must come back zeroed: repeat
         loss, grad = l1_loss_and_grad(img, gt)
         torch.cuda.synchronize()
-        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-9
+        assert abs(float(loss) - float(ref.detach())) <= 1e-6 * abs(float(ref.detach())) + 1e-9
         assert torch.equal(grad, ref_in.grad)
     # into caller-owned buffers
     lo, go = torch.zeros((), device=gpu_device), torch.zeros_like(img)
