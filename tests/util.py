@@ -83,10 +83,13 @@ def explain_pixel(o, x: int, y: int):
     """Why may the pixel (x, y) legitimately differ between two fp32 implementations of the reference's blend loop
     (forward.cu:330-361)?  Walks the pixel's 16x16-tile list in the ORACLE and returns the smallest normalised margin by
     which any of the three discrete tests was decided:
-        power > 0            margin |power| / 1e-5                               (absolute: power is O(1))
-        alpha < 1/255        margin |alpha - 1/255| / (1/255) / 2e-5
+        power > 0            margin |power| / (1e-5 + 4e-7 m)
+        alpha < 1/255        margin |alpha - 1/255| / (1/255) / (2e-5 + 4e-7 m)
         T (1 - alpha) < 1e-4 margin |T (1 - alpha) - 1e-4| / 1e-4 / (2e-5 + 2.4e-7 n)
-    (n = entries blended so far: T is a product of n factors, and the two implementations associate it differently).
+    (m = |a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy|, the magnitude of the terms `power` is the sum of: an elongated splat far
+    from its centre cancels terms of size 50 to a power of -5, and an absolute error of m ulps in the power is a relative
+    error of m ulps in alpha; n = entries blended so far: T is a product of n factors, and the two implementations
+    associate it differently).
     A value <= 1 means some splat sits on a threshold within rounding: the pixel is a threshold flip."""
     i = o._inputs
     W = i["W"]
@@ -103,14 +106,15 @@ def explain_pixel(o, x: int, y: int):
     dy = (xy[:, 1] - f32(y)).astype(f32)
     power = (f32(-0.5) * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy).astype(f32)
     alpha = np.minimum(f32(0.99), co[:, 3] * np.exp(np.minimum(power, f32(0)))).astype(f32)
-    best = float(np.min(np.abs(power.astype(np.float64)) / 1e-5))
+    mag = (0.5 * (np.abs(co[:, 0]) * dx * dx + np.abs(co[:, 2]) * dy * dy) + np.abs(co[:, 1] * dx * dy)).astype(np.float64)
+    best = float(np.min(np.abs(power.astype(np.float64)) / (1e-5 + 4e-7 * mag)))
     T = 1.0
     n = 0
     for k in range(ids.size):
         if power[k] > 0:
             continue
         a = float(alpha[k])
-        best = min(best, abs(a - 1.0 / 255.0) * 255.0 / 2e-5)
+        best = min(best, abs(a - 1.0 / 255.0) * 255.0 / (2e-5 + 4e-7 * float(mag[k])))
         if a < 1.0 / 255.0:
             continue
         tt = T * (1.0 - a)

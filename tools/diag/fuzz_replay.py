@@ -1,0 +1,38 @@
+"""GPU box: replay iteration K of `tools/fuzz_parity.py N SEED [big]` and look at its forward outliers.
+    python tools/diag/fuzz_replay.py K SEED [big]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from fateavatar_amd import scenes  # noqa: E402
+from tests import util  # noqa: E402
+
+K, seed, big = int(sys.argv[1]), int(sys.argv[2]), len(sys.argv) > 3
+rng = np.random.default_rng(seed)
+for it in range(K + 1):
+    P = int(rng.integers(1, 60000 if big else 6000))
+    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
+    deg = int(rng.integers(0, 4))
+    slo = float(10 ** rng.uniform(-3.5, -1.5)); shi = slo * float(rng.uniform(1, 20))
+    olo = float(rng.uniform(0.001, 0.5)); ohi = float(rng.uniform(olo, 1.0))
+    spread = float(rng.uniform(0.05, 1.5))
+    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
+              opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
+              bg=tuple(rng.uniform(0, 1, 3)))
+    if it < K:
+        rng.uniform(-1, 1, (3, H, W))   # (the dL/dpixel draw of fuzz_parity.py)
+print(P, H, W, kw)
+s = scenes.random_scene(P, H, W, **kw)
+o = util.oracle_forward(s)
+h = util.HipFrame(s, torch.device("cuda:0"))
+col, fT = h.color.cpu().numpy(), h.final_T.cpu().numpy()
+n_out, unexpl = util.unexplained_outliers(o, col, fT)
+print("instances", h.counts.num_instances, "max list", h.counts.max_tile_list, "outliers", n_out, "unexplained", unexpl[:8])
+bad = (np.abs(col - o.color) > 1e-5 + 1e-4 * np.abs(o.color)).any(0) | (np.abs(fT - o.final_T) > 1e-5 + 1e-4 * np.abs(o.final_T))
+nc = h.n_contrib.cpu().numpy()
+for y, x in list(zip(*np.nonzero(bad)))[:12]:
+    print(f"px ({x},{y}): margin {util.explain_pixel(o, x, y):.3f}  colour hip {col[:, y, x]} oracle {o.color[:, y, x]}  "
+          f"T hip {fT[y, x]:.6e} oracle {o.final_T[y, x]:.6e}  n_contrib hip {nc[y, x]} oracle {o.n_contrib[y, x]}")
