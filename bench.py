@@ -103,68 +103,102 @@ def cpu_baseline(scene, budget_s: float = 20.0):
 
 
 # ---------------------------------------------------------------- engines: what a "frame" is
+class _View:
+    """One view of the step: its camera, its replica of the Gaussians (parameters and gradient buffer), its upstream
+    gradient, and — views are IN FLIGHT TOGETHER — its own stream, fr_handle slot and captured graph."""
+
+    def __init__(self, eng, k, scene):
+        from fateavatar_amd.model import FlatGaussians, TorchCamera
+        self.k, self.scene = k, scene
+        self.pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree,
+                                eng.dev, fused_activations=eng.args.fused_activations)
+        self.cam = TorchCamera(scene.camera, eng.dev)
+        self.bg = torch.from_numpy(scene.bg).to(eng.dev)
+        H = W = eng.args.res
+        # upstream gradient of the image: d(L1-mean against a fixed random target)/d(pixel) has magnitude 1/(3HW) and
+        # a random sign (SURVEY.md §8d config 2); it is fixed, so the step is exactly render + backward
+        g = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + eng.rank * 64 + k)) < 0.5).float() * 2 - 1)
+        self.dL_dpix = (g / (3 * H * W)).to(eng.dev)
+        self.stream = torch.cuda.Stream(device=eng.dev)
+        self.done = torch.cuda.Event()
+        self.graph = None
+
+
 class HipEngine:
-    """The product path: FlatGaussians + render() + autograd backward on one MI355X, replayed as a HIP graph."""
+    """The product path: FlatGaussians + render() + autograd backward on one MI355X, each view replayed as a HIP graph.
+    `--in-flight K`: K views of the step run concurrently (a stream, an fr_handle and a graph each).  One frame's
+    kernels are latency-bound at this size — 1.5 waves per SIMD in the per-Gaussian kernels, 4 workgroups in the totals
+    kernel — and leave most of the chip idle; the reference's step loops over its batch of views one after the other
+    (model/fateavatar.py:251-276), here the views of the batch overlap."""
 
     def __init__(self, args, rank, world, local):
         from fateavatar_amd import rasterizer, scenes
-        from fateavatar_amd.model import FlatGaussians, TorchCamera
         from fateavatar_amd.render import render
-        self.rasterizer, self.local, self.args = rasterizer, local, args
+        self.rasterizer, self.local, self.args, self.rank = rasterizer, local, args, rank
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
-        # replicated Gaussians (same seed on every rank), one view per rank
-        self.scene = scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0, view=rank, n_views=max(world, 1),
-                                       scale=args.scale, opacity=args.opacity)
-        s = self.scene
-        self.pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, s.sh_degree, self.dev,
-                                fused_activations=args.fused_activations)
-        self.cam = TorchCamera(s.camera, self.dev)
-        self.bg = torch.from_numpy(s.bg).to(self.dev)
-        H = W = args.res
-        # upstream gradient of the image: d(L1-mean against a fixed random target)/d(pixel) has magnitude 1/(3HW) and
-        # a random sign (SURVEY.md §8d config 2); it is fixed, so the step is exactly render + backward
-        g = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + rank)) < 0.5).float() * 2 - 1)
-        self.dL_dpix = (g / (3 * H * W)).to(self.dev)
+        K = self.K = max(1, args.in_flight)
+        # replicated Gaussians (same seed everywhere), view index (rank * K + k) of world * K views around the head
+        self.views = [_View(self, k, scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0,
+                                                       view=rank * K + k, n_views=max(world * K, 1), scale=args.scale,
+                                                       opacity=args.opacity)) for k in range(K)]
+        self.scene = self.views[0].scene
         self._render = render
         self.graph = None
+        self.grads_read = None   # event: the exchange has read the gradient buffers of the previous step
+        self.exchanging = world > 1   # the views' completion events are only needed by the gradient exchange
 
-    def frame(self):
-        self.pc.begin_step()                       # grads set to None: backward assigns (zero_grad(set_to_none=True))
-        out = self._render(self.cam, self.pc, self.bg)             # activations + HIP rasterizer forward
-        torch.autograd.backward(out["render"], grad_tensors=self.dL_dpix)  # HIP rasterizer backward (+ activations)
+    def frame(self, v=None):
+        v = v or self.views[0]
+        v.pc.begin_step()                          # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        out = self._render(v.cam, v.pc, v.bg)                      # activations + HIP rasterizer forward
+        torch.autograd.backward(out["render"], grad_tensors=v.dL_dpix)  # HIP rasterizer backward (+ activations)
 
     def prepare(self):
-        """Eager warm-up (sizes the binning capacity, fills the allocator pools), then capture ONE frame."""
-        for _ in range(max(3, self.args.warmup // 2)):
-            self.frame()
-        torch.cuda.synchronize()
-        if self.args.graph:
-            # the per-frame work is launch-bound on the host (~40 small launches): capture one frame and replay it; the
-            # rasterizer runs in no-wait mode inside the capture (no host synchronisation at all); overflow of the
-            # binning capacity is checked after the timed region
-            with self.rasterizer.no_wait():
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        self.frame()
-                torch.cuda.current_stream().wait_stream(side)
+        """Per view: eager warm-up (sizes the binning capacity, fills the allocator pools), then capture ONE frame."""
+        for v in self.views:
+            with self.rasterizer.handle_slot(v.k):
+                for _ in range(max(3, self.args.warmup // 2)):
+                    self.frame(v)
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self.frame()
-            torch.cuda.synchronize()
+                if self.args.graph:
+                    # the per-frame work is launch-bound on the host (~40 small launches): capture one frame and replay
+                    # it; the rasterizer runs in no-wait mode inside the capture (no host synchronisation at all);
+                    # overflow of the binning capacity is checked after the timed region
+                    with self.rasterizer.no_wait():
+                        with torch.cuda.stream(v.stream):
+                            for _ in range(3):
+                                self.frame(v)
+                        torch.cuda.synchronize()
+                        v.graph = torch.cuda.CUDAGraph()
+                        # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
+                        with torch.cuda.graph(v.graph, stream=v.stream, capture_error_mode="thread_local"):
+                            self.frame(v)
+                    torch.cuda.synchronize()
+        self.graph = self.views[0].graph
 
-    def enqueue_frame(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self.frame()
+    def enqueue_frame(self, views=None):
+        """One step: every view's render + backward, each on its own stream."""
+        for v in (views or self.views):
+            with torch.cuda.stream(v.stream):
+                if self.grads_read is not None:
+                    v.stream.wait_event(self.grads_read)     # (N > 1) the exchange still reads this buffer
+                if v.graph is not None:
+                    v.graph.replay()
+                else:
+                    with self.rasterizer.handle_slot(v.k):
+                        self.frame(v)
+                if self.exchanging:
+                    v.done.record(v.stream)
 
-    def flat_grad(self):
-        return self.pc.collect_grads()
+    def flat_grads(self):
+        return [v.pc.collect_grads() for v in self.views]
+
+    def join(self):
+        """Make the current stream wait for the step's views (the exchange reads their gradients)."""
+        cur = torch.cuda.current_stream(self.dev)
+        for v in self.views:
+            cur.wait_event(v.done)
 
     def sync(self):
         torch.cuda.synchronize()
@@ -172,12 +206,14 @@ class HipEngine:
     def finish(self):
         """After the timed region: overflow check of the captured frames, per-kernel durations, counts."""
         from fateavatar_amd import _lib
-        if self.graph is not None and self.rasterizer.check_async_overflow(self.local):
-            c = self.rasterizer.last_counts[self.local]
-            raise SystemExit(f"binning capacity overflowed inside the captured graph (instances {c.num_instances}, "
-                             f"num_rendered {c.num_rendered}, max list {c.max_tile_list}); rerun (capacity hint was raised)")
-        # HIP events around every stage launch, on the launch stream, over eager frames (event records inside a
-        # replayed graph cannot be read back)
+        for v in self.views:
+            with self.rasterizer.handle_slot(v.k):
+                if v.graph is not None and self.rasterizer.check_async_overflow(self.local):
+                    c = self.rasterizer.last_counts[self.local]
+                    raise SystemExit(f"binning capacity overflowed inside the captured graph (instances {c.num_instances}, "
+                                     f"num_rendered {c.num_rendered}, max list {c.max_tile_list}); rerun (capacity hint was raised)")
+        # HIP events around every stage launch, on the launch stream, over eager frames of ONE view (event records inside
+        # a replayed graph cannot be read back)
         _lib.profile_enable(self.local, True)
         for _ in range(min(self.args.steps, 50)):
             self.frame()
@@ -195,18 +231,24 @@ class StubEngine:
     def __init__(self, args, rank, world, local):
         self.dev = torch.device("cpu")
         self.rank, self.k = rank, 0
-        self.grad = torch.zeros(1 << 12)
+        self.K = max(1, args.in_flight)
+        self.grads = [torch.zeros(1 << 12) for _ in range(self.K)]
         self.scene = None
+        self.grads_read = None
 
     def prepare(self):
         pass
 
-    def enqueue_frame(self):
-        self.grad.copy_(torch.arange(self.grad.numel(), dtype=torch.float32) * 1e-3 + (self.rank + 1) * (self.k + 1))
+    def enqueue_frame(self, views=None):
+        for j, g in enumerate(self.grads):
+            g.copy_(torch.arange(g.numel(), dtype=torch.float32) * 1e-3 + (self.rank * self.K + j + 1) * (self.k + 1))
         self.k += 1
 
-    def flat_grad(self):
-        return self.grad
+    def flat_grads(self):
+        return self.grads
+
+    def join(self):
+        pass
 
     def sync(self):
         pass
@@ -216,21 +258,32 @@ class StubEngine:
 
 
 class GradExchange:
-    """All-reduce(AVG) of the flat gradient of every step, overlapped with the following frame: the gradient is copied
-    (on the compute stream, behind the backward) into one of two exchange buffers and reduced there asynchronously;
-    a buffer is reused two steps later, after waiting for its collective."""
+    """All-reduce(AVG) of the flat gradient of every step, overlapped with the following frames: the gradients of the
+    step's views are summed (behind their backward passes) into one of two exchange buffers and reduced there
+    asynchronously; a buffer is reused two steps later, after waiting for its collective."""
 
     def __init__(self, like: torch.Tensor):
         self.bufs = [torch.empty_like(like), torch.empty_like(like)]
         self.works = [None, None]
         self.k = 0
 
-    def submit(self, flat_grad: torch.Tensor):
+    def submit(self, eng):
         from fateavatar_amd import dp
         i = self.k & 1
         if self.works[i] is not None:
             self.works[i].wait()
-        self.bufs[i].copy_(flat_grad, non_blocking=True)
+        eng.join()                                   # the step's views have written their gradients
+        grads = eng.flat_grads()
+        if len(grads) == 1:
+            self.bufs[i].copy_(grads[0], non_blocking=True)
+        else:                                        # mean over the local views; the collective averages over the ranks
+            torch.add(grads[0], grads[1], out=self.bufs[i])
+            for g in grads[2:]:
+                self.bufs[i].add_(g)
+            self.bufs[i].mul_(1.0 / len(grads))
+        if self.bufs[i].is_cuda:                     # the next step's views may overwrite their gradients after this point
+            eng.grads_read = torch.cuda.Event()
+            eng.grads_read.record()
         self.works[i] = dp.allreduce_mean_async(self.bufs[i])
         self.k += 1
 
@@ -260,6 +313,8 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--scale", type=float, default=None, help="splat scale (default: the template's NN spacing at P)")
     ap.add_argument("--opacity", type=float, default=0.1, help="splat opacity (the metric's scene: 0.1)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="views of a step that run concurrently on one GPU (1 = one frame at a time, as in round 1)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
@@ -288,12 +343,12 @@ def main():
 
     eng = (StubEngine if STUB else HipEngine)(args, rank, world, local)
     eng.prepare()
-    xchg = GradExchange(eng.flat_grad()) if world > 1 else None
+    xchg = GradExchange(eng.flat_grads()[0]) if world > 1 else None
 
     def step():
         eng.enqueue_frame()
         if xchg is not None:
-            xchg.submit(eng.flat_grad())
+            xchg.submit(eng)
             if not args.overlap:
                 xchg.drain()
 
@@ -312,6 +367,16 @@ def main():
     eng.sync()
     dp.barrier()
     elapsed = time.perf_counter() - t0
+
+    # the same engine with ONE view in flight (what `value` measured until views overlapped): a reference point
+    single = None
+    if not STUB and eng.K > 1 and world == 1:
+        eng.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.enqueue_frame(eng.views[:1])
+        eng.sync()
+        single = {"value": round(args.steps / (time.perf_counter() - t1), 2), "unit": "frames/s", "frames_in_flight": 1}
 
     prof, counts = eng.finish()
 
@@ -354,7 +419,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        fps = world * args.steps / elapsed
+        fps = world * eng.K * args.steps / elapsed
         H = W = args.res
         M = (args.sh_degree + 1) ** 2
         R = counts["num_rendered"]
@@ -384,7 +449,9 @@ def main():
                 roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd_sparse", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
                         "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
-                        "avg_launch_us": round(avg_s * 1e6, 2), "launches": n}
+                        "avg_launch_us": round(avg_s * 1e6, 2), "launches": n,
+                        "measured": "dispatch-tied HIP events around ISOLATED launches (eager frames of one view, nothing else "
+                                    "on the GPU); rocprofv3 of `bench.py --in-flight 1` agrees (profiles/)"}
         cpu = None
         if args.cpu_seconds > 0 and world == 1 and eng.scene is not None:
             cpu = cpu_baseline(eng.scene, args.cpu_seconds)
@@ -400,14 +467,16 @@ def main():
             "config": {"workload": f"{cfg_name}: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={M}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
-                       "frames_per_step_per_gpu": 1,
+                       "frames_per_step_per_gpu": eng.K,
+                       "frames_in_flight_per_gpu": eng.K,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
-                       "parallelism": f"dp{world} (one view per GPU, flat-grad all-reduce"
+                       "parallelism": f"dp{world} ({eng.K} view(s) per GPU and step, each on its own stream; flat-grad all-reduce"
                                       + (", overlapped with the next frame)" if world > 1 and args.overlap else ")"),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
+            "one_frame_at_a_time": single,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():

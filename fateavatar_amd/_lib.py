@@ -184,9 +184,12 @@ def last_error() -> str:
 _handles: dict = {}
 
 
-def handle(device_index: int):
-    """One fr_handle per device (created with that device current)."""
-    h = _handles.get(device_index)
+def handle(device_index: int, slot: int = 0):
+    """One fr_handle per (device, slot), created with that device current.  Frames of ONE handle are ordered (the handle
+    owns per-frame state); frames that are to overlap on the device — several views in flight on several streams — use
+    different slots (rasterizer.handle_slot)."""
+    key = device_index if slot == 0 else (device_index, slot)
+    h = _handles.get(key)
     if h is None:
         import torch
 
@@ -196,5 +199,5 @@ def handle(device_index: int):
             if rc != FR_OK:
                 raise RuntimeError(f"fr_create failed: {last_error()}")
         h = out
-        _handles[device_index] = h
+        _handles[key] = h
     return h

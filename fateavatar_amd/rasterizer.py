@@ -77,10 +77,31 @@ class no_wait:
         return False
 
 
-def read_counts(device_index: int = 0):
+_slot = 0   # which fr_handle of the device the calls of this thread of control use (see handle_slot)
+
+
+class handle_slot:
+    """`with rasterizer.handle_slot(k):` — render through the k-th handle of the device.  Frames of one handle are
+    ordered; views that should be IN FLIGHT TOGETHER (one stream and one captured graph each) take one slot each."""
+
+    def __init__(self, slot: int):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        global _slot
+        self._prev, _slot = _slot, self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global _slot
+        _slot = self._prev
+        return False
+
+
+def read_counts(device_index: int = 0, slot: int | None = None):
     """fr_counts of the most recent frame on this device (synchronise first)."""
     c = _lib.fr_counts()
-    _check(_lib.lib().fr_read_counts(_lib.handle(device_index), C.byref(c)), "fr_read_counts")
+    _check(_lib.lib().fr_read_counts(_lib.handle(device_index, _slot if slot is None else slot), C.byref(c)), "fr_read_counts")
     return c
 
 
@@ -145,7 +166,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     M = sh.size(1) if sh.numel() != 0 else 0
 
     L = _lib.lib()
-    h = _lib.handle(dev)
+    h = _lib.handle(dev, _slot)
     prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, _raw,
                   _aux(visible=_visible))
     inp = _inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
@@ -207,7 +228,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     radii = radii.contiguous()
 
     L = _lib.lib()
-    h = _lib.handle(dev)
+    h = _lib.handle(dev, _slot)
     aux = _aux(grad_accum=_stats[0], denom=_stats[1]) if _stats is not None else None
     prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw, aux)
     inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
@@ -289,6 +310,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings, raw_activations=False):
         rs = raster_settings
         ctx.raw = bool(raw_activations)
+        ctx.fr_slot = _slot   # the backward goes through the handle the forward used
         # the gradient slot of the int32 `radii` output would otherwise be materialised as a zero tensor per backward
         ctx.set_materialize_grads(False)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -350,7 +372,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads = rasterize_gaussians_backward(*args, _raw=ctx.raw, _stats=ctx.stats, _want=want)
+                with handle_slot(ctx.fr_slot):
+                    grads = rasterize_gaussians_backward(*args, _raw=ctx.raw, _stats=ctx.stats, _want=want)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
@@ -360,7 +383,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             # of the same step (several frames rendered from the same parameters) gets a fresh tensor, which autograd
             # then adds to the first
             out = {k: slot.claim() for k, slot in ctx.grad_slots.items() if slot is not None}
-            grads = rasterize_gaussians_backward(*args, _out=out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
+            with handle_slot(ctx.fr_slot):
+                grads = rasterize_gaussians_backward(*args, _out=out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

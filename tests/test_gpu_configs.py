@@ -238,12 +238,19 @@ def test_rccl_exchange_path_runs_on_this_gpu(gpu_device):
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "g = torch.arange(1 << 20, dtype=torch.float32, device='cuda')\n"
+        "g2 = g * 3\n"
+        "class Eng:\n"
+        "    grads_read = None\n"
+        "    def join(self): pass\n"
+        "    def flat_grads(self): return [g, g2]\n"
+        "e = Eng()\n"
         "x = bench.GradExchange(g)\n"
         "for k in range(5):\n"
-        "    g.add_(1.0)\n"
-        "    x.submit(g)\n"
+        "    if e.grads_read is not None: torch.cuda.current_stream().wait_event(e.grads_read)\n"
+        "    g.add_(1.0); g2.add_(3.0)\n"
+        "    x.submit(e)\n"
         "x.drain(); torch.cuda.synchronize()\n"
-        "assert torch.equal(x.latest(), g), 'exchange buffer does not hold the last gradient'\n"
+        "assert torch.equal(x.latest(), (g + g2) * 0.5), 'exchange buffer does not hold the mean of the last gradients'\n"
         "assert dp._collective_avg_ok(g) in (True, False)\n"
         "s = dp.allreduce_sum_(g.clone()); assert torch.equal(s, g)\n"
         "print('rccl-ok', dist.get_backend(), '.'.join(map(str, torch.cuda.nccl.version())), dp._avg_supported)\n"

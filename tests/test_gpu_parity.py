@@ -795,6 +795,65 @@ def test_forward_chain_makes_progress_while_other_work_holds_the_cus(gpu_device)
     assert torch.isfinite(a).all()
 
 
+def test_views_in_flight_together_match_views_rendered_alone(gpu_device):
+    """Three views of one model rendered and back-propagated CONCURRENTLY — a stream, an fr_handle slot and a captured
+    graph each (bench.py --in-flight) — give the images and gradients the same views give one after the other."""
+    import torch
+    from fateavatar_amd import rasterizer
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    K, res = 3, 192
+    bg = torch.ones(3, device=gpu_device)
+    views = []
+    for k in range(K):
+        s = scenes.head_scene(P=30000, res=res, sh_degree=2, seed=0, view=k, n_views=K, opacity=0.4)
+        g = torch.Generator().manual_seed(k)
+        views.append(dict(k=k, s=s, cam=TorchCamera(s.camera, gpu_device),
+                          pc=FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, s.sh_degree, gpu_device,
+                                           fused_activations=True),
+                          dL=((torch.rand((3, res, res), generator=g) - 0.5) / (res * res)).to(gpu_device),
+                          stream=torch.cuda.Stream(device=gpu_device)))
+
+    def frame(v):
+        v["pc"].begin_step()
+        out = render(v["cam"], v["pc"], bg)
+        torch.autograd.backward(out["render"], grad_tensors=v["dL"])
+        return out["render"]
+
+    alone = []
+    for v in views:                                   # one after the other, default handle
+        img = frame(v).detach().clone()
+        torch.cuda.synchronize()
+        alone.append((img, v["pc"].collect_grads().clone()))
+    outs = {}
+    for v in views:                                   # capture one graph per view on its own handle and stream
+        with rasterizer.handle_slot(v["k"] + 1):
+            for _ in range(2):
+                frame(v)
+            torch.cuda.synchronize()
+            with rasterizer.no_wait():
+                with torch.cuda.stream(v["stream"]):
+                    frame(v)
+                torch.cuda.synchronize()
+                v["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(v["graph"], stream=v["stream"]):
+                    outs[v["k"]] = frame(v)
+        torch.cuda.synchronize()
+    for _ in range(25):                               # in flight together
+        for v in views:
+            with torch.cuda.stream(v["stream"]):
+                v["graph"].replay()
+    torch.cuda.synchronize()
+    for v, (img, grad) in zip(views, alone):
+        with rasterizer.handle_slot(v["k"] + 1):
+            assert not rasterizer.check_async_overflow(gpu_device.index or 0)
+        assert torch.allclose(outs[v["k"]], img, rtol=1e-5, atol=1e-6), v["k"]
+        got = v["pc"].collect_grads()
+        assert float(grad.abs().max()) > 0
+        # (float atomics in the blend backward: two runs agree to rounding, not bit for bit)
+        assert util.rel_l2(got.cpu().numpy(), grad.cpu().numpy()) < 1e-5, v["k"]
+
+
 def test_long_lists_without_the_big_sorter_launch(gpu_device):
     """The big-list sorter is only launched when the previous frame had a list longer than 1024; a frame whose long
     lists come as a surprise is sorted by the slow path inside k_tile_sort and must be just as correct.  Frame order:
