@@ -110,8 +110,12 @@ class _View:
     def __init__(self, eng, k, scene):
         from fateavatar_amd.model import FlatGaussians, TorchCamera
         self.k, self.scene = k, scene
-        self.pc = FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree,
-                                eng.dev, fused_activations=eng.args.fused_activations)
+        # N > 1: two replicas (and two captured graphs), used by alternate steps, so that the gradient exchange of step i
+        # reads one set of gradient buffers while the frames of step i + 1 already write the other
+        self.pcs = [FlatGaussians(scene.means3D, scene.shs, scene.opacities, scene.scales, scene.rotations, scene.sh_degree,
+                                  eng.dev, fused_activations=eng.args.fused_activations)
+                    for _ in range(2 if eng.exchanging else 1)]
+        self.pc = self.pcs[0]
         self.cam = TorchCamera(scene.camera, eng.dev)
         self.bg = torch.from_numpy(scene.bg).to(eng.dev)
         H = W = eng.args.res
@@ -121,6 +125,7 @@ class _View:
         self.dL_dpix = (g / (3 * H * W)).to(eng.dev)
         self.stream = torch.cuda.Stream(device=eng.dev)
         self.done = torch.cuda.Event()
+        self.graphs = [None] * len(self.pcs)
         self.graph = None
 
 
@@ -137,6 +142,8 @@ class HipEngine:
         self.rasterizer, self.local, self.args, self.rank = rasterizer, local, args, rank
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
+        self.exchanging = world > 1   # the views' completion events and second buffer sets are only needed by the exchange
+        self.step_no = 0
         K = self.K = max(1, args.in_flight)
         # replicated Gaussians (same seed everywhere), view index (rank * K + k) of world * K views around the head
         self.views = [_View(self, k, scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0,
@@ -145,13 +152,13 @@ class HipEngine:
         self.scene = self.views[0].scene
         self._render = render
         self.graph = None
-        self.grads_read = None   # event: the exchange has read the gradient buffers of the previous step
-        self.exchanging = world > 1   # the views' completion events are only needed by the gradient exchange
+        self.grads_read = [None, None]   # events: the exchange has read the gradient buffers of set 0 / 1
 
-    def frame(self, v=None):
+    def frame(self, v=None, which=0):
         v = v or self.views[0]
-        v.pc.begin_step()                          # grads set to None: backward assigns (zero_grad(set_to_none=True))
-        out = self._render(v.cam, v.pc, v.bg)                      # activations + HIP rasterizer forward
+        pc = v.pcs[which]
+        pc.begin_step()                            # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        out = self._render(v.cam, pc, v.bg)                        # activations + HIP rasterizer forward
         torch.autograd.backward(out["render"], grad_tensors=v.dL_dpix)  # HIP rasterizer backward (+ activations)
 
     def prepare(self):
@@ -166,33 +173,45 @@ class HipEngine:
                     # it; the rasterizer runs in no-wait mode inside the capture (no host synchronisation at all);
                     # overflow of the binning capacity is checked after the timed region
                     with self.rasterizer.no_wait():
-                        with torch.cuda.stream(v.stream):
-                            for _ in range(3):
-                                self.frame(v)
-                        torch.cuda.synchronize()
-                        v.graph = torch.cuda.CUDAGraph()
-                        # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
-                        with torch.cuda.graph(v.graph, stream=v.stream, capture_error_mode="thread_local"):
-                            self.frame(v)
+                        for which in range(len(v.pcs)):
+                            with torch.cuda.stream(v.stream):
+                                for _ in range(3):
+                                    self.frame(v, which)
+                            torch.cuda.synchronize()
+                            v.graphs[which] = torch.cuda.CUDAGraph()
+                            # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
+                            with torch.cuda.graph(v.graphs[which], stream=v.stream, capture_error_mode="thread_local"):
+                                self.frame(v, which)
                     torch.cuda.synchronize()
+            v.graph = v.graphs[0]
         self.graph = self.views[0].graph
 
     def enqueue_frame(self, views=None):
         """One step: every view's render + backward, each on its own stream."""
+        which = self.step_no & 1 if self.exchanging else 0
+        self.which = which
         for v in (views or self.views):
             with torch.cuda.stream(v.stream):
-                if self.grads_read is not None:
-                    v.stream.wait_event(self.grads_read)     # (N > 1) the exchange still reads this buffer
-                if v.graph is not None:
-                    v.graph.replay()
+                if self.grads_read[which] is not None:
+                    v.stream.wait_event(self.grads_read[which])   # (N > 1) the exchange of two steps ago read this set
+                if v.graphs[which] is not None:
+                    v.graphs[which].replay()
                 else:
                     with self.rasterizer.handle_slot(v.k):
-                        self.frame(v)
+                        self.frame(v, which)
                 if self.exchanging:
                     v.done.record(v.stream)
+        self.step_no += 1
 
     def flat_grads(self):
-        return [v.pc.collect_grads() for v in self.views]
+        """Gradient buffers of the step enqueued last."""
+        return [v.pcs[getattr(self, "which", 0)].collect_grads() for v in self.views]
+
+    def mark_grads_read(self):
+        """(current stream) everything enqueued so far has read the gradient buffers of the step enqueued last."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.grads_read[getattr(self, "which", 0)] = ev
 
     def join(self):
         """Make the current stream wait for the step's views (the exchange reads their gradients)."""
@@ -250,6 +269,9 @@ class StubEngine:
     def join(self):
         pass
 
+    def mark_grads_read(self):
+        pass
+
     def sync(self):
         pass
 
@@ -277,13 +299,11 @@ class GradExchange:
         if len(grads) == 1:
             self.bufs[i].copy_(grads[0], non_blocking=True)
         else:                                        # mean over the local views; the collective averages over the ranks
-            torch.add(grads[0], grads[1], out=self.bufs[i])
-            for g in grads[2:]:
-                self.bufs[i].add_(g)
-            self.bufs[i].mul_(1.0 / len(grads))
-        if self.bufs[i].is_cuda:                     # the next step's views may overwrite their gradients after this point
-            eng.grads_read = torch.cuda.Event()
-            eng.grads_read.record()
+            w = 1.0 / len(grads)
+            torch.mul(grads[0], w, out=self.bufs[i])
+            for g in grads[1:]:
+                self.bufs[i].add_(g, alpha=w)
+        eng.mark_grads_read()                        # the step after next may overwrite these gradient buffers
         self.works[i] = dp.allreduce_mean_async(self.bufs[i])
         self.k += 1
 

@@ -240,13 +240,12 @@ def test_rccl_exchange_path_runs_on_this_gpu(gpu_device):
         "g = torch.arange(1 << 20, dtype=torch.float32, device='cuda')\n"
         "g2 = g * 3\n"
         "class Eng:\n"
-        "    grads_read = None\n"
         "    def join(self): pass\n"
         "    def flat_grads(self): return [g, g2]\n"
+        "    def mark_grads_read(self): pass\n"
         "e = Eng()\n"
         "x = bench.GradExchange(g)\n"
         "for k in range(5):\n"
-        "    if e.grads_read is not None: torch.cuda.current_stream().wait_event(e.grads_read)\n"
         "    g.add_(1.0); g2.add_(3.0)\n"
         "    x.submit(e)\n"
         "x.drain(); torch.cuda.synchronize()\n"
