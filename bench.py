@@ -497,6 +497,10 @@ def main():
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            # every stage's algorithmic bytes over the measured frame rate: the whole path against HBM
+            "frame_roofline": (None if not prof else {
+                "algorithmic_bytes_per_frame": int(sum(sb.values())), "achieved": round(sum(sb.values()) * fps / world / 1e9, 1),
+                "unit": "GB/s per GPU", "frac": round(sum(sb.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 4)}),
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
