@@ -36,6 +36,7 @@ class fr_params(C.Structure):
 
 FR_ADAM_MAX_SEGMENTS = 16
 FR_ADAM_STATE_FLOATS = 576
+FR_ADAM_MAX_GRADS = 4
 
 
 class fr_adam_config(C.Structure):
@@ -69,7 +70,7 @@ class fr_counts(C.Structure):
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_read_counts", "fr_backward", "fr_mark_visible", "fr_image_final_T",
-           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_l1_workspace_bytes", "fr_l1_loss_grad", "fr_multi_copy", "fr_face_scale",
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_adam_step_multi", "fr_l1_workspace_bytes", "fr_l1_loss_grad", "fr_multi_copy", "fr_face_scale",
            "fr_bind_forward", "fr_bind_backward"]
 
 
@@ -146,6 +147,9 @@ def lib():
     L.fr_bind_backward.restype = C.c_int
     L.fr_adam_step.argtypes = [C.POINTER(fr_adam_config), _fp, _fp, _fp, _fp, C.c_uint64, _fp, C.c_void_p]
     L.fr_adam_step.restype = C.c_int
+    L.fr_adam_step_multi.argtypes = [C.POINTER(fr_adam_config), _fp, C.POINTER(C.c_void_p), C.c_int32, _fp, _fp, C.c_uint64, _fp,
+                                     C.c_void_p]
+    L.fr_adam_step_multi.restype = C.c_int
     L.fr_l1_workspace_bytes.argtypes = []
     L.fr_l1_workspace_bytes.restype = C.c_size_t
     L.fr_l1_loss_grad.argtypes = [C.c_uint64, _fp, _fp, _fp, _fp, C.c_void_p, C.c_void_p]

@@ -84,6 +84,23 @@ class AvatarGaussians(torch.nn.Module):
             setattr(self, name, p)
             off += n
 
+    def lane(self) -> "AvatarGaussians":
+        """A second set of leaves over the SAME parameter storage with a gradient buffer of its own: what another view of
+        the batch, rendered in flight together with this one, back-propagates into (AvatarBatchStep)."""
+        o = AvatarGaussians.__new__(AvatarGaussians)
+        torch.nn.Module.__init__(o)
+        o.face_index, o.bary_coords, o.flat = self.face_index, self.bary_coords, self.flat
+        o.flat_grad = torch.zeros_like(self.flat)
+        off = 0
+        for name, w in self.FIELDS:
+            n = self.P * w
+            shp = (self.P,) + self.SHAPES[name]
+            p = torch.nn.Parameter(self.flat[off:off + n].view(shp))
+            p._fr_grad_out = GradOut(o.flat_grad[off:off + n].view(shp))
+            setattr(o, name, p)
+            off += n
+        return o
+
     def begin_step(self):
         for name, _ in self.FIELDS:
             getattr(self, name).grad = None
@@ -157,22 +174,30 @@ class AvatarStep(TrainStep):
         self.use_graph = bool(use_graph)
         self._graph, self._eager_steps, self.overflows = None, 0, 0
 
+    def adam_segments(self):
+        """The optimizer groups (train/optim.py:15-21 with config/fateavatar.yaml:34-39) as runs of the flat buffer."""
+        lr, P = self.lr, self.pc.P
+        return [(P * 1, lr["opacity"]), (P * 1, lr["offset"]), (P * 3, lr["color"]), (P * 4, lr["rotation"]), (P * 3, lr["scaling"])]
+
     def _make_adam(self):
-        pc, lr, P = self.pc, self.lr, self.pc.P
-        self.adam = FusedAdam(pc.flat, pc.flat_grad, [(P * 1, lr["opacity"]), (P * 1, lr["offset"]), (P * 3, lr["color"]),
-                                                      (P * 4, lr["rotation"]), (P * 3, lr["scaling"])],
-                              grad_scale=1.0 / self.world)
+        pc = self.pc
+        self.adam = FusedAdam(pc.flat, pc.flat_grad, self.adam_segments(), grad_scale=1.0 / self.world)
 
     def _forward_backward(self):
-        pc = self.pc
+        self._forward_backward_on(self)
+
+    def _forward_backward_on(self, L):
+        """Bind, render, L1, backward for one frame.  `L` holds what the frame reads and writes — pc, verts, cam, gt, loss,
+        _dimage, xyz_gradient_accum, denom, out: this object itself, or one lane of an AvatarBatchStep."""
+        pc = L.pc
         pc.begin_step()                                             # zero_grad(set_to_none=True), iteration.py:48-49
-        xyz, rot, scl = bind_gaussians(self.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
+        xyz, rot, scl = bind_gaussians(L.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
                                        pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
-        frame = _BoundFrame(xyz, pc, rot, scl, (self.xyz_gradient_accum, self.denom))
-        out = render(self.cam, frame, self.bg)
-        _, g = l1_loss_and_grad(out["render"], self.gt, loss_out=self.loss, grad_out=self._dimage)   # see TrainStep
+        frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom))
+        out = render(L.cam, frame, self.bg)
+        _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage)   # see TrainStep
         out["render"].backward(g)
-        self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
+        L.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
 
     def step(self, camera: TorchCamera, posed_verts: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
         self._extra_inputs = [(self.verts, posed_verts)]
@@ -299,3 +324,174 @@ class AvatarStep(TrainStep):
             self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])
             self.denom.copy_(dens["denom"])
         return sorted(model.keys())
+
+
+class _Lane:
+    """One view of a batch: everything its frame reads and writes next to the shared parameters."""
+
+
+class AvatarBatchStep(AvatarStep):
+    """K frames per optimisation step, IN FLIGHT TOGETHER: `step(cameras, posed_verts, gt_images)` with K of each.
+
+    reference: the model renders the frames of a batch one after the other with shared Gaussians
+    (`for bs_ in range(bs)`, model/fateavatar.py:251-276) and the loss is the mean over the batch (train/loss.py:92-105).
+    Here every frame of the batch is a LANE — its own leaves over the shared parameter storage with its own gradient
+    buffer (AvatarGaussians.lane), static inputs, densification statistics, stream, fr_handle slot and captured graph
+    (bind -> render -> L1 -> backward) — and the lanes run concurrently: one frame's kernels leave most of the chip idle
+    (DESIGN.md §4).  One fused Adam then steps on the SUM of the lanes' gradients (fr_adam_step_multi; grad_scale
+    = 1 / (K x ranks) makes it the batch mean)."""
+
+    def __init__(self, pc: AvatarGaussians, faces, canonical_verts, camera: TorchCamera, bg, views_per_step: int = 3, **kw):
+        from . import _lib
+        if not 1 <= int(views_per_step) <= _lib.FR_ADAM_MAX_GRADS:
+            raise ValueError(f"views_per_step must be 1..{_lib.FR_ADAM_MAX_GRADS}")
+        self.K = int(views_per_step)
+        super().__init__(pc, faces, canonical_verts, camera, bg, **kw)
+        self._build_lanes()
+
+    def _make_adam(self):
+        super()._make_adam()
+        self.adam.set_grad_scale(1.0 / (self.world * self.K))
+
+    def _build_lanes(self):
+        self.lanes = []
+        for k in range(self.K):
+            L = _Lane()
+            L.k = k
+            if k == 0:     # lane 0 IS this object's own frame state
+                L.pc, L.cam, L.verts, L.gt, L.loss, L._dimage = self.pc, self.cam, self.verts, self.gt, self.loss, self._dimage
+                L.xyz_gradient_accum, L.denom = self.xyz_gradient_accum, self.denom
+            else:
+                L.pc, L.cam, L.verts = self.pc.lane(), self.cam.clone(), self.verts.clone()
+                L.gt, L.loss, L._dimage = torch.zeros_like(self.gt), torch.zeros_like(self.loss), torch.zeros_like(self._dimage)
+                L.xyz_gradient_accum, L.denom = torch.zeros_like(self.xyz_gradient_accum), torch.zeros_like(self.denom)
+            L.out, L.graph = None, None
+            L.stream, L.done = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
+            self.lanes.append(L)
+        self._eager_steps = 0
+        self._ready = torch.cuda.Event()
+
+    # ---- the step
+    def _capture_lanes(self):
+        from . import rasterizer
+        for L in self.lanes:
+            with rasterizer.handle_slot(L.k), rasterizer.no_wait():
+                acc, den = L.xyz_gradient_accum.clone(), L.denom.clone()
+                L.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(L.stream):
+                    self._forward_backward_on(L)          # warms the allocator pools of the capture path: not a step
+                torch.cuda.synchronize()
+                L.xyz_gradient_accum.copy_(acc)
+                L.denom.copy_(den)
+                L.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(L.graph, stream=L.stream, capture_error_mode="thread_local"):
+                    self._forward_backward_on(L)
+                torch.cuda.synchronize()
+
+    def _drop_graphs(self):
+        for L in self.lanes:
+            L.graph = None
+        self._eager_steps = 0
+
+    def step(self, cameras, posed_verts, gt_images):
+        """One optimisation step on K frames.  Returns the K (device) loss scalars of the step."""
+        from . import rasterizer
+        from .loss import multi_copy
+        if not (len(cameras) == len(posed_verts) == len(gt_images) == self.K):
+            raise ValueError(f"AvatarBatchStep.step needs {self.K} cameras, vertex sets and images")
+        main = torch.cuda.current_stream(self.dev)
+        pairs = []
+        for L, cam, verts, gt in zip(self.lanes, cameras, posed_verts, gt_images):
+            pairs += [(L.verts, verts), (L.gt, gt)]
+            if cam is not L.cam:
+                L.cam.check_same_intrinsics(cam)
+                pairs.append((L.cam._packed, cam._packed))
+        try:
+            multi_copy(pairs)                      # the inputs of all K frames: one launch
+        except RuntimeError:                       # (host tensors, other dtypes, more than twelve pairs: plain copies)
+            for d, s in pairs:
+                d.copy_(s, non_blocking=True)
+        captured = self.lanes[0].graph is not None
+        if self.use_graph and not captured and self._eager_steps >= 2:
+            self._capture_lanes()
+            captured = True
+        self._steps_since_poll = getattr(self, "_steps_since_poll", 0) + 1
+        if captured and self._steps_since_poll >= 8:
+            # a replayed frame that overflowed its binning capacity (pinned counts, no synchronisation): back to eager
+            self._steps_since_poll = 0
+            for L in self.lanes:
+                with rasterizer.handle_slot(L.k):
+                    if rasterizer.check_async_overflow(self.dev.index or 0):
+                        self.overflows += 1
+                        self._drop_graphs()
+                        captured = False
+                        break
+        self._ready.record(main)                   # inputs loaded; the previous step's Adam has been enqueued before it
+        for L in self.lanes:
+            with torch.cuda.stream(L.stream):
+                L.stream.wait_event(self._ready)
+                if captured:
+                    L.graph.replay()
+                else:
+                    with rasterizer.handle_slot(L.k):
+                        self._forward_backward_on(L)
+                        L.pc.collect_grads()
+                L.done.record(L.stream)
+        if not captured:
+            self._eager_steps += 1
+        for L in self.lanes:
+            main.wait_event(L.done)
+        grads = [L.pc.flat_grad for L in self.lanes]
+        if self.world > 1:                         # sum of the local lanes, then the sum over the ranks; Adam scales
+            for g in grads[1:]:
+                grads[0].add_(g)
+            dp.allreduce_sum_(grads[0])
+            self.adam.step()
+        else:
+            self.adam.step(grads)
+        self.out = self.lanes[0].out
+        return tuple(L.loss for L in self.lanes)
+
+    def check(self) -> None:
+        from . import rasterizer
+        for L in self.lanes:
+            with rasterizer.handle_slot(L.k):
+                if L.graph is not None and rasterizer.check_async_overflow(self.dev.index or 0):
+                    raise RuntimeError("binning capacity overflowed inside a captured frame; re-create the step")
+
+    # ---- maintenance: the lanes' statistics are folded into this object's before anything reads them, and the lanes are
+    #      rebuilt whenever the point set (and with it every buffer) changes
+    @torch.no_grad()
+    def _fold_stats(self):
+        for L in self.lanes[1:]:
+            self.xyz_gradient_accum.add_(L.xyz_gradient_accum)
+            self.denom.add_(L.denom)
+            L.xyz_gradient_accum.zero_()
+            L.denom.zero_()
+
+    def reduce_densification_stats(self):
+        self._fold_stats()
+        return super().reduce_densification_stats()
+
+    def uv_densify(self, increase_num: int, generator=None) -> int:
+        torch.cuda.synchronize()
+        n = super().uv_densify(increase_num, generator)
+        self._build_lanes()
+        return n
+
+    def prune_low_opacity(self, min_opacity: float = 0.005) -> int:
+        torch.cuda.synchronize()
+        self._fold_stats()
+        n = super().prune_low_opacity(min_opacity)
+        self._build_lanes()
+        return n
+
+    def reset_opacity(self) -> None:
+        torch.cuda.synchronize()
+        super().reset_opacity()          # in place: the lanes' leaves see it (shared storage), their graphs stay valid
+
+    def load_state_dict(self, sd: dict) -> list:
+        torch.cuda.synchronize()
+        ignored = super().load_state_dict(sd)
+        self._build_lanes()
+        return ignored

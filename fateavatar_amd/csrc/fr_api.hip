@@ -309,7 +309,30 @@ int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, flo
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step: arrays must be 16-byte aligned");
-    return launch_adam(*cfg, param, grad, exp_avg, exp_avg_sq, n, state, static_cast<hipStream_t>(stream));
+    const float* one[1] = {grad};
+    return launch_adam(*cfg, param, one, 1, exp_avg, exp_avg_sq, n, state, static_cast<hipStream_t>(stream));
+}
+
+int fr_adam_step_multi(const fr_adam_config* cfg, float* param, const float* const* grads, int32_t n_grads, float* exp_avg,
+                       float* exp_avg_sq, uint64_t n, float* state, void* stream)
+{
+    if (!cfg || cfg->n_segments < 1 || cfg->n_segments > FR_ADAM_MAX_SEGMENTS)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: 1..FR_ADAM_MAX_SEGMENTS segments");
+    if (!grads || n_grads < 1 || n_grads > FR_ADAM_MAX_GRADS)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: 1..FR_ADAM_MAX_GRADS gradient buffers");
+    for (int k = 0; k < n_grads; k++)
+        if (n > 0 && (!grads[k] || (reinterpret_cast<uintptr_t>(grads[k]) & 15)))
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: null or misaligned gradient buffer");
+    if (n > 0 && (!param || !exp_avg || !exp_avg_sq || !state)) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: null array");
+    uint64_t prev = 0;
+    for (int i = 0; i < cfg->n_segments; i++) {
+        if (cfg->segment_end[i] < prev) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: segment ends must ascend");
+        prev = cfg->segment_end[i];
+    }
+    if (prev != n) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: the last segment must end at n");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_adam_step_multi: arrays must be 16-byte aligned");
+    return launch_adam(*cfg, param, grads, n_grads, exp_avg, exp_avg_sq, n, state, static_cast<hipStream_t>(stream));
 }
 
 size_t fr_l1_workspace_bytes(void) { return 17 * 128 + 1024 * sizeof(float); }

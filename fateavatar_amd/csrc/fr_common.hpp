@@ -308,8 +308,8 @@ int launch_bind_forward(const fr_binding& b, float* xyz, float* rot, float* scal
 int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g_rot, const float* g_scale, float* d_verts,
                          float* d_offset, float* d_rotation, float* d_scaling, hipStream_t s);
 int launch_face_scale(int F, const float* verts, const int* faces, float* out, hipStream_t s);
-int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                unsigned long long n, float* state, hipStream_t s);
+int launch_adam(const fr_adam_config& cfg, float* param, const float* const* grad_bufs, int n_grads, float* exp_avg,
+                float* exp_avg_sq, unsigned long long n, float* state, hipStream_t s);
 int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                         hipStream_t s);
 int launch_multi_copy(int n_seg, float* const* dst, const float* const* src, const unsigned long long* count, hipStream_t s);

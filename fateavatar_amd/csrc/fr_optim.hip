@@ -50,7 +50,27 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
     return p;
 }
 
-__global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ param, const float4* __restrict__ grad,
+// the gradient of the step = the SUM of up to FR_ADAM_MAX_GRADS buffers (the views of a batch rendered in flight
+// together, each into its own buffer; grad_scale turns the sum into the mean): no pass of its own to add them up
+struct AdamGrads {
+    int n;
+    const float* g[FR_ADAM_MAX_GRADS];
+};
+
+__device__ __forceinline__ float4 adam_grad4(const AdamGrads& gs, unsigned long long i)
+{
+    float4 r = reinterpret_cast<const float4*>(gs.g[0])[i];
+#pragma unroll
+    for (int k = 1; k < FR_ADAM_MAX_GRADS; k++) {
+        if (k < gs.n) {
+            const float4 t = reinterpret_cast<const float4*>(gs.g[k])[i];
+            r.x += t.x, r.y += t.y, r.z += t.z, r.w += t.w;
+        }
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ param, AdamGrads grads,
                                               float4* __restrict__ exp_avg, float4* __restrict__ exp_avg_sq,
                                               unsigned long long n, float* state)
 {
@@ -74,7 +94,7 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ p
         }
         if (i < n4) {
             float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
-            const float4 g = grad[i];
+            const float4 g = adam_grad4(grads, i);
             adam_one(p.x, g.x, m.x, v.x, lr[0], inv_sqrt_bc2, a);
             adam_one(p.y, g.y, m.y, v.y, lr[1], inv_sqrt_bc2, a);
             adam_one(p.z, g.z, m.z, v.z, lr[2], inv_sqrt_bc2, a);
@@ -82,10 +102,13 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ p
             param[i] = p, exp_avg[i] = m, exp_avg_sq[i] = v;
         } else {  // tail of a buffer whose length is not a multiple of 4
             float* ps = reinterpret_cast<float*>(param);
-            const float* gs = reinterpret_cast<const float*>(grad);
             float* ms = reinterpret_cast<float*>(exp_avg);
             float* vs = reinterpret_cast<float*>(exp_avg_sq);
-            for (int k = 0; k < 4 && e0 + k < n; k++) adam_one(ps[e0 + k], gs[e0 + k], ms[e0 + k], vs[e0 + k], lr[k], inv_sqrt_bc2, a);
+            for (int k = 0; k < 4 && e0 + k < n; k++) {
+                float g1 = grads.g[0][e0 + k];
+                for (int q = 1; q < grads.n; q++) g1 += grads.g[q][e0 + k];
+                adam_one(ps[e0 + k], g1, ms[e0 + k], vs[e0 + k], lr[k], inv_sqrt_bc2, a);
+            }
         }
     }
     // every thread of this workgroup has read the old state (above) before the barrier; the last workgroup to get here
@@ -96,10 +119,13 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ p
     }
 }
 
-int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                unsigned long long n, float* state, hipStream_t s)
+int launch_adam(const fr_adam_config& cfg, float* param, const float* const* grad_bufs, int n_grads, float* exp_avg,
+                float* exp_avg_sq, unsigned long long n, float* state, hipStream_t s)
 {
     if (n == 0) return FR_OK;
+    AdamGrads grads;
+    grads.n = n_grads;
+    for (int k = 0; k < FR_ADAM_MAX_GRADS; k++) grads.g[k] = k < n_grads ? grad_bufs[k] : grad_bufs[0];
     AdamArgs a;
     a.n_seg = cfg.n_segments;
     for (int i = 0; i < FR_ADAM_MAX_SEGMENTS; i++) {
@@ -114,8 +140,8 @@ int launch_adam(const fr_adam_config& cfg, float* param, const float* grad, floa
     const unsigned long long quads = (n + 3) / 4;
     unsigned long long blocks = (quads + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, reinterpret_cast<float4*>(param),
-                       reinterpret_cast<const float4*>(grad), reinterpret_cast<float4*>(exp_avg),
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, s, a, reinterpret_cast<float4*>(param), grads,
+                       reinterpret_cast<float4*>(exp_avg),
                        reinterpret_cast<float4*>(exp_avg_sq), n, state);
     FR_HIP(hipGetLastError());
     return FR_OK;

@@ -47,14 +47,14 @@ def l1_loss_and_grad(img: torch.Tensor, gt: torch.Tensor, loss_out: Optional[tor
 
 
 def multi_copy(pairs) -> None:
-    """`dst.copy_(src)` for up to four (dst, src) pairs of contiguous float32 device tensors in ONE launch
-    (`fr_multi_copy`): the per-frame inputs of a captured step."""
+    """`dst.copy_(src)` for up to twelve (dst, src) pairs of contiguous float32 device tensors in ONE launch
+    (`fr_multi_copy`): the per-frame inputs of a captured step (of every frame of a batch)."""
     import ctypes as C
     pairs = [(d, s) for d, s in pairs if d.numel()]
     if not pairs:
         return
-    if len(pairs) > 4:
-        raise RuntimeError("multi_copy: at most four pairs")
+    if len(pairs) > 12:
+        raise RuntimeError("multi_copy: at most twelve pairs")
     dev = pairs[0][0].device
     for d, s in pairs:
         if not (d.is_cuda and s.is_cuda and d.device == dev and s.device == dev):

@@ -167,6 +167,16 @@ class TorchCamera:
         self.full_proj_transform = self._packed[16:32].view(4, 4)
         self.camera_center = self._packed[32:35]
 
+    def clone(self) -> "TorchCamera":
+        """A camera with its own matrix block (same intrinsics): the static input of another captured frame."""
+        o = TorchCamera.__new__(TorchCamera)
+        o.__dict__.update(self.__dict__)
+        o._packed = self._packed.clone()
+        o.world_view_transform = o._packed[0:16].view(4, 4)
+        o.full_proj_transform = o._packed[16:32].view(4, 4)
+        o.camera_center = o._packed[32:35]
+        return o
+
     def copy_from(self, other: "TorchCamera") -> None:
         """Overwrite the matrices in place (same intrinsics): lets a captured HIP graph render a new view."""
         self.check_same_intrinsics(other)

@@ -8,7 +8,7 @@ a dozen `foreach` kernels, and nothing step-dependent on the host, so the step c
 from __future__ import annotations
 
 import ctypes as C
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 
@@ -97,12 +97,25 @@ class FusedAdam:
         self.cfg.grad_scale = float(s)
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, grads: Optional[Sequence[torch.Tensor]] = None) -> None:
+        """One Adam step on `self.grad` — or, given `grads` (1 .. FR_ADAM_MAX_GRADS flat buffers laid out like the
+        parameters), on their SUM: the views of a batch back-propagate into a buffer each, and grad_scale makes the sum
+        the batch mean."""
         dev = self.param.device
         with torch.cuda.device(dev):
-            rc = _lib.lib().fr_adam_step(C.byref(self.cfg), self.param.data_ptr(), self.grad.data_ptr(),
-                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.param.numel(),
-                                         self.state.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if grads is None:
+                rc = _lib.lib().fr_adam_step(C.byref(self.cfg), self.param.data_ptr(), self.grad.data_ptr(),
+                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.param.numel(),
+                                             self.state.data_ptr(), stream)
+            else:
+                for g in grads:
+                    if g.shape != self.param.shape or g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
+                        raise RuntimeError("FusedAdam.step: gradient buffers must look like the parameter buffer")
+                ptrs = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+                rc = _lib.lib().fr_adam_step_multi(C.byref(self.cfg), self.param.data_ptr(), ptrs, len(grads),
+                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.param.numel(),
+                                                   self.state.data_ptr(), stream)
         if rc != _lib.FR_OK:
             raise RuntimeError(f"fr_adam_step failed: {_lib.last_error()}")
 

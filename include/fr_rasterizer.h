@@ -202,6 +202,12 @@ typedef struct fr_adam_config {
 } fr_adam_config;
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  uint64_t n, float* state, void* hip_stream);
+/* The same step with the gradient given as the SUM of n_grads (1 .. FR_ADAM_MAX_GRADS) buffers of n floats: the views of
+ * a batch (the reference's `for bs_ in range(bs)` loop, model/fateavatar.py:251-276) each back-propagate into their own
+ * buffer, in flight together; grad_scale = 1 / (views x ranks) makes it the batch mean of train/loss.py:92-105. */
+#define FR_ADAM_MAX_GRADS 4
+int fr_adam_step_multi(const fr_adam_config* cfg, float* param, const float* const* grads, int32_t n_grads,
+                       float* exp_avg, float* exp_avg_sq, uint64_t n, float* state, void* hip_stream);
 
 /* ---- the image loss of the optimisation step (reference nn.L1Loss(reduction='mean') on the rendered
  * image, model/loss.py:92, followed by loss.backward()): loss = mean |img - gt| and grad = sign(img - gt) / n (what
@@ -214,7 +220,7 @@ int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, 
 
 /* ---- up to FR_COPY_MAX_SEGMENTS device-to-device copies of float arrays in one launch (the per-frame inputs of a
  * captured step: camera block, posed vertices, target image).  Segments must not overlap each other. */
-#define FR_COPY_MAX_SEGMENTS 4
+#define FR_COPY_MAX_SEGMENTS 12
 int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src, const uint64_t* count, void* hip_stream);
 
 /* ---- FateAvatar's mesh binding (reference model/fateavatar.py:225-258 with

@@ -270,3 +270,64 @@ def test_checkpoint_layout_and_reference_style_load(gpu_device, tmp_path):
     l = st2.step(S["cams"][0], S["posed"][0], gts[0])
     torch.cuda.synchronize()
     assert np.isfinite(float(l))
+
+
+def test_batch_step_is_the_mean_gradient_step_of_its_frames(gpu_device):
+    """AvatarBatchStep (K frames per step, in flight together) against what it stands for: the K frames' gradients,
+    each computed alone, averaged, and ONE Adam step on the mean (the reference's batch loop, model/fateavatar.py:251-276,
+    with the loss averaged over the batch, train/loss.py:92-105).  Checked for the eager lanes and the captured ones,
+    over several steps, including the per-lane densification statistics."""
+    import torch
+    from fateavatar_amd.avatar import AvatarBatchStep, AvatarStep
+    from fateavatar_amd.optim import FusedAdam
+    dev = gpu_device
+    K, P, res, n_frames, steps = 3, 20_000, 256, 6, 8
+    S = _setup(dev, P, res, n_frames)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+
+    # ---- the reference procedure: one frame at a time, no optimizer inside; Adam by hand on the mean gradient
+    pc_r = S["make"]()
+    ref = AvatarStep(pc_r, S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=False)
+    adam = FusedAdam(pc_r.flat, torch.zeros_like(pc_r.flat), ref.adam_segments(), grad_scale=1.0)
+    losses_ref = []
+    for it in range(steps):
+        mean = torch.zeros_like(pc_r.flat)
+        ls = []
+        for k in range(K):
+            f = (it * K + k) % n_frames
+            ref.cam.copy_from(S["cams"][f])
+            ref.verts.copy_(S["posed"][f])
+            ref.gt.copy_(gts[f])
+            ref._forward_backward()
+            mean.add_(pc_r.collect_grads(), alpha=1.0 / K)
+            ls.append(float(ref.loss))
+        adam.grad.copy_(mean)
+        adam.step()
+        losses_ref.append(ls)
+    torch.cuda.synchronize()
+    stats_ref = (ref.xyz_gradient_accum.clone(), ref.denom.clone())
+
+    for use_graph in (False, True):
+        pc = S["make"]()
+        st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=use_graph)
+        losses = []
+        for it in range(steps):
+            fs = [(it * K + k) % n_frames for k in range(K)]
+            out = st.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])
+            losses.append([float(x) for x in out])
+        torch.cuda.synchronize()
+        st.check()
+        assert (st.lanes[0].graph is not None) == use_graph and st.overflows == 0
+        assert st.adam.step_count == steps
+        assert np.allclose(losses, losses_ref, rtol=2e-3), (use_graph, losses[-1], losses_ref[-1])
+        assert float((pc.flat - pc_r.flat).abs().max()) < 5e-3, use_graph
+        assert util_rel_l2(pc.flat, pc_r.flat) < 1e-3, use_graph
+        acc, den = st.reduce_densification_stats()
+        assert torch.equal(den, stats_ref[1]) and float(den.max()) == steps * K
+        assert util_rel_l2(acc, stats_ref[0]) < 1e-3
+
+
+def util_rel_l2(a, b):
+    import torch
+    return float(torch.linalg.norm((a - b).double()) / torch.linalg.norm(b.double()))

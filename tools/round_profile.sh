@@ -10,6 +10,7 @@ python $R/bench.py --opacity 0.9 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_o
 python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_dense.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 > $O/${tag}_train_step_fateavatar_batch4.json 2>> $O/${tag}_bench.err
 FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${tag}_bench_2ranks_gloo_1gpu.json 2>> $O/${tag}_bench.err
 # per-kernel durations: one frame at a time (the roofline figures are per ISOLATED launch), then the default command
 $R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --no-graph --in-flight 1 > /dev/null 2>&1
