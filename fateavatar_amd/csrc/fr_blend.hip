@@ -223,18 +223,11 @@ __device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, fl
 __device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g, float tile_x0,
                                              float tile_y0)
 {
-    const float2 xy = g.means2D[id];
-    const float4 co = g.conic_opacity[id];
-    const float4 c = g.rgba[id];
-    float4* r = recs + (size_t)pos * kRecQuads;
-    // the conic is stored pre-scaled so that the blend loops get log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into
-    // v_exp_f32 (two multiplies less per pixel x Gaussian pair): a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
-    constexpr float kLog2e = 1.4426950408889634f;
-    const float a2 = co.x * (-0.5f * kLog2e), b2 = co.y * (-kLog2e), c2 = co.z * (-0.5f * kLog2e);
     (void)tile_x0, (void)tile_y0;
-    r[0] = make_float4(xy.x, xy.y, a2, b2);
-    r[1] = make_float4(c2, co.w, c.x, c.y);
-    r[2] = make_float4(c.z, __uint_as_float(id), 0.f, 0.f);   // (q2.zw: the footprint mask while a unit is staged in LDS)
+    const float4* t = g.rec_tmpl + (size_t)id * kRecQuads;   // (k_preprocess_fwd built the record: one 48-byte gather)
+    const float4 q0 = t[0], q1 = t[1], q2 = t[2];
+    float4* r = recs + (size_t)pos * kRecQuads;
+    r[0] = q0, r[1] = q1, r[2] = q2;   // (q2.zw: the footprint mask while a unit is staged in LDS)
 }
 
 // Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
@@ -245,30 +238,27 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
                                               int lane, const GeomView& g, float tile_x0, float tile_y0)
 {
     constexpr int B = K < 4 ? K : 4;
-    constexpr float kLog2e = 1.4426950408889634f;
+    (void)tile_x0, (void)tile_y0;
 #pragma unroll
     for (int r0 = 0; r0 < K; r0 += B) {
-        float2 xy[B];
-        float4 co[B], c[B];
-        uint32_t id[B];
+        float4 q0[B], q1[B], q2[B];
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
-            id[u] = i < n ? (uint32_t)v[r0 + u] : 0u;
-            xy[u] = g.means2D[id[u]];
-            co[u] = g.conic_opacity[id[u]];
-            c[u] = g.rgba[id[u]];
+            const uint32_t id = i < n ? (uint32_t)v[r0 + u] : 0u;
+            // (component-wise on purpose: as plain 16-byte copies the compiler turns load + store into a 48-byte memcpy
+            // through a stack slot — 208 bytes of scratch per lane and a sort kernel 15 us slower)
+            const float* __restrict__ t = reinterpret_cast<const float*>(g.rec_tmpl + (size_t)id * kRecQuads);
+            q0[u] = make_float4(t[0], t[1], t[2], t[3]);
+            q1[u] = make_float4(t[4], t[5], t[6], t[7]);
+            q2[u] = make_float4(t[8], t[9], 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
             if (i < n) {
                 float4* r = recs + (size_t)(start + i) * kRecQuads;
-                const float a2 = co[u].x * (-0.5f * kLog2e), b2 = co[u].y * (-kLog2e), c2 = co[u].z * (-0.5f * kLog2e);
-                (void)tile_x0, (void)tile_y0;
-                r[0] = make_float4(xy[u].x, xy[u].y, a2, b2);
-                r[1] = make_float4(c2, co[u].w, c[u].x, c[u].y);
-                r[2] = make_float4(c[u].z, __uint_as_float(id[u]), 0.f, 0.f);   // q2.zw: see write_record
+                r[0] = q0[u], r[1] = q1[u], r[2] = q2[u];
             }
         }
     }

@@ -302,9 +302,16 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             radius_out = mr;
             a.g.depth[idx] = p_view.z;
             key_depth = p_view.z;
-            a.g.means2D[idx] = make_float2(pix_x, pix_y);
             a.g.conic_opacity[idx] = make_float4(conic_a, conic_b, conic_c, opacity);
-            a.g.rgba[idx] = make_float4(col[0], col[1], col[2], 0.f);
+            {
+                // the blend record (GeomView::rec_tmpl): the conic pre-scaled so that the blend loops get
+                // log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into v_exp_f32: a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
+                constexpr float kLog2e = 1.4426950408889634f;
+                float4* t = a.g.rec_tmpl + (size_t)idx * 3;
+                t[0] = make_float4(pix_x, pix_y, conic_a * (-0.5f * kLog2e), conic_b * (-kLog2e));
+                t[1] = make_float4(conic_c * (-0.5f * kLog2e), opacity, col[0], col[1]);
+                t[2] = make_float4(col[2], __uint_as_float((uint32_t)idx), 0.f, 0.f);
+            }
             a.g.clamped[idx] = clamp_bits;
 
             // ---- 8x8-tile rectangle of the alpha >= 1/255 footprint, clipped to the pixels the
