@@ -19,6 +19,7 @@ ap.add_argument("K", type=int, nargs="?", default=2)
 ap.add_argument("--P", type=int, default=100_000)
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--extra", action="store_true", help="a fourth stream moves 2 x 23.6 MB per step, as a gradient exchange would")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -61,6 +62,10 @@ for v in views:
     v.capture()
 
 
+xs = torch.cuda.Stream()
+xa, xb = torch.zeros(5_900_000, device=dev), torch.zeros(5_900_000, device=dev)
+
+
 def run(active, steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -68,6 +73,10 @@ def run(active, steps):
         for v in active:
             with torch.cuda.stream(v.stream):
                 v.graph.replay()
+        if a.extra:
+            with torch.cuda.stream(xs):
+                xb.copy_(xa, non_blocking=True)
+                xa.add_(xb)
     torch.cuda.synchronize()
     return steps * len(active) / (time.perf_counter() - t0)
 
