@@ -144,7 +144,8 @@ class HipEngine:
         self.dev = torch.device("cuda", local)
         self.exchanging = world > 1   # the views' completion events and second buffer sets are only needed by the exchange
         self.step_no = 0
-        K = self.K = max(1, args.in_flight)
+        self.auto = args.in_flight <= 0          # pick the number of views in flight by a short calibration run
+        K = self.K = 3 if self.auto else args.in_flight
         # replicated Gaussians (same seed everywhere), view index (rank * K + k) of world * K views around the head
         self.views = [_View(self, k, scenes.head_scene(P=args.P, res=args.res, sh_degree=args.sh_degree, seed=0,
                                                        view=rank * K + k, n_views=max(world * K, 1), scale=args.scale,
@@ -186,9 +187,33 @@ class HipEngine:
             v.graph = v.graphs[0]
         self.graph = self.views[0].graph
 
-    def enqueue_frame(self, views=None):
+    def calibrate(self, world):
+        """--in-flight 0 (default): how many views should be in flight?  It depends on how the runtime maps streams to
+        hardware queues (three is best with its default four queues), so it is measured: 40 steps with 1,
+        2 and 3 views, rates summed over the ranks, best count kept — the same on every rank."""
+        self.calibration = None
+        if not self.auto:
+            return
+        rates = []
+        for k in range(1, len(self.views) + 1):
+            for _ in range(5):
+                self.enqueue_frame(self.views[:k], count=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                self.enqueue_frame(self.views[:k], count=False)
+            torch.cuda.synchronize()
+            rates.append(40 * k / (time.perf_counter() - t0))
+        r = torch.tensor(rates, dtype=torch.float64, device=self.dev)
+        if world > 1:
+            torch.distributed.all_reduce(r)
+        self.K = int(torch.argmax(r).item()) + 1
+        self.views = self.views[:self.K]
+        self.calibration = {str(k + 1): round(float(x) / world, 1) for k, x in enumerate(r.tolist())}
+
+    def enqueue_frame(self, views=None, count=True):
         """One step: every view's render + backward, each on its own stream."""
-        which = self.step_no & 1 if self.exchanging else 0
+        which = self.step_no & 1 if (self.exchanging and count) else 0
         self.which = which
         for v in (views or self.views):
             with torch.cuda.stream(v.stream):
@@ -201,7 +226,8 @@ class HipEngine:
                         self.frame(v, which)
                 if self.exchanging:
                     v.done.record(v.stream)
-        self.step_no += 1
+        if count:
+            self.step_no += 1
 
     def flat_grads(self):
         """Gradient buffers of the step enqueued last."""
@@ -251,6 +277,7 @@ class StubEngine:
         self.dev = torch.device("cpu")
         self.rank, self.k = rank, 0
         self.K = max(1, args.in_flight)
+        self.calibration = None
         self.grads = [torch.zeros(1 << 12) for _ in range(self.K)]
         self.scene = None
         self.grads_read = None
@@ -258,7 +285,10 @@ class StubEngine:
     def prepare(self):
         pass
 
-    def enqueue_frame(self, views=None):
+    def calibrate(self, world):
+        pass
+
+    def enqueue_frame(self, views=None, count=True):
         for j, g in enumerate(self.grads):
             g.copy_(torch.arange(g.numel(), dtype=torch.float32) * 1e-3 + (self.rank * self.K + j + 1) * (self.k + 1))
         self.k += 1
@@ -333,8 +363,9 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--scale", type=float, default=None, help="splat scale (default: the template's NN spacing at P)")
     ap.add_argument("--opacity", type=float, default=0.1, help="splat opacity (the metric's scene: 0.1)")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="views of a step that run concurrently on one GPU (1 = one frame at a time, as in round 1)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="views of a step that run concurrently on one GPU: 1 = one frame at a time (as in round 1), 0 = "
+                         "calibrate (1, 2 or 3, whichever renders most frames per second here)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
@@ -363,6 +394,7 @@ def main():
 
     eng = (StubEngine if STUB else HipEngine)(args, rank, world, local)
     eng.prepare()
+    eng.calibrate(world)
     xchg = GradExchange(eng.flat_grads()[0]) if world > 1 else None
 
     def step():
@@ -489,6 +521,7 @@ def main():
                                    "forward+backward through render() with a fixed dL/dpixel",
                        "frames_per_step_per_gpu": eng.K,
                        "frames_in_flight_per_gpu": eng.K,
+                       "in_flight_calibration_frames_per_s": eng.calibration,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
                        "parallelism": f"dp{world} ({eng.K} view(s) per GPU and step, each on its own stream; flat-grad all-reduce"
