@@ -372,7 +372,7 @@ __device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t b
 }
 
 // Grid: kMediumSorters workgroups that sort the medium lists (257..1024 keys, four waves per list, static
-// round-robin over the list the scan kernel built), followed by Q = ceil(T/4) workgroups of 4 waves for the
+// round-robin over the list k_tile_totals built), followed by Q = ceil(T/4) workgroups of 4 waves for the
 // short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
 // image region land in different workgroups) and sorts it in registers if it has <= 256 keys.  Lists longer
 // than 1024 are left to k_tile_sort_big.
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     // longest jobs first in dispatch order: medium lists, then the short ones
     if (blockIdx.x < kMediumSorters) {
         if (overflow) return;
-        // medium lists (<= 1024): four waves each, static round-robin over the list built by the scan kernel
+        // medium lists (<= 1024): four waves each, static round-robin over the list built by k_tile_totals
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t nm = v.counts->medium_tiles;

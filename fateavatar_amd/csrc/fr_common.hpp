@@ -108,8 +108,8 @@ struct DeviceCounts {  // lives at the head of the image buffer
 struct ImageView {
     DeviceCounts* counts;
     // The per-tile counters do NOT live in the image buffer: they belong to the handle (fr_handle_impl::tile_counters),
-    // are zero between frames (the scan re-zeroes tile_count after reading it, the emit pass counts tile_over back
-    // down) and so need no zeroing launch per frame.  launch_forward points these two members at them.
+    // are zero between frames (k_tile_totals re-zeroes tile_count after reading it) and so need no zeroing launch per
+    // frame.  launch_forward points tile_count / buckets at them.
     // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
     // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
     // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
@@ -173,7 +173,7 @@ struct BinningView {
     size_t cap, unit_cap;
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
     float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
-    uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_local writes it, the backward reads it)
+    uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_chained writes it, the backward reads it)
     uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile, segment, list start, list length)
     uint32_t* unit_done;  // [unit_cap] k_unit_blend_chained: the unit's final contribution is in memory (zeroed by k_tile_sort)
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel

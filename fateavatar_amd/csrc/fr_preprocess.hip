@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
             }
         }
     }
-    // num_rendered in reference semantics: per-workgroup partial sums, added up by the scan kernel (a single
+    // num_rendered in reference semantics: per-workgroup partial sums, added up by k_tile_totals (a single
     // counter would serialise one device-scope atomic per wave, ~11 ns each)
     __shared__ uint32_t s_ref[4];
     uint32_t s = ref_tiles;

@@ -130,7 +130,7 @@ class TrainStep:
                 d.copy_(s, non_blocking=True)
 
     def _poll_overflow(self):
-        """The scan kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
+        """The sort kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
         needs no synchronisation (they belong to the most recent frame that has got that far).  A replayed frame that
         overflowed the capacity the graph was captured with produced no image and no gradients: raise the capacity,
         drop the graph (the next steps run eagerly with the overflow check, then re-capture) and count the event."""

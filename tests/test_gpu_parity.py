@@ -200,7 +200,7 @@ def test_long_tile_lists_take_the_multi_wave_and_fallback_sorts(P, lo, hi, gpu_d
 
 
 def test_large_non_square_image(gpu_device):
-    """1536 x 1000 pixels = 192 x 125 tiles: the scan kernel's multi-quad-per-thread path, partial edge tiles in y,
+    """1536 x 1000 pixels = 192 x 125 tiles: the totals kernel's multi-workgroup path, partial edge tiles in y,
     and the XCD-private counter pitch for a tile count that is not a multiple of 16."""
     s = scenes.random_scene(5000, 1000, 1536, sh_degree=1, seed=21, spread=0.28, scale_lo=0.004, scale_hi=0.03,
                             opacity_lo=0.2, opacity_hi=0.9)

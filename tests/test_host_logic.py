@@ -164,3 +164,22 @@ def test_reference_render_runs_against_the_alias_packages_up_to_the_device_bound
     cam = TorchCamera(s.camera, torch.device("cpu"))
     with pytest.raises(RuntimeError, match="HIP device|no CPU"):
         ref.render(cam, pc, torch.from_numpy(s.bg), device="cpu")
+
+
+def test_handle_slot_is_scoped():
+    """`with rasterizer.handle_slot(k):` selects the k-th fr_handle of the device for the calls inside it (frames that are
+    to be in flight together take one slot each) and restores the previous slot on the way out, also on an exception."""
+    from fateavatar_amd import rasterizer
+    assert rasterizer._slot == 0
+    with rasterizer.handle_slot(2):
+        assert rasterizer._slot == 2
+        with rasterizer.handle_slot(1):
+            assert rasterizer._slot == 1
+        assert rasterizer._slot == 2
+    assert rasterizer._slot == 0
+    try:
+        with rasterizer.handle_slot(3):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert rasterizer._slot == 0
