@@ -95,7 +95,9 @@ def _check_backward(o, h, dpix, name):
         if scale == 0:
             assert np.abs(got).max() == 0, (name, k)
             continue
-        fr = util.frac_close(got[keep], ref[keep], 1e-4, 1e-6 * scale)
+        # (absolute floor 5 ppm of the largest entry: a splat that covers thousands of pixels sums thousands of signed
+        # terms to a small net gradient, and the two implementations add them in different orders)
+        fr = util.frac_close(got[keep], ref[keep], 1e-4, 5e-6 * scale)
         rl = util.rel_l2(got[keep], ref[keep])
         # (0.1 % of the entries, but never fewer than three: a scene of 100 Gaussians has 400 quaternion entries, and an
         # entry that is the small difference of large terms misses a 1e-4 relative test in fp32 either way)

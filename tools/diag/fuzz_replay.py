@@ -36,3 +36,23 @@ nc = h.n_contrib.cpu().numpy()
 for y, x in list(zip(*np.nonzero(bad)))[:12]:
     print(f"px ({x},{y}): margin {util.explain_pixel(o, x, y):.3f}  colour hip {col[:, y, x]} oracle {o.color[:, y, x]}  "
           f"T hip {fT[y, x]:.6e} oracle {o.final_T[y, x]:.6e}  n_contrib hip {nc[y, x]} oracle {o.n_contrib[y, x]}")
+if os.environ.get("FUZZ_BWD"):
+    from oracle import oracle
+    rng2 = np.random.default_rng(seed)
+    for it in range(K + 1):   # (replay fuzz_parity's stream once more for this case's dL/dpixel)
+        P_ = int(rng2.integers(1, 60000 if big else 6000))
+        H_, W_ = int(rng2.integers(8, 900 if big else 300)), int(rng2.integers(8, 900 if big else 300))
+        rng2.integers(0, 4); rng2.uniform(-3.5, -1.5); rng2.uniform(1, 20); o1 = rng2.uniform(0.001, 0.5); rng2.uniform(o1, 1.0)
+        rng2.uniform(0.05, 1.5); rng2.integers(1 << 30); rng2.choice([0.0, 0.1]); rng2.choice([1, 16]); rng2.uniform(0, 1, 3)
+        dpix = (rng2.uniform(-1, 1, (3, H_, W_)) / (H_ * W_)).astype(np.float32)
+    ob, hb = oracle.backward(o, dpix), h.backward(dpix)
+    k = os.environ["FUZZ_BWD"]
+    ref, got = getattr(ob, k).reshape(P, -1), hb[k].reshape(P, -1)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref)
+    bad = err > 1e-4 * np.abs(ref) + 1e-6 * scale
+    print(k, "entries off:", int(bad.sum()), "of", bad.size, "scale", scale)
+    for i in np.argwhere(bad)[:10]:
+        i = tuple(i)
+        print("  id", i, "ref", ref[i], "got", got[i], "err/|ref|", err[i] / abs(ref[i]), "err/scale", err[i] / scale,
+              "radius", o.radii[i[0]], "opacity", o.conic_opacity[i[0], 3])
