@@ -19,6 +19,7 @@ constexpr int kSubWords = 8;      // per-tile sub-list table: start (within the 
 // reads, independent alpha evaluations in flight, no divergent walk).
 constexpr uint32_t kDensePairsFwd = 1000;  // local forward blend: all-pairs loop above this many mask bits per unit
 constexpr uint32_t kDensePairsBwd = 1000;  // backward: the same choice inside k_unit_blend_bwd_sparse
+constexpr int kPreWG = 128;   // threads per workgroup of k_preprocess_fwd (its SH staging takes 12.5 KB of LDS per wave)
 constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
 constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)
@@ -67,7 +68,7 @@ struct GeomView {
                             // buffer: they belong to the handle (fr_handle_impl::accum), are all zero between
                             // backward passes (k_preprocess_bwd zeroes each row after reading it) and so cost the
                             // forward no zeroing writes; launch_forward / launch_backward point this member at them
-    uint32_t* block_ref_tiles;  // [ceil(P/256)] per-workgroup sums of the reference-semantics tiles_touched
+    uint32_t* block_ref_tiles;  // [ceil(P/kPreWG)] per-workgroup sums of the reference-semantics tiles_touched
     static GeomView make(void* buf, size_t P)
     {
         char* p = static_cast<char*>(buf);
@@ -79,14 +80,14 @@ struct GeomView {
         g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
         g.accum = nullptr;
-        g.block_ref_tiles = carve<uint32_t>(p, (P + 255) / 256 + 1);
+        g.block_ref_tiles = carve<uint32_t>(p, (P + kPreWG - 1) / kPreWG + 1);
         return g;
     }
     static size_t bytes(size_t P)
     {
         char* p = nullptr;
         GeomView g = make(p, P);
-        return reinterpret_cast<size_t>(g.block_ref_tiles + (P + 255) / 256 + 1) + 256;
+        return reinterpret_cast<size_t>(g.block_ref_tiles + (P + kPreWG - 1) / kPreWG + 1) + 256;
     }
 };
 

@@ -143,7 +143,7 @@ __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, 
 constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
 constexpr int kCountLdsBytes = 2816 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
 
-__global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
+__global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     float* const wave_lds = s_sh + (size_t)wave * wave_floats;
     if (sh_staged) {
         float* w_sh = wave_lds;
-        const int wave_first = blockIdx.x * 256 + wave * 64;
+        const int wave_first = blockIdx.x * kPreWG + wave * 64;
         if (wave_first < a.P)
             stage_wave_rows(w_sh, sh_stride, a.shs + (size_t)wave_first * M3, min(64, a.P - wave_first), M3, lane);
         my_sh = w_sh + lane * sh_stride;
@@ -461,7 +461,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreArgs a)
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (lane == 0) s_ref[wave] = s;
     __syncthreads();
-    if (threadIdx.x == 0) a.g.block_ref_tiles[blockIdx.x] = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3];
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kPreWG / 64; w++) t += s_ref[w];
+        a.g.block_ref_tiles[blockIdx.x] = t;
+    }
 }
 
 // Everything between the counting pass and the sort, in ONE wide launch (it used to be a totals kernel plus a
@@ -689,8 +693,8 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
         {
             StageScope sc(h, ST_PREPROCESS_FWD, s);
             const size_t sh_bytes = (in.shs && !in.colors_precomp) ? (size_t)64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
-            const size_t lds = 4 * (sh_bytes > (size_t)kCountLdsBytes ? sh_bytes : (size_t)kCountLdsBytes);
-            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), lds, s, a);
+            const size_t lds = (kPreWG / 64) * (sh_bytes > (size_t)kCountLdsBytes ? sh_bytes : (size_t)kCountLdsBytes);
+            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + kPreWG - 1) / kPreWG), dim3(kPreWG), lds, s, a);
         }
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
@@ -701,7 +705,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
             if ((rc = launch_zero(v.counts, sizeof(DeviceCounts), s))) return rc;
         }
         hipLaunchKernelGGL(k_tile_totals, dim3((v.tpad + 1023) / 1024), dim3(256), 0, s, v, T, cap, g.block_ref_tiles,
-                           (uint32_t)((P + 255) / 256));
+                           (uint32_t)((P + kPreWG - 1) / kPreWG));
     }
     FR_HIP(hipGetLastError());
     const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
