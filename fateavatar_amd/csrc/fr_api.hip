@@ -231,14 +231,14 @@ const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t fie
     GeomView g = GeomView::make(const_cast<void*>(geometry), (size_t)(P > 0 ? P : 0));
     switch (field) {
         case 0: return nullptr;   // (pixel-space centres: columns 0-1 of field 8)
-        case 1: return g.depth;
+        case 1: return nullptr;   // (view-space depth: column 10 of field 8)
         case 2: return g.conic_opacity;
         case 3: return nullptr;   // (colours: columns 6-8 of field 8)
         case 4: return g.cov3D;
-        case 5: return g.rect;
+        case 5: return nullptr;   // (the 8x8-tile rectangle is no longer stored)
         case 6: return g.clamped;
         case 7: return nullptr;   // (the gradient accumulators moved into the handle)
-        case 8: return g.rec_tmpl;   // [P][12]: x, y, a', b', c', opacity, r, g, b, id bits, 0, 0
+        case 8: return g.rec_tmpl;   // [P][12]: x, y, a', b', c', opacity, r, g, b, id bits, depth, 0
         default: return nullptr;
     }
 }

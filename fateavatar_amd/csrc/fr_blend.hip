@@ -251,7 +251,7 @@ __device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint
             const float* __restrict__ t = reinterpret_cast<const float*>(g.rec_tmpl + (size_t)id * kRecQuads);
             q0[u] = make_float4(t[0], t[1], t[2], t[3]);
             q1[u] = make_float4(t[4], t[5], t[6], t[7]);
-            q2[u] = make_float4(t[8], t[9], 0.f, 0.f);
+            q2[u] = make_float4(t[8], t[9], 0.f, 0.f);   // (.zw of a record in memory are unused; the template's .z is the depth)
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {

@@ -56,13 +56,11 @@ __host__ __device__ static inline T* carve(char*& p, size_t count)
 // Per-Gaussian state written by the forward preprocess and read by every later stage.
 struct GeomView {
     float4* rec_tmpl;       // [P*3] the 48-byte splat RECORD of the blend kernels as k_tile_sort copies it into every
-                            // (tile, Gaussian) instance's slot: (x, y, a', b'), (c', opacity, r, g), (b, id, 0, 0) with
+                            // (tile, Gaussian) instance's slot: (x, y, a', b'), (c', opacity, r, g), (b, id, depth, 0) with
                             // the pixel-space centre, the conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour
                             // fed to the blend (SH result or colors_precomp) — ONE gather per instance, not three
-    float* depth;           // [P] view-space z
     float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
     float* cov3D;           // [P*6]
-    uint2* rect;            // [P] 8x8-tile rectangle packed as (x0 | y0<<16, x1 | y1<<16), x1/y1 exclusive (diagnostics)
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward.  NOT part of the geometry
                             // buffer: they belong to the handle (fr_handle_impl::accum), are all zero between
@@ -74,10 +72,8 @@ struct GeomView {
         char* p = static_cast<char*>(buf);
         GeomView g;
         g.rec_tmpl = carve<float4>(p, P * 3);
-        g.depth = carve<float>(p, P);
         g.conic_opacity = carve<float4>(p, P);
         g.cov3D = carve<float>(p, P * 6);
-        g.rect = carve<uint2>(p, P);
         g.clamped = carve<uint8_t>(p, P);
         g.accum = nullptr;
         g.block_ref_tiles = carve<uint32_t>(p, (P + kPreWG - 1) / kPreWG + 1);

@@ -300,7 +300,6 @@ __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
                 if (!(fabsf(chk) < 3.0e38f)) break;
             }
             radius_out = mr;
-            a.g.depth[idx] = p_view.z;
             key_depth = p_view.z;
             a.g.conic_opacity[idx] = make_float4(conic_a, conic_b, conic_c, opacity);
             {
@@ -310,7 +309,7 @@ __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
                 float4* t = a.g.rec_tmpl + (size_t)idx * 3;
                 t[0] = make_float4(pix_x, pix_y, conic_a * (-0.5f * kLog2e), conic_b * (-kLog2e));
                 t[1] = make_float4(conic_c * (-0.5f * kLog2e), opacity, col[0], col[1]);
-                t[2] = make_float4(col[2], __uint_as_float((uint32_t)idx), 0.f, 0.f);
+                t[2] = make_float4(col[2], __uint_as_float((uint32_t)idx), p_view.z, 0.f);   // (.z: view-space depth, for diagnostics)
             }
             a.g.clamped[idx] = clamp_bits;
 
@@ -351,7 +350,6 @@ __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
         } while (false);
         a.radii[idx] = radius_out;
         if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
-        a.g.rect[idx] = rect;
     }
     // ---- count the (tile, Gaussian) instances AND write their keys.  The atomic that counts an instance hands out
     // its slot in the (tile, XCD) key bucket, and the key goes there at once: no second pass over the Gaussians (the

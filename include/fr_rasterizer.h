@@ -259,10 +259,10 @@ const float* fr_image_final_T(const void* image, int32_t W, int32_t H);
 const uint32_t* fr_image_n_contrib(const void* image, int32_t W, int32_t H);
 
 /* Test/diagnostic accessor: device pointer of one per-Gaussian array inside a geometry buffer filled by
- * fr_forward.  field: 1 depth (float), 2 conic_opacity (float4), 4 cov3D (6 floats), 5 tile rect (2 x uint32:
- * x0|y0<<16, x1|y1<<16 in 8x8 tiles), 6 clamped (uint8 bitmask), 8 the blend-record template (12 floats: x, y, a', b',
- * c', opacity, r, g, b, id bits, 0, 0 — the pixel-space centre and the colour that fields 0 and 3 used to hold are its
- * columns 0-1 and 6-8; 7 was the gradient accumulators: they live in the handle now).  NULL for any other field. */
+ * fr_forward.  field: 2 conic_opacity (float4), 4 cov3D (6 floats), 6 clamped (uint8 bitmask), 8 the blend-record
+ * template (12 floats: x, y, a', b', c', opacity, r, g, b, id bits, depth, 0 — the pixel-space centre, the view-space
+ * depth and the colour that fields 0, 1 and 3 used to hold are its columns 0-1, 10 and 6-8; 5 was the tile rectangle,
+ * 7 the gradient accumulators: they live in the handle now).  NULL for any other field. */
 const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t field);
 
 /* Test hook for the wave reduce-scatter used by the blend backward: in[64*36] (lane-major), out[64]:

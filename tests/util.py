@@ -47,10 +47,12 @@ class HipFrame:
         self.final_T, self.n_contrib = rasterizer.image_aux(self.img, self.H, self.W)
 
     def geometry(self, field: int, cols: int, dtype=torch.float32):
-        """A per-Gaussian array of the forward state.  Fields 0 (pixel-space centre) and 3 (colour) live inside the
+        """A per-Gaussian array of the forward state.  Fields 0 (pixel-space centre), 1 (depth) and 3 (colour) live inside the
         blend-record template (field 8, GeomView::rec_tmpl)."""
         if field == 0:
             return np.ascontiguousarray(self.geometry(8, 12)[:, 0:2])
+        if field == 1:
+            return np.ascontiguousarray(self.geometry(8, 12)[:, 10:11])
         if field == 3:
             t = self.geometry(8, 12)
             return np.ascontiguousarray(np.concatenate([t[:, 6:9], np.zeros((t.shape[0], 1), np.float32)], axis=1))
