@@ -328,7 +328,10 @@ class GradExchange:
         grads = eng.flat_grads()
         if len(grads) == 1:
             self.bufs[i].copy_(grads[0], non_blocking=True)
-        else:                                        # mean over the local views; the collective averages over the ranks
+        elif self.bufs[i].is_cuda:                   # mean over the local views (one pass); the collective averages over the ranks
+            from fateavatar_amd.loss import scaled_sum
+            scaled_sum(self.bufs[i], grads, 1.0 / len(grads))
+        else:                                        # (the CPU stub of tests/test_bench_dp.py)
             w = 1.0 / len(grads)
             torch.mul(grads[0], w, out=self.bufs[i])
             for g in grads[1:]:

@@ -358,4 +358,17 @@ int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src
     return launch_multi_copy(n_segments, dst, src, cnt, static_cast<hipStream_t>(stream));
 }
 
+int fr_scaled_sum(int32_t n_src, const float* const* src, float* dst, uint64_t count, float scale, void* stream)
+{
+    if (n_src < 1 || n_src > FR_ADAM_MAX_GRADS || !src || (count > 0 && !dst))
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_scaled_sum: 1..FR_ADAM_MAX_GRADS sources");
+    uintptr_t bits = reinterpret_cast<uintptr_t>(dst);
+    for (int k = 0; k < n_src; k++) {
+        if (count > 0 && !src[k]) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_scaled_sum: null source");
+        bits |= reinterpret_cast<uintptr_t>(src[k]);
+    }
+    if (bits & 15) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_scaled_sum: arrays must be 16-byte aligned");
+    return launch_scaled_sum(n_src, src, dst, count, scale, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -310,6 +310,7 @@ int launch_adam(const fr_adam_config& cfg, float* param, const float* const* gra
                 float* exp_avg_sq, unsigned long long n, float* state, hipStream_t s);
 int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                         hipStream_t s);
+int launch_scaled_sum(int n_src, const float* const* src, float* dst, unsigned long long count, float scale, hipStream_t s);
 int launch_multi_copy(int n_seg, float* const* dst, const float* const* src, const unsigned long long* count, hipStream_t s);
 int launch_selftest_reduce(const float* in, float* out, hipStream_t s);
 

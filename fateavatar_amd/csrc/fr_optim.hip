@@ -255,4 +255,48 @@ int launch_multi_copy(int n_seg, float* const* dst, const float* const* src, con
     return FR_OK;
 }
 
+// ---------------------------------------------------------------- scaled sum of up to four equally long arrays
+// dst = scale * (src[0] + ... + src[n-1]): the mean of the gradient buffers of the views a rank rendered in flight
+// together, written into the exchange buffer of the all-reduce in one pass (three PyTorch kernels otherwise: 142 MB of
+// traffic instead of 94 at 23.6 MB per buffer, on a GPU that is busy rendering the next step's frames).
+struct SumArgs {
+    int n;
+    const float* src[FR_ADAM_MAX_GRADS];
+};
+
+__global__ void __launch_bounds__(256) k_scaled_sum(SumArgs a, float* __restrict__ dst, unsigned long long count, float scale)
+{
+    const unsigned long long n4 = count / 4, stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t0; i < n4; i += stride) {
+        float4 r = reinterpret_cast<const float4*>(a.src[0])[i];
+#pragma unroll
+        for (int k = 1; k < FR_ADAM_MAX_GRADS; k++) {
+            if (k < a.n) {
+                const float4 t = reinterpret_cast<const float4*>(a.src[k])[i];
+                r.x += t.x, r.y += t.y, r.z += t.z, r.w += t.w;
+            }
+        }
+        reinterpret_cast<float4*>(dst)[i] = make_float4(r.x * scale, r.y * scale, r.z * scale, r.w * scale);
+    }
+    for (unsigned long long e = 4 * n4 + t0; e < count; e += stride) {
+        float r = a.src[0][e];
+        for (int k = 1; k < a.n; k++) r += a.src[k][e];
+        dst[e] = r * scale;
+    }
+}
+
+int launch_scaled_sum(int n_src, const float* const* src, float* dst, unsigned long long count, float scale, hipStream_t s)
+{
+    if (count == 0) return FR_OK;
+    SumArgs a;
+    a.n = n_src;
+    for (int k = 0; k < FR_ADAM_MAX_GRADS; k++) a.src[k] = k < n_src ? src[k] : src[0];
+    unsigned long long blocks = (count / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(k_scaled_sum, dim3((unsigned)blocks), dim3(256), 0, s, a, dst, count, scale);
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
 }  // namespace fr

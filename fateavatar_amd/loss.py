@@ -70,3 +70,23 @@ def multi_copy(pairs) -> None:
         rc = _lib.lib().fr_multi_copy(n, dst, src, cnt, torch.cuda.current_stream(dev).cuda_stream)
     if rc != _lib.FR_OK:
         raise RuntimeError(f"fr_multi_copy failed: {_lib.last_error()}")
+
+
+def scaled_sum(dst: torch.Tensor, srcs, scale: float) -> torch.Tensor:
+    """dst = scale * sum(srcs) for 1 .. 4 contiguous float32 device tensors of dst's size, in ONE pass (`fr_scaled_sum`):
+    the mean of the gradient buffers of the views a rank rendered in flight together."""
+    import ctypes as C
+    srcs = list(srcs)
+    if not 1 <= len(srcs) <= _lib.FR_ADAM_MAX_GRADS:
+        raise RuntimeError(f"scaled_sum: 1..{_lib.FR_ADAM_MAX_GRADS} sources")
+    dev = dst.device
+    for t in [dst] + srcs:
+        if not t.is_cuda or t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != dst.numel():
+            raise RuntimeError("scaled_sum: contiguous float32 tensors of one device and one size")
+    ptrs = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().fr_scaled_sum(len(srcs), ptrs, dst.data_ptr(), dst.numel(), float(scale),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+    if rc != _lib.FR_OK:
+        raise RuntimeError(f"fr_scaled_sum failed: {_lib.last_error()}")
+    return dst

@@ -218,6 +218,11 @@ size_t fr_l1_workspace_bytes(void);
 int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                     void* hip_stream);
 
+/* ---- dst = scale * (src[0] + ... + src[n_src - 1]), n_src in 1 .. FR_ADAM_MAX_GRADS arrays of `count` floats, 16-byte
+ * aligned: the mean of the gradient buffers of the views a rank rendered in flight together, written into the exchange
+ * buffer of the data-parallel all-reduce in one pass.  dst may be one of the sources. */
+int fr_scaled_sum(int32_t n_src, const float* const* src, float* dst, uint64_t count, float scale, void* hip_stream);
+
 /* ---- up to FR_COPY_MAX_SEGMENTS device-to-device copies of float arrays in one launch (the per-frame inputs of a
  * captured step: camera block, posed vertices, target image).  Segments must not overlap each other. */
 #define FR_COPY_MAX_SEGMENTS 12

@@ -70,3 +70,22 @@ def test_multi_copy(gpu_device):
     assert torch.equal(big[1:36], src[0]) and float(big[0]) == 0 and float(big[36]) == 0
     with pytest.raises(RuntimeError):
         multi_copy([(dst[0], src[1])])
+
+
+def test_scaled_sum(gpu_device):
+    from fateavatar_amd.loss import scaled_sum
+    g = torch.Generator().manual_seed(3)
+    for n in (1 << 20, 1001):
+        srcs = [torch.randn(n, generator=g).to(gpu_device) for _ in range(3)]
+        dst = torch.empty(n, device=gpu_device)
+        for k in (1, 2, 3):
+            scaled_sum(dst, srcs[:k], 1.0 / k)
+            want = srcs[0].clone()
+            for t in srcs[1:k]:
+                want = want + t
+            assert torch.equal(dst, want * (1.0 / k))
+        a = srcs[0].clone()
+        scaled_sum(a, [a, srcs[1]], 0.5)            # in place
+        assert torch.equal(a, (srcs[0] + srcs[1]) * 0.5)
+    with pytest.raises(RuntimeError):
+        scaled_sum(dst, [srcs[0][:10]], 1.0)
