@@ -123,7 +123,7 @@ class _View:
         # a random sign; it is fixed, so the step is exactly render + backward
         g = ((torch.rand((3, H, W), generator=torch.Generator().manual_seed(1 + eng.rank * 64 + k)) < 0.5).float() * 2 - 1)
         self.dL_dpix = (g / (3 * H * W)).to(eng.dev)
-        self.stream = torch.cuda.Stream(device=eng.dev)
+        self.stream = None            # (HipEngine picks streams that really overlap: fateavatar_amd/streams.py)
         self.done = torch.cuda.Event()
         self.graphs = [None] * len(self.pcs)
         self.graph = None
@@ -151,6 +151,9 @@ class HipEngine:
                                                        view=rank * K + k, n_views=max(world * K, 1), scale=args.scale,
                                                        opacity=args.opacity)) for k in range(K)]
         self.scene = self.views[0].scene
+        from fateavatar_amd.streams import concurrent_streams
+        for v, st in zip(self.views, concurrent_streams(K, self.dev, also_with=[torch.cuda.current_stream(self.dev)])):
+            v.stream = st
         self._render = render
         self.graph = None
         self.grads_read = [None, None]   # events: the exchange has read the gradient buffers of set 0 / 1

@@ -354,6 +354,10 @@ class AvatarBatchStep(AvatarStep):
         self.adam.set_grad_scale(1.0 / (self.world * self.K))
 
     def _build_lanes(self):
+        from .streams import concurrent_streams
+        # (streams that land on one hardware queue are serialised: pick lanes' streams that overlap with each other and
+        # with the caller's — fateavatar_amd/streams.py)
+        streams = concurrent_streams(self.K, self.dev, also_with=[torch.cuda.current_stream(self.dev)])
         self.lanes = []
         for k in range(self.K):
             L = _Lane()
@@ -366,7 +370,7 @@ class AvatarBatchStep(AvatarStep):
                 L.gt, L.loss, L._dimage = torch.zeros_like(self.gt), torch.zeros_like(self.loss), torch.zeros_like(self._dimage)
                 L.xyz_gradient_accum, L.denom = torch.zeros_like(self.xyz_gradient_accum), torch.zeros_like(self.denom)
             L.out, L.graph = None, None
-            L.stream, L.done = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
+            L.stream, L.done = streams[k], torch.cuda.Event()
             self.lanes.append(L)
         self._eager_steps = 0
         self._ready = torch.cuda.Event()

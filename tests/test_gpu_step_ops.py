@@ -89,3 +89,16 @@ def test_scaled_sum(gpu_device):
         assert torch.equal(a, (srcs[0] + srcs[1]) * 0.5)
     with pytest.raises(RuntimeError):
         scaled_sum(dst, [srcs[0][:10]], 1.0)
+
+
+def test_concurrent_streams_overlap(gpu_device):
+    """fateavatar_amd.streams: the runtime maps streams onto a few hardware queues; streams on one queue are serialised.
+    concurrent_streams() returns streams that overlap pairwise and with the caller's stream."""
+    from fateavatar_amd.streams import _overlap, concurrent_streams
+    cur = torch.cuda.current_stream(gpu_device)
+    ss = concurrent_streams(3, gpu_device, also_with=[cur])
+    assert len(ss) == 3 and len({s.cuda_stream for s in ss}) == 3
+    for i, a in enumerate(ss):
+        assert _overlap(cur, a, gpu_device, 400_000)
+        for b in ss[i + 1:]:
+            assert _overlap(a, b, gpu_device, 400_000) and _overlap(b, a, gpu_device, 400_000)

@@ -19,6 +19,7 @@ ap.add_argument("K", type=int, nargs="?", default=2)
 ap.add_argument("--P", type=int, default=100_000)
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--probe", action="store_true", help="pick the view streams with fateavatar_amd.streams.concurrent_streams")
 ap.add_argument("--extra", action="store_true", help="a fourth stream moves 2 x 23.6 MB per step, as a gradient exchange would")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -58,6 +59,10 @@ class View:
 
 
 views = [View(k) for k in range(a.K)]
+if a.probe:
+    from fateavatar_amd.streams import concurrent_streams
+    for v, st in zip(views, concurrent_streams(a.K, dev, also_with=[torch.cuda.current_stream()])):
+        v.stream = st
 for v in views:
     v.capture()
 
