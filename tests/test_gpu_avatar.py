@@ -331,3 +331,65 @@ def test_batch_step_is_the_mean_gradient_step_of_its_frames(gpu_device):
 def util_rel_l2(a, b):
     import torch
     return float(torch.linalg.norm((a - b).double()) / torch.linalg.norm(b.double()))
+
+
+def test_batch_step_survives_the_maintenance_schedule(gpu_device):
+    """AvatarBatchStep under densify / prune / opacity reset / checkpoint: the lanes' densification statistics are folded
+    together before anything reads them (every frame of every lane counts), the lanes are rebuilt over the re-bound
+    point set (fresh graphs, same shared parameter storage), the opacity reset keeps the captured lanes, and a step
+    restored from a checkpoint continues like the one that wrote it."""
+    import torch
+    from fateavatar_amd.avatar import AvatarBatchStep
+    dev = gpu_device
+    K = 2
+    S = _setup(dev, 5000, 96, 4, seed=3)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    pc = S["make"]()
+    st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K)
+
+    def run(n, start=0):
+        out = None
+        for it in range(start, start + n):
+            fs = [(it * K + k) % 4 for k in range(K)]
+            out = st.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])
+        torch.cuda.synchronize()
+        return [float(x) for x in out]
+
+    run(6)
+    assert st.lanes[0].graph is not None and st.lanes[1].graph is not None
+    assert st.lanes[1].pc.flat.data_ptr() == pc.flat.data_ptr() and st.lanes[1].pc.flat_grad.data_ptr() != pc.flat_grad.data_ptr()
+    acc, den = st.reduce_densification_stats()              # folds the lanes
+    assert float(den.max()) == 6 * K and float(st.lanes[1].denom.abs().max()) == 0.0
+    rows0 = pc.P
+    did = st.maintain(3000, dict(increase_num=200, prune_interval=10 ** 9))
+    assert did == {"densified": 200} and pc.P == rows0 + 200
+    assert all(L.graph is None and L.pc.P == pc.P and L.denom.shape == (pc.P, 1) for L in st.lanes)
+    assert st.lanes[1].pc.flat.data_ptr() == pc.flat.data_ptr()
+    l = run(6, 6)
+    assert all(np.isfinite(l)) and st.lanes[1].graph is not None
+    with torch.no_grad():
+        pc._opacity[::5] = -8.0
+    keep = ~(torch.sigmoid(pc._opacity) < 0.005).reshape(-1)
+    den_before = st.reduce_densification_stats()[1]
+    did = st.maintain(2000, dict(densify_interval=10 ** 9))
+    assert did["pruned"] == int((~keep).sum()) > 0 and pc.P == int(keep.sum())
+    assert torch.equal(st.denom, den_before[keep]) and float(st.denom.max()) == 6 * K
+    run(4, 12)
+    graphs = [L.graph for L in st.lanes]
+    did = st.maintain(60000, dict(densify_interval=10 ** 9, prune_interval=10 ** 9))
+    assert did == {"opacity_reset": True} and [L.graph for L in st.lanes] == graphs
+    assert float(torch.sigmoid(st.lanes[1].pc._opacity.detach()).max()) <= 0.01 + 1e-6      # the lanes share the storage
+    l = run(3, 16)
+    st.check()
+    assert all(np.isfinite(l)) and st.overflows == 0
+    # checkpoint round trip: a fresh step loaded from the state continues with the same losses
+    sd = st.state_dict()
+    pc2 = S["make"]()
+    st2 = AvatarBatchStep(pc2, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=False)
+    st2.load_state_dict(sd)
+    assert pc2.P == pc.P and st2.lanes[1].pc.flat.data_ptr() == pc2.flat.data_ptr()
+    fs = [0, 1]
+    a = [float(x) for x in st.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])]
+    b = [float(x) for x in st2.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])]
+    assert np.allclose(a, b, rtol=1e-4), (a, b)
