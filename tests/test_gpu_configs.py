@@ -82,7 +82,7 @@ def test_config5_head_500k_1024(variant, gpu_device):
     _check_backward(o, h, _dpix(1024, 1024), "config5-" + variant)
 
 
-FUZZ = [(seed, big) for seed in range(10) for big in (False,)] + [(100 + seed, True) for seed in range(4)]
+FUZZ = [(seed, False) for seed in range(16)] + [(100 + seed, True) for seed in range(8)]
 
 
 @pytest.mark.parametrize("seed,big", FUZZ)
