@@ -199,6 +199,11 @@ def handle(device_index: int, slot: int = 0):
     if h is None:
         import torch
 
+        if torch.cuda.is_current_stream_capturing():
+            # fr_create allocates (device + pinned memory, a stream, events): not allowed under capture, and trying
+            # would invalidate the caller's capture
+            raise RuntimeError(f"rasterizer handle (device {device_index}, slot {slot}) does not exist yet and cannot be "
+                               "created while a stream is being captured: run one eager frame through it first")
         with torch.cuda.device(device_index):
             out = C.c_void_p()
             rc = lib().fr_create(C.byref(out))

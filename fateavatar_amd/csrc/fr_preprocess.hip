@@ -620,6 +620,21 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     BinningView b = BinningView::make(binning, (size_t)cap, (size_t)T);
     const bool debug = prm.debug != 0;
     int rc;
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    // The handle's buffers (gradient accumulators, per-tile counters, key buckets) grow with the scene and the tile
+    // grid.  Growing means hipStreamSynchronize + hipFree + hipMalloc, none of which a capturing stream allows — and
+    // trying would invalidate the caller's capture.  Say so before touching the stream.
+    if (capturing) {
+        const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
+        const bool grows = (size_t)P > h->accum_rows || v.tpad > h->tile_counter_tiles || !h->key_buckets
+                           || (size_t)T > h->bucket_tiles || h->bucket_cap < need + need / 4;
+        if (grows)
+            return fail_msg(FR_ERR_UNSUPPORTED,
+                            "this frame needs handle buffers (re)allocated, which cannot happen while the stream is "
+                            "being captured: run one eager frame of this size on this handle first");
+    }
     // the backward's gradient accumulators live in the handle (zero between backward passes): size them here, where an
     // allocation is still allowed (a backward may be part of a captured graph)
     if ((rc = ensure_accum(h, (size_t)P, s))) return rc;
@@ -627,9 +642,6 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
 
     // frames of one handle share the per-tile counters: order this frame behind the previous one if that was
     // enqueued on a different stream (fr_common.hpp, fr_handle_impl::frame_done)
-    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap_status);
-    const bool capturing = cap_status != hipStreamCaptureStatusNone;
     if (!capturing && h->have_last && h->last_stream != s) FR_HIP(hipStreamWaitEvent(s, h->frame_done, 0));
 
     // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally

@@ -65,7 +65,8 @@ extern "C" {
  * one handle must not overlap on the host (one thread at a time); on the device, frames enqueued on one stream are
  * ordered by it and a frame on another stream first waits for the previous frame's event.  The handle's device memory
  * grows with the tile grid / Gaussian count / longest per-XCD tile sub-list (hipMalloc — not while the stream is being
- * captured into a hipGraph: run one eager frame of that size first). */
+ * captured into a hipGraph: run one eager frame of that size first; fr_forward on a capturing stream that would have
+ * to grow something returns FR_ERR_UNSUPPORTED before enqueuing anything, which leaves the capture valid). */
 typedef struct fr_handle fr_handle;
 
 /* Optional fused side outputs: per-Gaussian values the caller's step otherwise derives

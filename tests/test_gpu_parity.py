@@ -425,6 +425,58 @@ def test_graph_replay_survives_interleaved_eager_kernels(gpu_device):
     assert util.rel_l2(pc.flat_grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-5
 
 
+def test_capturing_a_size_the_handle_has_not_seen_is_refused_cleanly(gpu_device):
+    """A handle grows its own buffers (accumulators, tile counters, key buckets) with the scene and the tile grid; that
+    needs hipMalloc/hipFree, which a capturing stream does not allow.  fr_forward says so BEFORE touching the stream
+    (FR_ERR_UNSUPPORTED), the capture ends without a HIP error, and after one eager frame the same capture works."""
+    import torch
+    from fateavatar_amd import rasterizer
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render
+    s = scenes.head_scene(P=6000, res=200, sh_degree=1, seed=3)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 1, gpu_device, fused_activations=True)
+    cam = TorchCamera(s.camera, gpu_device)
+    bg = torch.from_numpy(s.bg).to(gpu_device)
+    keep = torch.zeros(3, 200, 200, device=gpu_device)
+
+    def frame():
+        with torch.no_grad():
+            keep.copy_(render(cam, pc, bg)["render"])
+
+    with rasterizer.handle_slot(0):   # sizes the torch-side buffers and the capacity hint
+        frame()
+        torch.cuda.synchronize()
+        want = keep.clone()
+    side = torch.cuda.Stream()
+    with rasterizer.handle_slot(12), rasterizer.no_wait():   # a handle that does not exist yet: the wrapper refuses
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="eager frame"):
+            with torch.cuda.graph(graph, stream=side):
+                frame()
+    from fateavatar_amd import _lib
+    _lib.handle(0, 11)
+    with rasterizer.handle_slot(11), rasterizer.no_wait():   # one that exists but has not seen a frame: fr_forward does
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="eager frame of this size"):
+            with torch.cuda.graph(graph, stream=side):
+                frame()
+        torch.cuda.synchronize()   # (no sticky HIP error)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            frame()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(keep, want)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            frame()
+        keep.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(keep, want)
+        assert not rasterizer.read_counts(0).overflow
+
+
 def test_fused_adam_matches_torch_adam(gpu_device):
     """fr_adam_step over a flat buffer with per-segment (and two-rate) learning rates == torch.optim.Adam over the
     equivalent parameter groups (train/optim.py:11-37), step by step, including the bias correction."""
