@@ -125,7 +125,8 @@ class _View:
         self.dL_dpix = (g / (3 * H * W)).to(eng.dev)
         self.stream = None            # (HipEngine picks streams that really overlap: fateavatar_amd/streams.py)
         self.done = torch.cuda.Event()
-        self.graphs = [None] * len(self.pcs)
+        self.graphs = [None] * len(self.pcs)       # the frame that OVERWRITES the set's gradient buffers
+        self.graphs_add = [None] * len(self.pcs)   # (N > 1, rounds > 1) the frame that ADDS to them
         self.graph = None
 
 
@@ -142,8 +143,9 @@ class HipEngine:
         self.rasterizer, self.local, self.args, self.rank = rasterizer, local, args, rank
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
-        self.exchanging = world > 1   # the views' completion events and second buffer sets are only needed by the exchange
-        self.step_no = 0
+        self.exchanging = world > 1 or args.exchange_at_1   # the views' completion events and second buffer sets are only needed by the exchange
+        self.rounds = max(1, args.rounds)
+        self.round_no = 0
         self.auto = args.in_flight <= 0          # pick the number of views in flight by a short calibration run
         K = self.K = 3 if self.auto else args.in_flight
         # replicated Gaussians (same seed everywhere), view index (rank * K + k) of world * K views around the head
@@ -158,10 +160,13 @@ class HipEngine:
         self.graph = None
         self.grads_read = [None, None]   # events: the exchange has read the gradient buffers of set 0 / 1
 
-    def frame(self, v=None, which=0):
+    def frame(self, v=None, which=0, add=False):
         v = v or self.views[0]
         pc = v.pcs[which]
-        pc.begin_step()                            # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        if not add:
+            pc.begin_step()                        # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        # (add: the gradients of the previous round are kept, and the backward kernel adds this frame's to them in
+        # place — FR_FLAG_ACCUMULATE through the parameters' gradient slots: local gradient accumulation)
         out = self._render(v.cam, pc, v.bg)                        # activations + HIP rasterizer forward
         torch.autograd.backward(out["render"], grad_tensors=v.dL_dpix)  # HIP rasterizer backward (+ activations)
 
@@ -186,6 +191,13 @@ class HipEngine:
                             # thread_local: the RCCL watchdog thread of an N > 1 run must not trip the capture
                             with torch.cuda.graph(v.graphs[which], stream=v.stream, capture_error_mode="thread_local"):
                                 self.frame(v, which)
+                            if self.exchanging and self.rounds > 1:
+                                with torch.cuda.stream(v.stream):
+                                    self.frame(v, which, add=True)
+                                torch.cuda.synchronize()
+                                v.graphs_add[which] = torch.cuda.CUDAGraph()
+                                with torch.cuda.graph(v.graphs_add[which], stream=v.stream, capture_error_mode="thread_local"):
+                                    self.frame(v, which, add=True)
                     torch.cuda.synchronize()
             v.graph = v.graphs[0]
         self.graph = self.views[0].graph
@@ -215,22 +227,27 @@ class HipEngine:
         self.calibration = {str(k + 1): round(float(x) / world, 1) for k, x in enumerate(r.tolist())}
 
     def enqueue_frame(self, views=None, count=True):
-        """One step: every view's render + backward, each on its own stream."""
-        which = self.step_no & 1 if (self.exchanging and count) else 0
+        """One ROUND: every view's render + backward, each on its own stream.  N > 1: a step is `rounds` rounds on one
+        set of gradient buffers (the first overwrites them, the others add), and steps alternate between the two sets."""
+        which, add, last = 0, False, False
+        if self.exchanging and count:
+            step, r = divmod(self.round_no, self.rounds)
+            which, add, last = step & 1, r > 0, r == self.rounds - 1
         self.which = which
         for v in (views or self.views):
             with torch.cuda.stream(v.stream):
-                if self.grads_read[which] is not None:
+                if not add and self.grads_read[which] is not None:
                     v.stream.wait_event(self.grads_read[which])   # (N > 1) the exchange of two steps ago read this set
-                if v.graphs[which] is not None:
-                    v.graphs[which].replay()
+                g = v.graphs_add[which] if add else v.graphs[which]
+                if g is not None:
+                    g.replay()
                 else:
                     with self.rasterizer.handle_slot(v.k):
-                        self.frame(v, which)
-                if self.exchanging:
+                        self.frame(v, which, add)
+                if last:                                   # the exchange waits for the step's last round only
                     v.done.record(v.stream)
         if count:
-            self.step_no += 1
+            self.round_no += 1
 
     def flat_grads(self):
         """Gradient buffers of the step enqueued last."""
@@ -279,6 +296,7 @@ class StubEngine:
     def __init__(self, args, rank, world, local):
         self.dev = torch.device("cpu")
         self.rank, self.k = rank, 0
+        self.rounds = max(1, args.rounds)
         self.K = max(1, args.in_flight)
         self.calibration = None
         self.grads = [torch.zeros(1 << 12) for _ in range(self.K)]
@@ -292,8 +310,9 @@ class StubEngine:
         pass
 
     def enqueue_frame(self, views=None, count=True):
-        for j, g in enumerate(self.grads):
-            g.copy_(torch.arange(g.numel(), dtype=torch.float32) * 1e-3 + (self.rank * self.K + j + 1) * (self.k + 1))
+        for j, g in enumerate(self.grads):   # like the engine: a step's first round overwrites, the others add
+            x = torch.arange(g.numel(), dtype=torch.float32) * 1e-3 + (self.rank * self.K + j + 1) * (self.k + 1)
+            g.copy_(x) if self.k % self.rounds == 0 else g.add_(x)
         self.k += 1
 
     def flat_grads(self):
@@ -317,30 +336,34 @@ class GradExchange:
     step's views are summed (behind their backward passes) into one of two exchange buffers and reduced there
     asynchronously; a buffer is reused two steps later, after waiting for its collective."""
 
-    def __init__(self, like: torch.Tensor):
+    def __init__(self, like: torch.Tensor, rounds: int = 1):
         self.bufs = [torch.empty_like(like), torch.empty_like(like)]
         self.works = [None, None]
         self.k = 0
+        self.rounds = max(1, int(rounds))   # every view's buffer holds the sum over the step's rounds
 
     def submit(self, eng):
+        """After the step's last round: mean of the views' accumulated gradients into an exchange buffer, all-reduce."""
         from fateavatar_amd import dp
         i = self.k & 1
         if self.works[i] is not None:
             self.works[i].wait()
         eng.join()                                   # the step's views have written their gradients
         grads = eng.flat_grads()
-        if len(grads) == 1:
-            self.bufs[i].copy_(grads[0], non_blocking=True)
-        elif self.bufs[i].is_cuda:                   # mean over the local views (one pass); the collective averages over the ranks
+        buf = self.bufs[i]
+        scale = 1.0 / (len(grads) * self.rounds)     # mean over the rank's frames of the step; the collective averages over the ranks
+        if len(grads) == 1 and scale == 1.0:
+            buf.copy_(grads[0], non_blocking=True)
+        elif buf.is_cuda:                            # one pass
             from fateavatar_amd.loss import scaled_sum
-            scaled_sum(self.bufs[i], grads, 1.0 / len(grads))
+            scaled_sum(buf, grads, scale)
         else:                                        # (the CPU stub of tests/test_bench_dp.py)
-            w = 1.0 / len(grads)
-            torch.mul(grads[0], w, out=self.bufs[i])
+            acc = grads[0].clone()
             for g in grads[1:]:
-                self.bufs[i].add_(g, alpha=w)
+                acc.add_(g)
+            torch.mul(acc, scale, out=buf)
         eng.mark_grads_read()                        # the step after next may overwrite these gradient buffers
-        self.works[i] = dp.allreduce_mean_async(self.bufs[i])
+        self.works[i] = dp.allreduce_mean_async(buf)
         self.k += 1
 
     def drain(self):
@@ -351,6 +374,15 @@ class GradExchange:
 
     def latest(self) -> torch.Tensor:
         return self.bufs[(self.k - 1) & 1]
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def _free_port() -> int:
@@ -372,6 +404,13 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="views of a step that run concurrently on one GPU: 1 = one frame at a time (as in round 1), 0 = "
                          "calibrate (1, 2 or 3, whichever renders most frames per second here)")
+    ap.add_argument("--rounds", type=int, default=4,
+                    help="rounds of views per step: a step renders rounds x (views in flight) frames per GPU and, on N > 1 "
+                         "GPUs, exchanges their mean gradient ONCE (local gradient accumulation in the backward kernel, "
+                         "the usual way to keep a 23.6 MB all-reduce behind the rendering).  The same at every N")
+    ap.add_argument("--exchange-at-1", action="store_true",
+                    help="diagnostic: run N = 1 with the N > 1 machinery (second gradient-buffer sets, per-round fold, "
+                         "all-reduce on a one-rank RCCL group): what the exchange costs the rendering apart from the wire")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
@@ -392,6 +431,8 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
 
     from fateavatar_amd import dp
+    if args.exchange_at_1:
+        os.environ["FR_DP_GROUP_OF_ONE"] = "1"
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -401,10 +442,13 @@ def main():
     eng = (StubEngine if STUB else HipEngine)(args, rank, world, local)
     eng.prepare()
     eng.calibrate(world)
-    xchg = GradExchange(eng.flat_grads()[0]) if world > 1 else None
+    rounds = max(1, args.rounds)
+    exchanging = world > 1 or args.exchange_at_1
+    xchg = GradExchange(eng.flat_grads()[0], rounds) if exchanging else None
 
     def step():
-        eng.enqueue_frame()
+        for _ in range(rounds):
+            eng.enqueue_frame()
         if xchg is not None:
             xchg.submit(eng)
             if not args.overlap:
@@ -428,19 +472,19 @@ def main():
 
     # the same engine with ONE view in flight (what `value` measured until views overlapped): a reference point
     single = None
-    if not STUB and eng.K > 1 and world == 1:
+    if not STUB and eng.K > 1 and not exchanging:
         eng.sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps * rounds):
             eng.enqueue_frame(eng.views[:1])
         eng.sync()
-        single = {"value": round(args.steps / (time.perf_counter() - t1), 2), "unit": "frames/s", "frames_in_flight": 1}
+        single = {"value": round(args.steps * rounds / (time.perf_counter() - t1), 2), "unit": "frames/s", "frames_in_flight": 1}
 
     prof, counts = eng.finish()
 
     # ---- data-parallel record: who took part, what was exchanged, how long one exchange takes on its own
     dpinfo = None
-    if world > 1:
+    if exchanging:
         import torch.distributed as dist
         reduced = xchg.latest().clone()
         buf = torch.empty_like(reduced)
@@ -468,6 +512,7 @@ def main():
                   "num_rendered_per_rank": [int(t.item()) for t in allr], "allreduce_payload_bytes": payload,
                   "allreduce_us": round(ar_s * 1e6, 1),
                   "allreduce_busbw_GBps": round(2 * (world - 1) / world * payload / ar_s / 1e9, 1),
+                  "group_of_one": bool(args.exchange_at_1),
                   "overlap": bool(args.overlap),
                   "grad_checksum": float(reduced.double().abs().sum().item())}
 
@@ -477,7 +522,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        fps = world * eng.K * args.steps / elapsed
+        fps = world * eng.K * rounds * args.steps / elapsed
         H = W = args.res
         M = (args.sh_degree + 1) ** 2
         R = counts["num_rendered"]
@@ -525,13 +570,15 @@ def main():
             "config": {"workload": f"{cfg_name}: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={M}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
-                       "frames_per_step_per_gpu": eng.K,
+                       "frames_per_step_per_gpu": eng.K * rounds,
+                       "rounds_per_step": rounds,
                        "frames_in_flight_per_gpu": eng.K,
                        "in_flight_calibration_frames_per_s": eng.calibration,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
-                       "parallelism": f"dp{world} ({eng.K} view(s) per GPU and step, each on its own stream; flat-grad all-reduce"
-                                      + (", overlapped with the next frame)" if world > 1 and args.overlap else ")"),
+                       "parallelism": f"dp{world} ({rounds} round(s) of {eng.K} view(s) per GPU and step, each view on its own "
+                                      "stream; ONE flat-grad all-reduce of the step's mean gradient"
+                                      + (", overlapped with the next step's frames)" if world > 1 and args.overlap else ")"),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
@@ -541,9 +588,17 @@ def main():
                 "algorithmic_bytes_per_frame": int(sum(sb.values())), "achieved": round(sum(sb.values()) * fps / world / 1e9, 1),
                 "unit": "GB/s per GPU", "frac": round(sum(sb.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 4)}),
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
+    # RCCL prints a version banner through C stdio, which (into a pipe) is flushed only at exit — behind the JSON line.
+    # Everything buffered goes out first, on every rank, so that the JSON line is the last line of the run.
+    _flush_c_stdio()
     if torch.distributed.is_initialized():
+        dp.barrier()
         torch.distributed.destroy_process_group()
+        _flush_c_stdio()
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ FR_ERR_HIP = 3
 FR_ERR_UNSUPPORTED = 4
 FR_FLAG_NO_WAIT = 1
 FR_FLAG_RAW_ACTIVATIONS = 2
+FR_FLAG_ACCUMULATE_SHIFT = 8   # fr_backward: bit (8 + k) = add into the k-th array of fr_grads
 
 _fp = C.c_void_p  # device pointers travel as integers
 

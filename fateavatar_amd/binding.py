@@ -90,7 +90,7 @@ class _Bind(torch.autograd.Function):
         def out(need, slot, shape):
             if not need:
                 return None
-            buf = slot.claim() if slot is not None else None   # first backward of the step writes the slot in place
+            buf = slot.claim()[0] if slot is not None else None   # first backward of the step writes the slot in place
             if buf is not None and buf.numel() == int(torch.Size(shape).numel()) and buf.is_contiguous():
                 return buf.view(shape)
             return torch.empty(shape, dtype=torch.float32, device=dev)

@@ -258,13 +258,14 @@ int launch_multi_copy(int n_seg, float* const* dst, const float* const* src, con
 // ---------------------------------------------------------------- scaled sum of up to four equally long arrays
 // dst = scale * (src[0] + ... + src[n-1]): the mean of the gradient buffers of the views a rank rendered in flight
 // together, written into the exchange buffer of the all-reduce in one pass (three PyTorch kernels otherwise: 142 MB of
-// traffic instead of 94 at 23.6 MB per buffer, on a GPU that is busy rendering the next step's frames).
+// traffic instead of 94 at 23.6 MB per buffer, on a GPU that is busy rendering the next step's frames).  dst may be one
+// of the sources (every element is read before it is written, by the same thread): dst += ... for local accumulation.
 struct SumArgs {
     int n;
     const float* src[FR_ADAM_MAX_GRADS];
 };
 
-__global__ void __launch_bounds__(256) k_scaled_sum(SumArgs a, float* __restrict__ dst, unsigned long long count, float scale)
+__global__ void __launch_bounds__(256) k_scaled_sum(SumArgs a, float* dst, unsigned long long count, float scale)
 {
     const unsigned long long n4 = count / 4, stride = (unsigned long long)gridDim.x * blockDim.x;
     const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -5,7 +5,8 @@
 //
 // Compiled with -ffp-contract=off and written in the reference's operation order (see
 // fr_preprocess.hip).  Every output row is written (zeros for culled Gaussians), so callers
-// need not pre-zero anything.
+// need not pre-zero anything — or, per array, ADDED to what the array holds (FR_FLAG_ACCUMULATE:
+// gradient accumulation over the frames of a batch without a second buffer and an add kernel).
 #include "fr_common.hpp"
 
 namespace fr {
@@ -33,11 +34,20 @@ struct PreBwdArgs {
     fr_grads out;
     float* grad_accum;  // optional (fr_aux): += ||dL_dmeans2D[:, :2]|| of visible Gaussians
     float* denom;       // optional (fr_aux): += 1 for visible Gaussians
+    uint32_t acc;       // bit k: ADD into the k-th array of fr_grads instead of overwriting it (FR_FLAG_ACCUMULATE)
 };
 
-__device__ __forceinline__ void store3(float* p, size_t i, float a, float b, float c)
+// bit positions of `acc` = position of the pointer in fr_grads
+enum { G_MEANS2D = 0, G_COLORS, G_OPACITY, G_MEANS3D, G_COV3D, G_SH, G_SCALES, G_ROTATIONS };
+
+// one gradient element: overwritten, or added to what the array holds (wave-uniform choice per array)
+__device__ __forceinline__ void put(float* p, float v, bool add) { *p = add ? *p + v : v; }
+
+__device__ __forceinline__ void store3(float* p, size_t i, float a, float b, float c, bool add)
 {
-    if (p) p[3 * i] = a, p[3 * i + 1] = b, p[3 * i + 2] = c;
+    if (!p) return;
+    if (add) a += p[3 * i], b += p[3 * i + 1], c += p[3 * i + 2];
+    p[3 * i] = a, p[3 * i + 1] = b, p[3 * i + 2] = c;
 }
 
 // Everything for ONE Gaussian.  `row` (LDS, may be null) holds this Gaussian's SH coefficients on entry and
@@ -47,21 +57,34 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
 {
     const size_t i = (size_t)idx;
     const int Mc = a.M;
-    if (!(radius > 0)) {
+    const auto adds = [&](int k) { return ((a.acc >> k) & 1u) != 0u; };
+    if (!(radius > 0)) {   // no gradient: zeros where the arrays are overwritten, nothing where they accumulate
         if (row)
             for (int k = 0; k < Mc * 3; k++) row[k] = 0.f;
-        store3(a.out.dL_dmeans2D, i, 0.f, 0.f, 0.f);
-        store3(a.out.dL_dcolors, i, 0.f, 0.f, 0.f);
-        if (a.out.dL_dopacity) a.out.dL_dopacity[i] = 0.f;
-        store3(a.out.dL_dmeans3D, i, 0.f, 0.f, 0.f);
-        if (a.out.dL_dcov3D)
+        if (!adds(G_MEANS2D)) store3(a.out.dL_dmeans2D, i, 0.f, 0.f, 0.f, false);
+        if (!adds(G_COLORS)) store3(a.out.dL_dcolors, i, 0.f, 0.f, 0.f, false);
+        if (a.out.dL_dopacity && !adds(G_OPACITY)) a.out.dL_dopacity[i] = 0.f;
+        if (!adds(G_MEANS3D)) store3(a.out.dL_dmeans3D, i, 0.f, 0.f, 0.f, false);
+        if (a.out.dL_dcov3D && !adds(G_COV3D))
             for (int k = 0; k < 6; k++) a.out.dL_dcov3D[6 * i + k] = 0.f;
-        if (a.out.dL_dsh && !row)
+        if (a.out.dL_dsh && !row && !adds(G_SH))
             for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
-        store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f);
-        if (a.out.dL_drotations)
+        if (!adds(G_SCALES)) store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f, false);
+        if (a.out.dL_drotations && !adds(G_ROTATIONS))
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
         return;
+    }
+    // accumulating arrays: what they hold is requested NOW, so that the round trip runs under the arithmetic below
+    // (a load next to its store would sit behind the stores in front of it)
+    float old_m3[3] = {0.f, 0.f, 0.f}, old_sc[3] = {0.f, 0.f, 0.f}, old_q[4] = {0.f, 0.f, 0.f, 0.f}, old_op = 0.f;
+    if (a.acc) {
+        if (adds(G_MEANS3D) && a.out.dL_dmeans3D)
+            for (int k = 0; k < 3; k++) old_m3[k] = a.out.dL_dmeans3D[3 * i + k];
+        if (adds(G_SCALES) && a.out.dL_dscales)
+            for (int k = 0; k < 3; k++) old_sc[k] = a.out.dL_dscales[3 * i + k];
+        if (adds(G_ROTATIONS) && a.out.dL_drotations)
+            for (int k = 0; k < 4; k++) old_q[k] = a.out.dL_drotations[4 * i + k];
+        if (adds(G_OPACITY) && a.out.dL_dopacity) old_op = a.out.dL_dopacity[i];
     }
     // read the accumulator row and leave it zeroed for the next backward (the rows are zero between backward
     // passes: no zeroing launch, and no zeroing writes in the forward)
@@ -82,13 +105,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
     const float dcx = -0.5f * acc[ACC_CA], dcy = -0.5f * acc[ACC_CB], dcz = -0.5f * acc[ACC_CC];
     const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
-    store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f);
+    store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f, adds(G_MEANS2D));
     // fused _add_densification_stats (model/fateavatar.py:734-737); this branch is radii > 0
     if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
     if (a.denom) a.denom[i] += 1.0f;
-    store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2]);
+    store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2], adds(G_COLORS));
     // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
-    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = a.raw ? dop * co.w * (1.0f - co.w) : dop;
+    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = old_op + (a.raw ? dop * co.w * (1.0f - co.w) : dop);
 
     const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     const float* vm = cam.view;
@@ -138,7 +161,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
     }
     if (a.out.dL_dcov3D)
-        for (int k = 0; k < 6; k++) a.out.dL_dcov3D[6 * i + k] = dcov[k];
+        for (int k = 0; k < 6; k++) put(a.out.dL_dcov3D + 6 * i + k, dcov[k], adds(G_COV3D));
 
     // dL/dT (upper 2x3), backward.cu:237-248.  Vrk[c][r] is symmetric.
     float dT0[3], dT1[3];
@@ -184,6 +207,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         // registers before it writes anything
         const float* sh_src = row ? row : a.shs + i * Mc * 3;
         float* dsh = row ? row : (a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr);
+        const bool dsh_adds = !row && adds(G_SH);   // (a staged row is added to the array by unstage_rows)
         const uint8_t cl = a.g.clamped[idx];
         float dRGB[3];
         for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1) ? 0 : 1);
@@ -193,7 +217,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
 #define SH(k, c) shc[(k)]
 #define DSH(k, c, v_)                    \
     do {                                 \
-        if (dsh) dsh[(k) * 3 + (c)] = (v_); \
+        if (dsh) put(dsh + (k) * 3 + (c), (v_), dsh_adds); \
     } while (0)
         for (int c = 0; c < 3; c++) {
             float shc[16];
@@ -243,7 +267,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         }
         // coefficients above the active degree receive no gradient (the reference leaves its
         // zero-initialised rows untouched)
-        if (dsh)
+        if (dsh && !dsh_adds)
             for (int k = used; k < Mc; k++) dsh[k * 3] = 0.f, dsh[k * 3 + 1] = 0.f, dsh[k * 3 + 2] = 0.f;
 #undef SH
 #undef DSH
@@ -256,10 +280,10 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         dmx += ((+sum2 - dox * dox) * ddx - doy * dox * ddy - doz * dox * ddz) * invsum32;
         dmy += (-dox * doy * ddx + (sum2 - doy * doy) * ddy - doz * doy * ddz) * invsum32;
         dmz += (-dox * doz * ddx - doy * doz * ddy + (sum2 - doz * doz) * ddz) * invsum32;
-    } else if (a.out.dL_dsh && !row) {
+    } else if (a.out.dL_dsh && !row && !adds(G_SH)) {
         for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
     }
-    store3(a.out.dL_dmeans3D, i, dmx, dmy, dmz);
+    store3(a.out.dL_dmeans3D, i, old_m3[0] + dmx, old_m3[1] + dmy, old_m3[2] + dmz, false);
 
     // ---------------- Sigma3D -> scale, quaternion (backward.cu:278-341)
     if (a.scales) {
@@ -294,12 +318,12 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         const float dsy = Rc[0][1] * dMt[1][0] + Rc[1][1] * dMt[1][1] + Rc[2][1] * dMt[1][2];
         const float dsz = Rc[0][2] * dMt[2][0] + Rc[1][2] * dMt[2][1] + Rc[2][2] * dMt[2][2];
         // raw-parameter mode: d exp = the activated scale
-        if (a.raw) store3(a.out.dL_dscales, i, dsx * sc[0], dsy * sc[1], dsz * sc[2]);
-        else store3(a.out.dL_dscales, i, dsx, dsy, dsz);
+        if (a.raw) store3(a.out.dL_dscales, i, old_sc[0] + dsx * sc[0], old_sc[1] + dsy * sc[1], old_sc[2] + dsz * sc[2], false);
+        else store3(a.out.dL_dscales, i, old_sc[0] + dsx, old_sc[1] + dsy, old_sc[2] + dsz, false);
         for (int w = 0; w < 3; w++) dMt[0][w] *= s[0], dMt[1][w] *= s[1], dMt[2][w] *= s[2];
 #define Dm(c_, r_) dMt[c_][r_]
         if (a.out.dL_drotations) {
-            float* dq = a.out.dL_drotations + 4 * i;
+            float dq[4];
             dq[0] = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
             dq[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
             dq[2] = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
@@ -312,11 +336,12 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
                 dq[2] = (dq[2] - y * dot) * rot_inv;
                 dq[3] = (dq[3] - z * dot) * rot_inv;
             }
+            for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = old_q[k] + dq[k];
         }
 #undef Dm
     } else {
-        store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f);
-        if (a.out.dL_drotations)
+        if (!adds(G_SCALES)) store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f, false);
+        if (a.out.dL_drotations && !adds(G_ROTATIONS))
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
     }
 }
@@ -358,23 +383,53 @@ __device__ __forceinline__ void stage_rows(float* dst, int stride, const float* 
         }
     }
 }
-__device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane)
+template <bool ADD>
+__device__ __forceinline__ void unstage_rows_t(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane)
 {
     const int total = rows * row_len;
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
-    for (int c = lane * 4; c < total; c += 64 * 4) {
-        float v[4];
+    // ADD: the array's old values are requested kBatch 16-byte loads at a time before the first one is used
+    constexpr int kBatch = ADD ? 6 : 1;
+    for (int base = lane * 4; base < total; base += 64 * 4 * kBatch) {
+        float4 o[kBatch];
+        if (ADD) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = c + k;
-            const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
-            v[k] = (e < total) ? src[r * stride + (e - r * row_len)] : 0.f;
+            for (int u = 0; u < kBatch; u++) {
+                const int c = base + u * 64 * 4;
+                o[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c + 3 < total) {
+                    o[u] = *reinterpret_cast<const float4*>(dst + c);
+                } else {
+                    if (c < total) o[u].x = dst[c];
+                    if (c + 1 < total) o[u].y = dst[c + 1];
+                    if (c + 2 < total) o[u].z = dst[c + 2];
+                }
+            }
         }
-        if (c + 3 < total) *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
-        else
-            for (int k = 0; k < 4; k++)
-                if (c + k < total) dst[c + k] = v[k];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const int c = base + u * 64 * 4;
+            if (c >= total) break;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = c + k;
+                const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
+                v[k] = (e < total) ? src[r * stride + (e - r * row_len)] : 0.f;
+            }
+            if (ADD) v[0] += o[u].x, v[1] += o[u].y, v[2] += o[u].z, v[3] += o[u].w;
+            if (c + 3 < total) *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int k = 0; k < 4; k++)
+                    if (c + k < total) dst[c + k] = v[k];
+        }
     }
+}
+__device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane,
+                                             bool add)
+{
+    if (add) unstage_rows_t<true>(dst, src, stride, rows, row_len, lane);
+    else unstage_rows_t<false>(dst, src, stride, rows, row_len, lane);
 }
 
 #ifndef FR_PREBWD_WAVES
@@ -399,7 +454,7 @@ __global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd(PreBwdArgs
     __syncthreads();
     if (idx < a.P) preprocess_bwd_one(a, cam, radius, idx, staged ? w_rows + lane * stride : nullptr);
     __syncthreads();
-    if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane);
+    if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane, ((a.acc >> G_SH) & 1u) != 0u);
 }
 
 int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
@@ -434,6 +489,7 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     a.radii = radii, a.g = g, a.out = gr;
     a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
     a.denom = prm.aux ? prm.aux->denom : nullptr;
+    a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
     {
         StageScope sc(h, ST_PREPROCESS_BWD, s);
         const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)kPreBwdWaves * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;

@@ -23,7 +23,8 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # FR_DP_GROUP_OF_ONE=1: a one-rank process group, so that the N > 1 machinery can be run on the REAL backend on one GPU
+    if (world > 1 or os.environ.get("FR_DP_GROUP_OF_ONE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

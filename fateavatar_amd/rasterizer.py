@@ -116,8 +116,8 @@ def check_async_overflow(device_index: int = 0) -> bool:
 
 
 def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw=False,
-            aux=None) -> _lib.fr_params:
-    flags = (_lib.FR_FLAG_NO_WAIT if _no_wait else 0) | (_lib.FR_FLAG_RAW_ACTIVATIONS if raw else 0)
+            aux=None, extra_flags=0) -> _lib.fr_params:
+    flags = (_lib.FR_FLAG_NO_WAIT if _no_wait else 0) | (_lib.FR_FLAG_RAW_ACTIVATIONS if raw else 0) | int(extra_flags)
     prm = _lib.fr_params(int(P), int(degree), int(M), int(W), int(H), float(tan_fovx), float(tan_fovy),
                          float(scale_modifier), int(bool(prefiltered)), int(bool(debug)), flags)
     if aux is not None:
@@ -196,12 +196,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                  geomBuffer, R, binningBuffer, imageBuffer, debug, _want=None, _out=None, _raw=False,
-                                 _stats=None):
+                                 _stats=None, _accumulate=()):
     """`_C.rasterize_gaussians_backward` (rasterize_points.cu:117-196).
 
     Returns (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
     dL_dscales[P,3], dL_drotations[P,4]).  `_stats=(xyz_gradient_accum[P,1], denom[P,1])` (extension): the kernel
-    also does `_add_densification_stats` (model/fateavatar.py:734-737) for the Gaussians with radii > 0."""
+    also does `_add_densification_stats` (model/fateavatar.py:734-737) for the Gaussians with radii > 0.
+    `_accumulate` (extension): names of `_out` buffers the frame's gradient is ADDED to (FR_FLAG_ACCUMULATE)."""
     dev = _dev_index(means3D)
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -209,8 +210,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     opts = dict(device=means3D.device, dtype=torch.float32)
     shapes = dict(dL_dmeans2D=(P, 3), dL_dcolors=(P, NUM_CHANNELS), dL_dopacity=(P, 1), dL_dmeans3D=(P, 3),
                   dL_dcov3D=(P, 6), dL_dsh=(P, M, 3), dL_dscales=(P, 3), dL_drotations=(P, 4))
+    names = tuple(shapes)
+    for k in _accumulate:
+        if not (_out and _out.get(k) is not None):
+            raise RuntimeError(f"rasterize_gaussians_backward: cannot accumulate into {k}: no buffer was given for it")
     if P == 0:
-        return tuple(torch.zeros(s, **opts) for s in shapes.values())
+        return tuple((_out[k] if k in _accumulate else torch.zeros(s, **opts)) for k, s in shapes.items())
+    acc_flags = sum(1 << (_lib.FR_FLAG_ACCUMULATE_SHIFT + names.index(k)) for k in _accumulate)
     # the kernel writes every row of every array it is given, so uninitialised memory is fine
     g = {k: (torch.empty(s, **opts) if (_want is None or k in _want) else None) for k, s in shapes.items()}
     if _out:  # caller-provided gradient buffers (e.g. views into a flat gradient buffer): written in place
@@ -230,7 +236,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     L = _lib.lib()
     h = _lib.handle(dev, _slot)
     aux = _aux(grad_accum=_stats[0], denom=_stats[1]) if _stats is not None else None
-    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw, aux)
+    prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw, aux, acc_flags)
     inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
     grads = _lib.fr_grads(*[_ptr(g[k]) for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D",
@@ -277,10 +283,12 @@ def cpu_deep_copy_tuple(input_tuple):
 class GradOut:
     """A gradient slot a parameter tensor can carry as `tensor._fr_grad_out`: the rasterizer's backward writes the
     parameter's gradient straight into `buf` instead of allocating a tensor that autograd then copies or adds.
-    That is only valid for ONE backward per accumulation: the kernel overwrites.  The slot is therefore claimed by the
-    first backward after the parameter's .grad was cleared and refused to every later one until it is cleared again
-    (forward() re-arms it when it sees `.grad is None`), so multi-frame batches — several renders from the same
-    parameters, one summed loss, as model/fateavatar.py:251-276 does — accumulate correctly."""
+    The kernel OVERWRITES for the first backward after the parameter's .grad was cleared (forward() re-arms the slot
+    when it sees `.grad is None`).  A later backward — several renders from the same parameters, as
+    model/fateavatar.py:251-276 does — is ADDED to the buffer by the kernel (FR_FLAG_ACCUMULATE) when that is provably
+    where the parameter's gradient lives (`param.grad` is a view of `buf`: gradients kept from an earlier backward);
+    otherwise (e.g. the frames of ONE backward pass of a summed loss, whose first gradient still sits in autograd's
+    input buffer, possibly already added to another producer's) it gets a fresh tensor that autograd adds."""
 
     def __init__(self, buf: torch.Tensor):
         self.buf = buf
@@ -295,11 +303,16 @@ class GradOut:
             slot.claimed = False   # gradients were cleared (zero_grad(set_to_none=True)): a new accumulation starts
         return slot
 
-    def claim(self):
-        if self.claimed:
-            return None
-        self.claimed = True
-        return self.buf
+    def claim(self, param=None):
+        """-> (buffer or None, accumulate)."""
+        if not self.claimed:
+            self.claimed = True
+            return self.buf, False
+        g = param.grad if (param is not None and param.is_leaf) else None
+        if (g is not None and g.data_ptr() == self.buf.data_ptr() and g.shape == self.buf.shape and g.is_contiguous()
+                and g.dtype == self.buf.dtype):
+            return self.buf, True
+        return None, False
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -341,9 +354,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         # optional extension: an input tensor may carry `_fr_grad_out`, a GradOut slot whose preallocated buffer
         # receives its gradient (zero-copy into e.g. a flat data-parallel gradient buffer)
         ctx.grad_slots = {"dL_dmeans3D": GradOut.of(means3D), "dL_dsh": GradOut.of(sh) if sh.numel() else None}
+        owners = {"dL_dmeans3D": means3D, "dL_dsh": sh}
         if ctx.raw:  # raw parameters reach the kernels directly: their gradients can be written in place too
             ctx.grad_slots.update(dL_dopacity=GradOut.of(opacities), dL_dscales=GradOut.of(scales),
                                   dL_drotations=GradOut.of(rotations))
+            owners.update(dL_dopacity=opacities, dL_dscales=scales, dL_drotations=rotations)
+        # (leaves only: a reference to a non-leaf input from its own grad_fn's context would be a cycle)
+        ctx.grad_owners = {k: t for k, t in owners.items() if ctx.grad_slots.get(k) is not None and t.is_leaf}
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -382,9 +399,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             # the FIRST backward of a step may write a gradient straight into its slot's buffer; any further backward
             # of the same step (several frames rendered from the same parameters) gets a fresh tensor, which autograd
             # then adds to the first
-            out = {k: slot.claim() for k, slot in ctx.grad_slots.items() if slot is not None}
+            claims = {k: slot.claim(ctx.grad_owners.get(k)) for k, slot in ctx.grad_slots.items() if slot is not None}
+            out = {k: c[0] for k, c in claims.items()}
+            added = tuple(k for k, c in claims.items() if c[1])
             with handle_slot(ctx.fr_slot):
-                grads = rasterize_gaussians_backward(*args, _out=out, _raw=ctx.raw, _stats=ctx.stats, _want=want)
+                grads = rasterize_gaussians_backward(*args, _out=out, _raw=ctx.raw, _stats=ctx.stats, _want=want,
+                                                     _accumulate=added)
+            if added:   # already in the parameter's .grad: nothing for autograd to add
+                names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                         "dL_drotations")
+                grads = tuple(None if n in added else g for n, g in zip(names, grads))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,

@@ -103,6 +103,16 @@ typedef struct fr_params {
  * dL_drotations.  Requires scales + rotations (not cov3D_precomp).  Pass the same flag to fr_backward. */
 #define FR_FLAG_RAW_ACTIVATIONS 2
 
+/* fr_backward only: FR_FLAG_ACCUMULATE(k) makes the k-th array of fr_grads (k = position of the pointer in the
+ * struct: 0 = dL_dmeans2D ... 7 = dL_drotations) ACCUMULATE: the frame's gradient is added to what the array holds
+ * instead of overwriting it (culled Gaussians then touch nothing).  A batch of frames rendered from the same
+ * parameters (the reference's batch loop, model/fateavatar.py:251-276, whose gradients autograd sums with one add
+ * kernel and one temporary per frame and parameter) accumulates in one buffer: first frame without the flag, the
+ * others with it.  FR_FLAG_ACCUMULATE_ALL = every array. */
+#define FR_FLAG_ACCUMULATE_SHIFT 8
+#define FR_FLAG_ACCUMULATE(k) (1 << (FR_FLAG_ACCUMULATE_SHIFT + (k)))
+#define FR_FLAG_ACCUMULATE_ALL (0xFF << FR_FLAG_ACCUMULATE_SHIFT)
+
 /* Device pointers.  NULL = the "empty tensor" of the reference glue
  * (rasterize_points.cu:94-103 passes data_ptr() of empty tensors; kernels branch on nullptr). */
 typedef struct fr_inputs {

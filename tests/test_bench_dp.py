@@ -23,24 +23,25 @@ def _run(extra, env_extra=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("overlap,K", [(True, 3), (False, 3), (True, 1)])
-def test_bench_spawns_two_ranks_and_averages_every_step(overlap, K):
+@pytest.mark.parametrize("overlap,K,R", [(True, 3, 1), (False, 3, 2), (True, 1, 1), (True, 2, 3), (True, 1, 4)])
+def test_bench_spawns_two_ranks_and_averages_every_step(overlap, K, R):
     steps, warm = 7, 3
-    j = _run(["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--in-flight", str(K)]
+    j = _run(["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--in-flight", str(K), "--rounds", str(R)]
              + ([] if overlap else ["--no-overlap"]))
     assert j["n_gpus"] == 2 and j["data"] == "stub" and j["steps"] == steps and j["scaling"] == "weak"
     d = j["dp"]
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["overlap"] is overlap
     assert d["num_rendered_per_rank"] == [1000, 1001]
     assert d["allreduce_payload_bytes"] == 4 * 4096 and d["allreduce_us"] > 0
-    # the stub gradient of (rank r, view v of its K, step k) is i * 1e-3 + (r * K + v + 1) * (k + 1); the mean over the
-    # K views of each rank and then over the two ranks of the LAST step (k = warm + steps - 1) must be what the
-    # exchange buffer holds: the mean of 1 .. 2K is (2K + 1) / 2
-    k = warm + steps - 1
-    want = sum(i * 1e-3 + (2 * K + 1) / 2 * (k + 1) for i in range(4096))
+    # the stub gradient of (rank r, view v of its K, round k counted from the start) is i * 1e-3 + (r * K + v + 1) * (k + 1).
+    # A step is R rounds; the exchange buffer must hold the mean over the R rounds of the LAST step, the K views of each
+    # rank and the two ranks: the mean of 1 .. 2K is (2K + 1) / 2, the mean of (k + 1) over the last step's rounds is
+    # (warm + steps - 1) * R + (R + 1) / 2
+    kmean = (warm + steps - 1) * R + (R + 1) / 2
+    want = sum(i * 1e-3 + (2 * K + 1) / 2 * kmean for i in range(4096))
     assert abs(d["grad_checksum"] - want) <= 1e-4 * want, (d["grad_checksum"], want)
-    assert j["config"]["frames_per_step_per_gpu"] == K
-    assert j["value"] > 0 and abs(j["value"] - 2 * K * steps / (j["ms_per_step"] * steps * 1e-3)) <= 0.02 * j["value"]
+    assert j["config"]["frames_per_step_per_gpu"] == K * R and j["config"]["rounds_per_step"] == R
+    assert j["value"] > 0 and abs(j["value"] - 2 * K * R * steps / (j["ms_per_step"] * steps * 1e-3)) <= 0.02 * j["value"]
 
 
 def test_bench_single_rank_stub_line_is_well_formed():

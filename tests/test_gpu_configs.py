@@ -256,3 +256,27 @@ def test_rccl_exchange_path_runs_on_this_gpu(gpu_device):
         "dist.destroy_process_group()\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
     assert "rccl-ok nccl" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_exchange_machinery_on_one_gpu_accumulates_rounds_in_place(gpu_device):
+    """`bench.py --exchange-at-1`: the N > 1 step (two gradient-buffer sets, rounds that ADD to the set in the backward
+    kernel, one fold and one RCCL all-reduce per step) on a one-rank group.  Every round renders the same views, so
+    the step's mean gradient must not depend on the number of rounds, and the JSON line must be the LAST line of the
+    run (RCCL prints a banner through C stdio)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = {}
+    for rounds in (1, 3):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--exchange-at-1", "--rounds", str(rounds), "--P", "20000",
+                            "--res", "256", "--steps", "6", "--warmup", "4", "--cpu-seconds", "0", "--in-flight", "2"],
+                           capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, MASTER_PORT=str(29541 + rounds)))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        last = r.stdout.strip().splitlines()[-1]
+        j = json.loads(last)
+        assert j["config"]["frames_per_step_per_gpu"] == 2 * rounds and j["dp"]["group_of_one"] and j["dp"]["backend"] == "nccl"
+        sums[rounds] = j["dp"]["grad_checksum"]
+    assert sums[1] > 0 and abs(sums[3] - sums[1]) <= 2e-6 * sums[1], sums

@@ -742,12 +742,24 @@ def test_mesh_binding_options_and_degenerate_face(gpu_device):
     assert torch.allclose(rot.detach().cpu()[ok], o[1][ok], rtol=2e-5, atol=2e-6)
 
 
-def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device, fused, monkeypatch):
     """model/fateavatar.py:251-276 renders every frame of the batch first and back-propagates one summed loss
-    afterwards: two forwards in flight, then both backwards.  Gradients must equal the sum of the per-frame ones."""
+    afterwards: two forwards in flight, then both backwards.  Gradients must equal the sum of the per-frame ones.
+    One frame at a time with the gradients kept, the second backward is ADDED to the gradient buffers by the kernel
+    (FR_FLAG_ACCUMULATE) instead of going through a temporary and autograd's add."""
     import torch
+    from fateavatar_amd import rasterizer
     from fateavatar_amd.model import FlatGaussians, TorchCamera
     from fateavatar_amd.render import render
+    accumulated = []
+    inner = rasterizer.rasterize_gaussians_backward
+
+    def spy(*a, **k):
+        accumulated.append(tuple(sorted(k.get("_accumulate", ()))))
+        return inner(*a, **k)
+
+    monkeypatch.setattr(rasterizer, "rasterize_gaussians_backward", spy)
     P, res = 5000, 112
     sa = scenes.head_scene(P=P, res=res, sh_degree=2, seed=8, view=0, n_views=3, opacity=0.4)
     sb = scenes.head_scene(P=P, res=res, sh_degree=2, seed=8, view=1, n_views=3, opacity=0.4)
@@ -757,7 +769,7 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
     ws = [torch.from_numpy((rng.uniform(-1, 1, (3, res, res)) / res ** 2).astype(np.float32)).to(gpu_device) for _ in range(2)]
 
     def grads(order):
-        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device)
+        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device, fused_activations=fused)
         if order == "batched":
             outs = [render(c, pc, bg) for c in cams]                      # both forwards first
             (sum((o["render"] * w).sum() for o, w in zip(outs, ws))).backward()
@@ -771,11 +783,15 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device):
         return {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}, vs
 
     ga, va = grads("batched")
+    assert accumulated == [(), ()]
+    del accumulated[:]
     gb, vb = grads("sequential")
+    in_place = ("dL_dmeans3D", "dL_dsh") if not fused else ("dL_dmeans3D", "dL_dopacity", "dL_drotations", "dL_dscales", "dL_dsh")
+    assert accumulated == [(), tuple(sorted(in_place))], accumulated
     # the truth: each frame alone, from its own copy of the parameters, added up
     want = None
     for c, w in zip(cams, ws):
-        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device)
+        pc = FlatGaussians(sa.means3D, sa.shs, sa.opacities, sa.scales, sa.rotations, 2, gpu_device, fused_activations=fused)
         (render(c, pc, bg)["render"] * w).sum().backward()
         g1 = {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}
         want = g1 if want is None else {n: want[n] + g1[n] for n in want}
@@ -982,3 +998,47 @@ def test_non_finite_gaussians_are_dropped_not_propagated(gpu_device):
         assert np.isfinite(g[k]).all(), k
         assert np.abs(g[k][bad]).max() == 0, k
         assert util.rel_l2(g[k][~bad], gc[k]) < 1e-5, k
+
+
+def test_backward_accumulates_into_the_arrays_it_is_told_to(gpu_device):
+    """FR_FLAG_ACCUMULATE(k): the k-th gradient array receives old + gradient (the same fp32 add torch does), culled
+    Gaussians leave it untouched, and arrays without the flag are overwritten as always."""
+    import torch
+    from fateavatar_amd import rasterizer as R
+    s = scenes.head_scene(P=3000, res=96, sh_degree=3, seed=12, opacity=0.5)
+    m = s.means3D.copy()
+    m[::7] += 100.0          # out of the frustum: culled
+    dev = gpu_device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    cam = s.camera
+    means, shs, op, sc, rot = t(m), t(s.shs), t(s.opacities), t(s.scales), t(s.rotations)
+    bg = t(s.bg)
+    empty = torch.empty(0, device=dev)
+    view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
+    fw = R.rasterize_gaussians(bg, means, empty, op, sc, rot, 1.0, empty, view, proj, cam.tanfovx, cam.tanfovy, 96, 96, shs, 3,
+                               campos, False, False)
+    num_rendered, color, radii, geom, binning, img = fw
+    assert int((radii == 0).sum()) >= 3000 // 7
+    g = t(np.random.default_rng(0).uniform(-1, 1, (3, 96, 96)) / 96 ** 2)
+    args = (bg, means, radii, empty, sc, rot, 1.0, empty, view, proj, cam.tanfovx, cam.tanfovy, g, shs, 3, campos, geom,
+            num_rendered, binning, img, False)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    plain = dict(zip(names, R.rasterize_gaussians_backward(*args)))
+    gen = torch.Generator().manual_seed(5)
+    for added in (names, ("dL_dsh", "dL_dopacity"), ("dL_dmeans3D",)):
+        old = {k: torch.randn(plain[k].shape, generator=gen).to(dev) * float(plain[k].abs().max()) for k in names}
+        out = {k: old[k].clone() for k in names}
+        got = dict(zip(names, R.rasterize_gaussians_backward(*args, _out=out, _accumulate=added)))
+        for k in names:
+            assert got[k].data_ptr() == out[k].data_ptr()
+            want = old[k] + plain[k] if k in added else plain[k]
+            # (two backward passes differ in the last bits: the blend backward adds with atomics)
+            tol = 2e-6 * max(float(plain[k].abs().max()), 1e-30)
+            assert float((got[k] - want).abs().max()) <= tol, (added, k, float((got[k] - want).abs().max()), tol)
+            culled = (radii == 0)
+            if k in added:
+                assert torch.equal(got[k][culled], old[k][culled]), (added, k)
+            else:
+                assert float(got[k][culled].abs().max()) == 0.0, (added, k)
+    with pytest.raises(RuntimeError):
+        R.rasterize_gaussians_backward(*args, _accumulate=("dL_dsh",))
