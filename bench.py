@@ -165,6 +165,8 @@ class HipEngine:
         pc = v.pcs[which]
         if not add:
             pc.begin_step()                        # grads set to None: backward assigns (zero_grad(set_to_none=True))
+        else:
+            pc.accumulate_into_kept_grads()
         # (add: the gradients of the previous round are kept, and the backward kernel adds this frame's to them in
         # place — FR_FLAG_ACCUMULATE through the parameters' gradient slots: local gradient accumulation)
         out = self._render(v.cam, pc, v.bg)                        # activations + HIP rasterizer forward

@@ -140,6 +140,17 @@ class FlatGaussians(torch.nn.Module):
         train/iteration.py:49): the next backward ASSIGNS instead of accumulating."""
         for name, _ in self.FIELDS:
             getattr(self, name).grad = None
+        self.accumulate_into_kept_grads(False)
+
+    def accumulate_into_kept_grads(self, on: bool = True) -> None:
+        """Gradient accumulation over several `.backward()` calls without `begin_step()` in between (one frame at a
+        time, gradients kept): with `on`, the rasterizer's backward ADDS each further frame's gradients to the flat
+        gradient buffer inside its kernel (FR_FLAG_ACCUMULATE; rasterizer.GradOut) instead of handing autograd a
+        temporary to add.  Only for `.backward()`; `begin_step()` switches it off again."""
+        for name, _ in self.FIELDS:
+            slot = getattr(getattr(self, name), "_fr_grad_out", None)
+            if slot is not None:
+                slot.add_to_kept = bool(on)
 
     def collect_grads(self) -> torch.Tensor:
         """After backward: make `flat_grad` hold every parameter's gradient (xyz / features are already there;

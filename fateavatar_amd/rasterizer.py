@@ -284,15 +284,20 @@ class GradOut:
     """A gradient slot a parameter tensor can carry as `tensor._fr_grad_out`: the rasterizer's backward writes the
     parameter's gradient straight into `buf` instead of allocating a tensor that autograd then copies or adds.
     The kernel OVERWRITES for the first backward after the parameter's .grad was cleared (forward() re-arms the slot
-    when it sees `.grad is None`).  A later backward — several renders from the same parameters, as
-    model/fateavatar.py:251-276 does — is ADDED to the buffer by the kernel (FR_FLAG_ACCUMULATE) when that is provably
-    where the parameter's gradient lives (`param.grad` is a view of `buf`: gradients kept from an earlier backward);
-    otherwise (e.g. the frames of ONE backward pass of a summed loss, whose first gradient still sits in autograd's
-    input buffer, possibly already added to another producer's) it gets a fresh tensor that autograd adds."""
+    when it sees `.grad is None`); any further backward gets a fresh tensor, which autograd adds — several renders
+    from the same parameters, as model/fateavatar.py:251-276 does, accumulate correctly.
+
+    Opt-in (`add_to_kept = True`, what FlatGaussians.accumulate_into_kept_grads() sets): a further backward is ADDED
+    to the buffer by the kernel itself (FR_FLAG_ACCUMULATE) when that is provably where the parameter's gradient lives
+    (`param.grad` is a view of `buf`: the gradients of an earlier `.backward()` were kept), and autograd is handed
+    nothing for that parameter.  It is opt-in because the backward cannot tell `.backward()` from
+    `torch.autograd.grad()`, which must not touch `param.grad`; and it never applies to the frames of ONE backward
+    pass of a summed loss, whose first gradient still sits in autograd's input buffer (param.grad is None)."""
 
     def __init__(self, buf: torch.Tensor):
         self.buf = buf
         self.claimed = False
+        self.add_to_kept = False
 
     @staticmethod
     def of(t):
@@ -308,7 +313,7 @@ class GradOut:
         if not self.claimed:
             self.claimed = True
             return self.buf, False
-        g = param.grad if (param is not None and param.is_leaf) else None
+        g = param.grad if (self.add_to_kept and param is not None and param.is_leaf) else None
         if (g is not None and g.data_ptr() == self.buf.data_ptr() and g.shape == self.buf.shape and g.is_contiguous()
                 and g.dtype == self.buf.dtype):
             return self.buf, True

@@ -780,12 +780,17 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device, fused, m
                 o = render(c, pc, bg)
                 (o["render"] * w).sum().backward()
                 vs.append(o["viewspace_points"].grad.clone())
+                if order == "sequential, added in the kernel":
+                    pc.accumulate_into_kept_grads()
         return {n: getattr(pc, n).grad.clone() for n, _ in pc.FIELDS}, vs
 
     ga, va = grads("batched")
     assert accumulated == [(), ()]
     del accumulated[:]
     gb, vb = grads("sequential")
+    assert accumulated == [(), ()]       # (not asked for: autograd adds, as it must for torch.autograd.grad users)
+    del accumulated[:]
+    gc, vc = grads("sequential, added in the kernel")
     in_place = ("dL_dmeans3D", "dL_dsh") if not fused else ("dL_dmeans3D", "dL_dopacity", "dL_drotations", "dL_dscales", "dL_dsh")
     assert accumulated == [(), tuple(sorted(in_place))], accumulated
     # the truth: each frame alone, from its own copy of the parameters, added up
@@ -798,6 +803,7 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device, fused, m
     for n in ga:
         assert util.rel_l2(ga[n].cpu().numpy(), want[n].cpu().numpy()) < 1e-5, ("batched", n)
         assert util.rel_l2(gb[n].cpu().numpy(), want[n].cpu().numpy()) < 1e-5, ("sequential", n)
+        assert util.rel_l2(gc[n].cpu().numpy(), want[n].cpu().numpy()) < 1e-5, ("sequential, added in the kernel", n)
     assert float(ga["_xyz"].abs().max()) > 0 and float(ga["_features"].abs().max()) > 0
     for x, y in zip(va, vb):
         assert util.rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-5
