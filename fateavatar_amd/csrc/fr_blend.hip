@@ -1533,6 +1533,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
         // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
         if ((uint32_t)__builtin_amdgcn_readlane((int)cum, 63) > dense_pairs) {
+#ifdef FR_BWD_STATS
+            if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[4], 1u);   // units in the all-pairs form
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bwd_unit_all_pairs(S.rec, (int)ui.m, lim, fx, fy, T, A, T_final, (bg0 * dpr + bg1 * dpg) + bg2 * dpb, dpr, dpg, dpb,
@@ -1564,6 +1567,14 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             // bound by the latency of its LDS round trips, not by issue slots); only the T / accum_rec recurrence is serial
             u64 Bg = Bp & range;
             const uint32_t nA = (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1;
+#ifdef FR_BWD_STATS   // development build (tools/diag/bwd_stats.sh): where do the kernel's iterations go?
+            if (lane == 0) {
+                DeviceCounts* dc = const_cast<DeviceCounts*>(counts);
+                atomicAdd(&dc->pair_hist[0], 1u);      // record ranges processed
+                atomicAdd(&dc->pair_hist[1], nA);      // phase A iterations (two records each)
+                atomicAdd(&dc->pair_hist[3], npairs);  // pair slots
+            }
+#endif
             for (uint32_t it = 0; it < nA; it++) {
                 bool act[2];
                 int j[2];
@@ -1609,6 +1620,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
             uint32_t slot = (cum - cnt) - slot0;
             const uint32_t nB = (wave_max_u32((uint32_t)__popcll(Mg)) + 1u) >> 1;
+#ifdef FR_BWD_STATS
+            if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[2], nB);   // phase B iterations (two pixels each)
+#endif
             for (uint32_t it = 0; it < nB; it++) {
                 float2 qw[2];
                 float4 dp[2];
