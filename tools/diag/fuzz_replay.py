@@ -56,3 +56,15 @@ if os.environ.get("FUZZ_BWD"):
         i = tuple(i)
         print("  id", i, "ref", ref[i], "got", got[i], "err/|ref|", err[i] / abs(ref[i]), "err/scale", err[i] / scale,
               "radius", o.radii[i[0]], "opacity", o.conic_opacity[i[0], 3])
+    # which rows carry the L2 error (flip-affected rows are excluded from the test's rel_l2)
+    from tests.test_gpu_parity import _flip_affected_gaussians
+    skip, n_flips = _flip_affected_gaussians(o, h)
+    e2 = ((got - ref) ** 2).sum(1)
+    keep = ~skip
+    print("flips", n_flips, "rows skipped", int(skip.sum()), "rel_l2 kept rows", util.rel_l2(got[keep], ref[keep]),
+          "rel_l2 all rows", util.rel_l2(got, ref))
+    order = np.argsort(-np.where(keep, e2, 0.0))[:10]
+    tot = float(e2[keep].sum())
+    for i in order:
+        print(f"  row {i}: share of kept err^2 {e2[i] / tot:.3f}  ref {ref[i]}  got {got[i]}  radius {o.radii[i]}  "
+              f"opacity {o.conic_opacity[i, 3]:.3f}  |ref|/scale {np.abs(ref[i]).max() / scale:.3g}")
