@@ -1489,7 +1489,6 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
     const TransposeConsts tc = transpose_consts(lane);
     const uint32_t nu = counts->num_units;
     const uint32_t wave_stride = gridDim.x * kWavesPerWG;
-    const u64 lt_mask = (1ull << lane) - 1ull;          // pixels in front of this lane's pixel in mask order
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     // which (record-in-septet, component) this lane flushes: lanes 0..62 = 7 records x 9 components
     const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;
@@ -1598,8 +1597,10 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                     const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
                     cd[k] = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;              // colour . dL_dpixel
                     ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity
-                    slot[k] = sb - slot0 + (uint32_t)__popc(__float_as_uint(q2.z) & (uint32_t)lt_mask) +
-                              (uint32_t)__popc(__float_as_uint(q2.w) & (uint32_t)(lt_mask >> 32));
+                    // rank of this pixel among the record's pixels: mask bits below this lane (v_mbcnt: popcount of
+                    // (operand & lanes-below-mine) + accumulator, two instructions for the 64 bits)
+                    slot[k] = __builtin_amdgcn_mbcnt_hi(__float_as_uint(q2.w),
+                                                        __builtin_amdgcn_mbcnt_lo(__float_as_uint(q2.z), sb - slot0));
                 }
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
