@@ -106,6 +106,7 @@ int fr_create(fr_handle** out)
     h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
     const char* bb = getenv("FR_BLEND_BWD");
     h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
+    h->batch_blend_bwd = bb && strcmp(bb, "batch") == 0;
     // the sparse backward reads the footprint masks the sparse forward leaves in the records
     if (h->dense_blend_fwd) h->dense_blend_bwd = true;
     const char* pf = getenv("FR_DENSE_PAIRS_FWD");

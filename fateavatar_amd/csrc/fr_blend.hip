@@ -1476,6 +1476,24 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
     gather_tile<false>(v, tile, u0, (n + kUnit - 1) / kUnit, g_out, unit_state, W, H, bg0, bg1, bg2, out_color, lane);
 }
 
+#ifdef FR_BWD_TRACE   // development build (tools/diag/bwd_trace.sh): per-wave time stamps of the backward's phases
+__device__ unsigned long long g_bwd_trace[8192 * 16];
+#define FR_STAMP(K) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#define FR_STAMPV(K, V) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = (unsigned long long)(V); } while (0)
+__device__ unsigned char g_bwd_lens[8192 * 128];   // per unit: 64 phase-A chain lengths, 64 phase-B walk lengths
+extern "C" int fr_debug_read_bwd_lens(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_lens), bytes < sizeof(g_bwd_lens) ? bytes : sizeof(g_bwd_lens));
+}
+extern "C" int fr_debug_read_bwd_trace(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_trace), bytes < sizeof(g_bwd_trace) ? bytes : sizeof(g_bwd_trace));
+}
+#else
+#define FR_STAMP(K) do { } while (0)
+#define FR_STAMPV(K, V) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                               void* binning, int W, int H, const float* __restrict__ bg,
                                                               const float* __restrict__ dL_dpix, float* __restrict__ accum,
@@ -1495,12 +1513,16 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
     // the same for the all-pairs form (bwd_unit_all_pairs): 4 records x 9 components after its reduce-scatter
     const int vv = bitrev6(lane);
     const int own_u = vv / 9, own_c = vv - own_u * 9;
+    FR_STAMP(0);
+    FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
         const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
         const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
         const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
+        FR_STAMP(1);
         // nothing at or behind the deepest contributor of any pixel of the tile can matter
         if (!__any(last > ui.base)) continue;
+        FR_STAMP(2);
 
         // ---- lane = record: stage the records; this lane keeps what phase B needs of its own
         const RecRegs rr = fetch_record(b.recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
@@ -1522,6 +1544,8 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         const int lim = (int)last - (int)ui.base;      // records [0, lim) of this unit can contribute to this pixel
         u64 Bp = ((u64)bt.y << 32) | bt.x;
         Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
+        FR_STAMP(3);
+        FR_STAMPV(9, __builtin_amdgcn_readlane((int)cum, 63));
 
         const float fx = (float)ui.px, fy = (float)ui.py;
         const float tfb = -T_final * ((bg0 * dpr + bg1 * dpg) + bg2 * dpb);   // -T_final * (bg . dL_dpixel)
@@ -1616,6 +1640,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
+            if (hi == (int)ui.m) { FR_STAMP(4); FR_STAMPV(10, nA); }
             // ---- phase B: lane = record, over its own pixels (two per iteration); its pairs are consecutive slots
             float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
@@ -1656,6 +1681,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (hi == (int)ui.m) { FR_STAMP(5); FR_STAMPV(11, nB); }
             // ---- flush: [record][9] through LDS (the pair slots are dead now), then 7 records x 9 components per atomic
             float* fl = reinterpret_cast<float*>(S.pair);
 #pragma unroll
@@ -1667,13 +1693,347 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                 if (lane < 63 && rj < hi) {
                     const uint32_t id = __float_as_uint(S.rec[rj * kRecQuads + 2].y);
                     const float val = fl[rj * 9 + fl_c];
+#if defined(FR_BWD_ABLATE) && FR_BWD_ABLATE == 1      // (timing experiments: plain stores instead of atomics / no flush at all)
+                    if (val != 0.f) accum[(size_t)id * kAccumStride + fl_c] = val;
+#elif defined(FR_BWD_ABLATE) && FR_BWD_ABLATE == 2
+                    if (val == 12345.f) accum[(size_t)id * kAccumStride + fl_c] = val;
+#else
                     if (val != 0.f) atomic_add_f32(accum + (size_t)id * kAccumStride + fl_c, val);
+#endif
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (hi == (int)ui.m) FR_STAMP(6);
             hi = lo;
         }
+        FR_STAMP(7);
+        FR_STAMPV(12, __builtin_amdgcn_s_memrealtime());
+    }
+}
+
+// ================================================================== batched sparse blend backward
+// k_unit_blend_bwd_sparse above gives every unit its own wave: in both of its walks the wave runs for as long as its
+// LONGEST lane (the pixel with the most records, the record with the most pixels), and at BASELINE config 2 the average
+// lane holds a pair in only 31 % / 33 % of those iterations.  Here a WORKGROUP takes four units together and deals the
+// 256 pixel chains (phase A) and the 256 record walks (phase B) out again BY LENGTH: a counting sort over the lengths
+// (one returning LDS atomic per task, a 65-bin scan) puts the 64 longest tasks into wave 0, the next 64 into wave 1,
+// and so on, so the lanes of a wave finish together and a wave's trip count is simply its first lane's.  The walks
+// themselves are those of the per-unit kernel (same expressions, same order per pixel and per record, so the sums only
+// differ by the order of the atomics); what changes is which lane walks what.
+//   LDS per workgroup (40.8 KB -> four workgroups = 16 waves per CU): the four units' records (48 B each; a unit's
+//   region later holds its 64 x 9 gradient sums), the (q, w) pair slots of the whole batch, per (unit, pixel) the walk
+//   set and the entry state, the two task orders and histograms.
+//   A batch whose units name more pairs than there are slots is processed in several groups of consecutive units; a
+//   unit above the all-pairs threshold is left to its own wave (bwd_unit_all_pairs) after the sparse ones.
+constexpr int kBU = 4;                  // units per workgroup (= waves per workgroup)
+constexpr int kBatchPairCap = 2400;     // (q, w) slots per workgroup
+
+struct BatchLds {
+    float4 rec[kBU][kBatch * kRecQuads];   // (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, mask hi)   12 KB
+    float2 pair[kBatchPairCap + 2];        // (q, w) of every pair, record-major within a unit, units of a group in a row   18.75 KB
+                                           // (+ 2: the 16-byte zeroing stores may reach one slot past the last)
+    float4 pst[kBU * 64][2];               // per (unit, pixel): (walk set lo, hi, T, A) (dL_dpixel r, g, b, tfb)   8 KB
+    uint32_t hist[2][68];                  // task lengths 0..64: counts, then start positions (descending length)
+    uint8_t order[2][kBU * 64];            // tasks by descending length: phase A (unit << 6 | pixel), phase B (unit << 6 | record)
+    float2 origin[kBU];                    // tile origin of every unit
+    uint32_t unit_pairs[kBU];              // pair slots every unit needs (0: nothing to walk)
+};
+static_assert(sizeof(BatchLds) <= 40960, "four workgroups per CU");
+
+#ifdef FR_BWD_TRACE
+#define FR_BSTAMP(K) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kBU + w) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#define FR_BSTAMPV(K, V) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kBU + w) * 16 + (K)] = (unsigned long long)(V); } while (0)
+#else
+#define FR_BSTAMP(K) do { } while (0)
+#define FR_BSTAMPV(K, V) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(64 * kBU, 4) k_batch_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
+                                                                  void* binning, int W, int H, const float* __restrict__ bg,
+                                                                  const float* __restrict__ dL_dpix, float* __restrict__ accum,
+                                                                  uint32_t dense_pairs)
+{
+    __shared__ BatchLds S;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FR_BSTAMP(0);
+    const uint32_t nu = counts->num_units;
+    if (blockIdx.x * (uint32_t)kBU >= nu) return;   // (the whole workgroup)
+    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const TransposeConsts tc = transpose_consts(lane);
+    // (normally one batch per workgroup: the grid covers the units of BASELINE config 2 four times over)
+    for (uint32_t batch = blockIdx.x; batch * (uint32_t)kBU < nu; batch += gridDim.x) {
+    if (batch != blockIdx.x) __syncthreads();   // (the previous batch is flushed: LDS is free again)
+    const uint32_t u = batch * kBU + (uint32_t)w;
+    const bool has = u < nu;
+    if (threadIdx.x < 2 * 68) (&S.hist[0][0])[threadIdx.x] = 0u;
+
+    // ---- this wave's unit: every load below depends on the descriptor only, and all of them are in flight together
+    const uint4 d = b.unit_tile[has ? u : 0u];
+    const uint32_t tile = d.x, base = d.y * kUnit, start = d.z, n = d.w;
+    const uint32_t m = has ? min((uint32_t)kUnit, n - base) : 0u;
+    const int tx0 = (int)(tile % (uint32_t)v.tiles_x) * kTile, ty0 = (int)(tile / (uint32_t)v.tiles_x) * kTile;
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+    const bool inside = has && px < W && py < H;
+    const size_t pix = inside ? (size_t)py * W + px : 0, HW = (size_t)H * W;
+    const uint32_t ridx = min(base + (uint32_t)lane, n ? n - 1u : 0u);    // (clamped: the loads stay unconditional)
+    const float4* rsrc = b.recs + ((size_t)start + ridx) * kRecQuads;
+    const uint32_t last_raw = v.n_contrib[pix];
+    const float4 rq0 = rsrc[0], rq1 = rsrc[1];
+    const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
+    const uint2 mraw = b.masks[(size_t)start + ridx];
+    const float4 st = b.unit_state[(size_t)(has ? u : 0u) * kUnit + lane];
+    const float Tf_raw = v.final_T[pix];
+    const float d0 = dL_dpix[pix], d1 = dL_dpix[HW + pix], d2 = dL_dpix[2 * HW + pix];
+    __syncthreads();   // (the histograms are zero)
+    FR_BSTAMP(1);
+
+    const uint32_t last = inside ? last_raw : 0u;
+    const bool live = has && __any(last > base);   // nothing at or behind the deepest contributor of the tile can matter
+    const bool valid_rec = live && base + (uint32_t)lane < n;
+    const uint2 mj = valid_rec ? mraw : make_uint2(0u, 0u);
+    const u64 Mj = ((u64)mj.y << 32) | mj.x;
+    const uint32_t cnt = (uint32_t)__popcll(Mj);
+    const uint32_t cum = wave_incl_scan_u32(cnt);
+    const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)cum, 63);
+    // all-pairs form, by this wave alone, at the end (also whatever would not fit the pair slots on its own)
+    const bool dense = live && npairs > min(dense_pairs, (uint32_t)kBatchPairCap);
+    const bool sparse = live && !dense;
+    const uint32_t my_id = __float_as_uint(rq2.y);
+    {
+        // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch)
+        S.rec[w][lane * kRecQuads + 0] = make_float4(valid_rec ? rq0.x : 0.f, valid_rec ? rq0.y : 0.f, valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
+        S.rec[w][lane * kRecQuads + 1] = make_float4(valid_rec ? rq1.x : 0.f, valid_rec ? rq1.y : 0.f, valid_rec ? rq1.z : 0.f, valid_rec ? rq1.w : 0.f);
+        // the all-pairs form reads (colour b, id) from here; the walks read (colour b, first slot, mask)
+        S.rec[w][lane * kRecQuads + 2] = make_float4(rq2.x, dense ? rq2.y : __uint_as_float(cum - cnt), __uint_as_float(sparse ? mj.x : 0u),
+                                                     __uint_as_float(sparse ? mj.y : 0u));
+    }
+    const uint2 bt = transpose_bits64(sparse ? mj : make_uint2(0u, 0u), lane, tc);
+    const int lim = (int)last - (int)base;      // records [0, lim) of this unit can contribute to this pixel
+    u64 Bp = ((u64)bt.y << 32) | bt.x;
+    Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
+    const float T_final = inside ? Tf_raw : 0.f;
+    const float dpr = inside ? d0 : 0.f, dpg = inside ? d1 : 0.f, dpb = inside ? d2 : 0.f;
+    const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
+    const float T_in = lim > 0 ? st.w : 0.f;
+    const float A_in = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;   // accum_rec . dL_dpixel (see k_unit_blend_bwd)
+    S.pst[w * 64 + lane][0] = make_float4(__uint_as_float((uint32_t)Bp), __uint_as_float((uint32_t)(Bp >> 32)), T_in, A_in);
+    S.pst[w * 64 + lane][1] = make_float4(dpr, dpg, dpb, -T_final * bgd);
+    if (lane == 0) {
+        S.unit_pairs[w] = sparse ? npairs : 0u;
+        S.origin[w] = make_float2((float)tx0, (float)ty0);
+    }
+    // every slot a record's mask names is read in phase B; phase A leaves out the pairs behind a pixel's last contributor
+    const bool all_written = __all(inside && lim >= (int)m);
+    __syncthreads();   // (records, pixel states and pair counts of the four units are in LDS)
+    FR_BSTAMP(2);
+    FR_BSTAMPV(9, npairs);
+
+    const uint32_t up0 = S.unit_pairs[0], up1 = S.unit_pairs[1], up2 = S.unit_pairs[2], up3 = S.unit_pairs[3];
+    const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;   // which (record-in-septet, component) this lane flushes
+    float* sums = reinterpret_cast<float*>(&S.rec[0][0]);    // unit g's sums: the first 64 x 9 floats of ITS record region
+    constexpr int kRecFloats = kBatch * kRecQuads * 4;       // floats per unit region
+
+    if (up0 + up1 + up2 + up3 != 0u) {
+        // ---- groups of consecutive units whose pairs fit the slots (normally ONE group: all four)
+        for (int g0 = 0; g0 < kBU;) {
+            // slot0[g]: first pair slot of unit g inside the group (units outside the group: unused)
+            uint32_t slot0[kBU] = {0u, 0u, 0u, 0u};
+            int g1 = g0;
+            {
+                const uint32_t up[kBU] = {up0, up1, up2, up3};
+                uint32_t acc = 0;
+#pragma unroll
+                for (int g = 0; g < kBU; g++) {
+                    const bool take = g >= g0 && g == g1 && (g == g0 || acc + up[g] <= (uint32_t)kBatchPairCap);
+                    slot0[g] = acc;
+                    acc += take ? up[g] : 0u;
+                    g1 = take ? g + 1 : g1;
+                }
+            }
+            const bool mine = w >= g0 && w < g1 && sparse;   // this wave's unit is part of the group
+            const uint32_t my_slot0 = w == 0 ? slot0[0] : w == 1 ? slot0[1] : w == 2 ? slot0[2] : slot0[3];
+            if (g0 > 0) {   // (a further group: the histograms start from zero again)
+                __syncthreads();
+                if (threadIdx.x < 2 * 68) (&S.hist[0][0])[threadIdx.x] = 0u;
+                __syncthreads();
+            }
+            // ---- counting sort of the tasks by length, longest first: rank inside the length's bin ...
+            const uint32_t lenA = mine ? (uint32_t)__popcll(Bp) : 0u, lenB = mine ? cnt : 0u;
+#ifdef FR_BWD_TRACE
+            if (mine && u < 8192u) g_bwd_lens[u * 128u + lane] = (unsigned char)lenA, g_bwd_lens[u * 128u + 64u + lane] = (unsigned char)lenB;
+#endif
+            // (tasks of length 0 need no place: hundreds of lanes adding to ONE LDS word take ~100 cycles each)
+            const uint32_t rankA = lenA ? atomicAdd(&S.hist[0][lenA], 1u) : 0u, rankB = lenB ? atomicAdd(&S.hist[1][lenB], 1u) : 0u;
+            if (mine && !all_written)
+                for (uint32_t z = (uint32_t)lane; z * 2u < npairs + 1u; z += 64u) {
+                    float2* zp = S.pair + ((my_slot0 + z * 2u) & ~1u);   // (16-byte aligned: may clear the slot in front, still unwritten)
+                    *reinterpret_cast<float4*>(zp) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            __syncthreads();
+            // ... bin starts: bins in descending length order (waves 0 and 1, one histogram each)
+            if (w < 2) {
+                const uint32_t c = S.hist[w][64 - lane];           // lane l <-> length 64 - l
+                const uint32_t inc = wave_incl_scan_u32(c);
+                const uint32_t c0 = S.hist[w][0];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                S.hist[w][64 - lane] = inc - c;
+                if (lane == 63) S.hist[w][0] = inc, (void)c0;      // length 0 comes last
+            }
+            __syncthreads();
+            if (lenA) S.order[0][S.hist[0][lenA] + rankA] = (uint8_t)(w * 64 + lane);
+            if (lenB) S.order[1][S.hist[1][lenB] + rankB] = (uint8_t)(w * 64 + lane);
+            const uint32_t totalA = S.hist[0][0], totalB = S.hist[1][0];   // tasks with something to walk
+            __syncthreads();
+            FR_BSTAMP(3);
+
+            // ---- phase A: lane = one (unit, pixel) chain, back to front over the records its walk set names.  Two
+            // records per iteration (independent alpha evaluations; only the T / accum_rec recurrence is serial).
+            {
+                const bool have = (uint32_t)(w * 64 + lane) < totalA;
+                const uint32_t t = have ? S.order[0][w * 64 + lane] : 0u;
+                const uint32_t g = t >> 6, p = t & 63u;
+                const float4 s0 = S.pst[t][0], s1 = S.pst[t][1];
+                const float2 org = S.origin[g];
+                u64 Bg = ((u64)__float_as_uint(s0.y) << 32) | __float_as_uint(s0.x);
+                Bg = have ? Bg : 0ull;
+                // the pixels of a record's mask below this one: its rank among the record's pairs
+                const uint32_t below_lo = p < 32u ? (1u << p) - 1u : ~0u, below_hi = p < 32u ? 0u : (1u << (p - 32u)) - 1u;
+                float T = s0.z, A = s0.w;
+                const float ar = s1.x, ag = s1.y, ab = s1.z, tfb = s1.w;
+                const float fx = org.x + (float)(p & 7u), fy = org.y + (float)(p >> 3);
+                const float4* R = &S.rec[0][0] + g * (kBatch * kRecQuads);
+                uint32_t gs0 = slot0[0];
+#pragma unroll
+                for (int k = 1; k < kBU; k++) gs0 = g == (uint32_t)k ? slot0[k] : gs0;
+                const uint32_t nA = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(Bg)) + 1u) >> 1;
+                FR_BSTAMPV(10, nA);
+                for (uint32_t it = 0; it < nA; it++) {
+                    bool act[2];
+                    int j[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        act[k] = Bg != 0ull;
+                        j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
+                        Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
+                    }
+                    float ar_e[2], cd[2];
+                    uint32_t slot[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float4 q0 = R[j[k] * kRecQuads + 0];
+                        const float4 q1 = R[j[k] * kRecQuads + 1];
+                        const float4 q2 = R[j[k] * kRecQuads + 2];
+                        const float dx = q0.x - fx, dy = q0.y - fy;
+                        const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
+                        const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
+                        const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+                        cd[k] = (q1.z * ar + q1.w * ag) + q2.x * ab;                 // colour . dL_dpixel
+                        ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity
+                        // slot = unit's first slot + record's first slot + rank of this pixel among the record's pixels
+                        slot[k] = (uint32_t)__popc(__float_as_uint(q2.w) & below_hi) +
+                                  ((uint32_t)__popc(__float_as_uint(q2.z) & below_lo) + (__float_as_uint(q2.y) + gs0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float a_e = __builtin_amdgcn_fmed3f(ar_e[k], 0.f, 0.99f);
+                        const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
+                        T *= inv;                                                   // backward.cu:503
+                        const float e = cd[k] - A;
+                        const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
+                        A += a_e * e;
+                        if (act[k]) S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
+                    }
+                }
+            }
+            __syncthreads();   // (every pair of the group is in its slot)
+            FR_BSTAMP(4);
+
+            // ---- phase B: lane = one (unit, record): walks the pixels of its mask (two per iteration), its pairs are
+            // consecutive slots; nine sums in registers
+            {
+                const bool have = (uint32_t)(w * 64 + lane) < totalB;
+                const uint32_t t = have ? S.order[1][w * 64 + lane] : 0u;
+                const uint32_t g = t >> 6;
+                const float4* R = &S.rec[0][0] + g * (kBatch * kRecQuads);
+                const float4 q0 = R[(t & 63u) * kRecQuads + 0];
+                const float4 q2 = R[(t & 63u) * kRecQuads + 2];
+                const float2 org = S.origin[g];
+                u64 Mg = have ? (((u64)__float_as_uint(q2.w) << 32) | __float_as_uint(q2.z)) : 0ull;
+                uint32_t gs0 = slot0[0];
+#pragma unroll
+                for (int k = 1; k < kBU; k++) gs0 = g == (uint32_t)k ? slot0[k] : gs0;
+                uint32_t slot = gs0 + __float_as_uint(q2.y);
+                const float rxl = q0.x - org.x, ryl = q0.y - org.y;       // record centre, tile-local
+                const float4* P = &S.pst[g * 64][1];
+                const uint32_t nB = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(Mg)) + 1u) >> 1;
+                FR_BSTAMPV(11, nB);
+                __syncthreads();   // (every lane has read its record: the record regions may now take the sums)
+                float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (uint32_t it = 0; it < nB; it++) {
+                    float2 qw[2];
+                    float4 dp[2];
+                    float dx[2], dy[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const bool act = Mg != 0ull;
+                        const int pp = act ? (int)__builtin_ctzll(Mg) : 0;
+                        Mg &= Mg - 1ull;
+                        qw[k] = S.pair[act ? slot : 0u];
+                        qw[k].x = act ? qw[k].x : 0.f;
+                        qw[k].y = act ? qw[k].y : 0.f;
+                        slot += act ? 1u : 0u;
+                        dp[k] = P[pp * 2];
+                        dx[k] = rxl - (float)(pp & 7), dy[k] = ryl - (float)(pp >> 3);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float qdx = qw[k].x * dx[k], qdy = qw[k].x * dy[k];
+                        sm[ACC_MX] += qdx;
+                        sm[ACC_MY] += qdy;
+                        sm[ACC_CA] += qdx * dx[k];
+                        sm[ACC_CB] += qdx * dy[k];
+                        sm[ACC_CC] += qdy * dy[k];
+                        sm[ACC_OP] += qw[k].x;
+                        sm[ACC_R] += qw[k].y * dp[k].x;
+                        sm[ACC_G] += qw[k].y * dp[k].y;
+                        sm[ACC_B] += qw[k].y * dp[k].z;
+                    }
+                }
+                if (have) {
+                    float* o = sums + g * kRecFloats + (t & 63u) * 9u;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) o[c] = sm[c];
+                }
+            }
+            __syncthreads();   // (the sums of the group's records are in LDS)
+            FR_BSTAMP(5);
+            // ---- flush: wave = unit, 7 records x 9 components per atomic instruction (one 64-byte line per record)
+            for (int r0 = 0; r0 < (int)m; r0 += 7) {
+                const int rj = min(r0 + fl_rec, 63);
+                // (a record without pairs had no phase-B lane: nothing was written to its row)
+                const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute(rj << 2, (int)(cnt ? my_id : ~0u));
+                if (mine && lane < 63 && r0 + fl_rec < (int)m && id != ~0u) {
+                    const float val = sums[w * kRecFloats + rj * 9 + fl_c];
+                    if (val != 0.f) atomic_add_f32(accum + (size_t)id * kAccumStride + fl_c, val);
+                }
+            }
+            FR_BSTAMP(6);
+            g0 = g1;
+        }
+    }
+    // ---- a unit in which most pairs are named: all 64 x 64, by this wave alone (see bwd_unit_all_pairs)
+    if (dense) {
+        const int vv = bitrev6(lane);
+        const int own_u = vv / 9, own_c = vv - own_u * 9;
+        bwd_unit_all_pairs(S.rec[w], (int)m, lim, (float)px, (float)py, T_in, A_in, T_final, bgd, dpr, dpg, dpb, accum, lane, vv,
+                           own_u, own_c);
+    }
+    FR_BSTAMP(7);
+    FR_BSTAMPV(8, 1);
     }
 }
 
@@ -1769,13 +2129,20 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     hipEvent_t ev_a, ev_b;
     if (!h->dense_blend_bwd && next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
         // the graded kernel, timed the way a profiler times it: events taken from the dispatch itself
-        hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts, v,
-                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        if (h->batch_blend_bwd)
+            hipExtLaunchKernelGGL(k_batch_blend_bwd, dim3(unit_grid), dim3(64 * kBU), 0, s, ev_a, ev_b, 0, v.counts, v, binning,
+                                  prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        else
+            hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts,
+                                  v, binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
     } else {
         StageScope sc(h, ST_BLEND_BWD, s);
         if (h->dense_blend_bwd)
             hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,
                                prm.H, in.background, dL_dpix, g.accum);
+        else if (h->batch_blend_bwd)
+            hipLaunchKernelGGL(k_batch_blend_bwd, dim3(unit_grid), dim3(64 * kBU), 0, s, v.counts, v, binning, prm.W, prm.H,
+                               in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
         else
             hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning,
                                prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);

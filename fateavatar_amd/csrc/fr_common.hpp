@@ -243,6 +243,8 @@ struct fr_handle_impl {
     uint32_t chain_spins = 1u << 16;   // polls before a blend unit stops waiting for another one and computes its product / row itself (FR_CHAIN_SPINS)
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
     bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
+    bool batch_blend_bwd = false; // FR_BLEND_BWD=batch: four units per workgroup with length-sorted walks (k_batch_blend_bwd: fewer
+                                  // instructions, but slower — see the kernel's header) instead of one wave per unit
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];
 };

@@ -1,0 +1,60 @@
+"""Per-wave phase timeline of the blend backward (GPU box).  Needs the -DFR_BWD_TRACE build:
+    tools/diag/build_variant.sh trace -DFR_BWD_TRACE        (here)
+    FR_HIP_LIB=$PWD/.ab/libfr_trace.so python tools/diag/bwd_trace.py [--P 100000 --res 512]   (GPU box)
+Stamps (shader cycles, s_memtime): 0 entry, 1 descriptor + pixel loads issued, 2 n_contrib arrived, 3 staged + scanned +
+transposed, 4 phase A of the first range done, 5 phase B done, 6 flush done, 7 unit done; values: 8/12 s_memrealtime at
+entry / exit (100 MHz), 9 pair slots of the unit, 10/11 iterations of phase A / B of the first range."""
+import argparse, ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from fateavatar_amd import scenes, _lib  # noqa: E402
+from tests.util import HipFrame  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--P", type=int, default=100000)
+ap.add_argument("--res", type=int, default=512)
+ap.add_argument("--opacity", type=float, default=0.1)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+s = scenes.head_scene(P=a.P, res=a.res, opacity=a.opacity)
+f = HipFrame(s, dev)
+g = (np.random.default_rng(0).uniform(-1, 1, (3, a.res, a.res)) / (a.res * a.res)).astype(np.float32)
+for _ in range(3):
+    f.backward(g)
+torch.cuda.synchronize()
+L = _lib.lib()
+buf = np.zeros(8192 * 16, np.uint64)
+L.fr_debug_read_bwd_trace.argtypes = [C.c_void_p, C.c_size_t]
+rc = L.fr_debug_read_bwd_trace(buf.ctypes.data, buf.nbytes)
+assert rc == 0, rc
+t = buf.reshape(8192, 16).astype(np.int64)
+work = t[:, 7] > 0
+w = t[work]
+print(f"waves with a unit: {work.sum()} of 8192; instances {f.counts.num_instances}")
+rt0 = t[t[:, 8] > 0, 8].min()
+if os.environ.get("FR_BLEND_BWD") == "unit":
+    print(f"kernel span by s_memrealtime: first entry -> last unit exit {(w[:, 12].max() - rt0) / 100:.2f} us; "
+          f"entries spread over {(t[t[:, 8] > 0, 8].max() - rt0) / 100:.2f} us")
+else:
+    print(f"span of the working waves in shader cycles (one clock domain assumed): {w[:, 7].max() - w[:, 0].min()}")
+if os.environ.get("FR_BLEND_BWD") == "unit":
+    names = ["entry->descriptor", "descriptor->n_contrib", "n_contrib->staged+transposed", "staged->phase A done",
+             "phase A->phase B done", "phase B->flush done", "flush->unit done (further ranges)"]
+else:   # k_batch_blend_bwd: 0 entry, 1 loads issued + barrier, 2 staged + barrier, 3 tasks sorted, 4 A, 5 B, 6 flush, 7 end
+    names = ["entry->loads issued", "loads->staged (barrier)", "staged->tasks sorted", "sorted->phase A done (barrier)",
+             "phase A->phase B done (barrier)", "phase B->flush done", "flush->end (further groups, all-pairs units)"]
+d = np.diff(w[:, :8], axis=1)
+print(f"{'segment':38s} {'mean':>8s} {'p50':>8s} {'p90':>8s} {'max':>8s}  (shader cycles)")
+for k, n in enumerate(names):
+    x = d[:, k]
+    print(f"{n:38s} {x.mean():8.0f} {np.percentile(x, 50):8.0f} {np.percentile(x, 90):8.0f} {x.max():8.0f}")
+tot = w[:, 7] - w[:, 0]
+print(f"{'whole unit':38s} {tot.mean():8.0f} {np.percentile(tot, 50):8.0f} {np.percentile(tot, 90):8.0f} {tot.max():8.0f}")
+print(f"pairs/unit mean {w[:, 9].mean():.0f} p90 {np.percentile(w[:, 9], 90):.0f} max {w[:, 9].max()};  nA mean {w[:, 10].mean():.1f} max {w[:, 10].max()};"
+      f"  nB mean {w[:, 11].mean():.1f} max {w[:, 11].max()}")
+# the slowest units: what made them slow
+idx = np.argsort(-tot)[:8]
+for i in idx:
+    print("slow unit: total", tot[i], "segments", d[i].tolist(), "pairs", w[i, 9], "nA", w[i, 10], "nB", w[i, 11])
+# correlation of unit duration with pairs
+print("corr(total, pairs) =", np.corrcoef(tot, w[:, 9])[0, 1])
