@@ -433,7 +433,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
             // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
             const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
             for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
-                if (u0 + k < unit_cap) unit_tile[u0 + k] = make_uint4(tile, k, start, n);
+                if (u0 + k < unit_cap)   // (tile position, not tile index: the blend kernels need no division)
+                    unit_tile[u0 + k] = make_uint4((tile / (uint32_t)v.tiles_x) << 16 | (tile % (uint32_t)v.tiles_x), k, start, n);
             // hand-off words of k_unit_blend_chained: a unit's per-pixel product is valid once it is non-zero
             if (unit_tseg)
                 for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
@@ -551,7 +552,7 @@ __device__ __forceinline__ void stage_unit(float4* s_rec, const float4* __restri
 }
 
 struct UnitInfo {
-    uint32_t tile, seg, start, n, base, m;  // tile id, segment index, list start, list length, first record, records in unit
+    uint32_t tx, ty, seg, start, n, base, m;  // tile position, segment index, list start, list length, first record, records in unit
     int px, py;
     bool inside;
 };
@@ -561,8 +562,8 @@ __device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint4* __restric
                                               const uint32_t* __restrict__ tile_offset, int W, int H, int tiles_x, int lane)
 {
     UnitInfo i;
-    const uint4 d = unit_tile[u];  // one load: (tile, segment, list start, list length)
-    i.tile = d.x;
+    const uint4 d = unit_tile[u];  // one load: (tile y << 16 | tile x, segment, list start, list length)
+    i.tx = d.x & 0xFFFFu, i.ty = d.x >> 16;
     i.seg = d.y;
     i.start = d.z;
     i.n = d.w;
@@ -570,8 +571,9 @@ __device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint4* __restric
     (void)tile_offset;
     i.base = i.seg * kUnit;
     i.m = min((uint32_t)kUnit, i.n - i.base);
-    i.px = (int)(i.tile % (uint32_t)tiles_x) * kTile + (lane & 7);
-    i.py = (int)(i.tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
+    i.px = (int)i.tx * kTile + (lane & 7);
+    i.py = (int)i.ty * kTile + (lane >> 3);
+    (void)tiles_x;
     i.inside = i.px < W && i.py < H;
     return i;
 }
@@ -923,10 +925,13 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
 constexpr int kPairCap = 640;    // (q, w) slots per wave; denser units are processed in several record ranges
 
 struct SparseLds {
-    float4 rec[kBatch * kRecQuads];   // the unit's records (q2.zw = footprint mask)                          3 KB
+    float4 rec[kBatch * kRecQuads];   // the unit's records: (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, hi)   3 KB
     float4 pix[64];                   // per pixel: dL_dpixel (r, g, b, -)                                     1 KB
-    float2 pair[kPairCap];            // (q, w) of every pair, RECORD-major: a record's pairs are consecutive  5 KB
-    uint32_t sbase[64];               // first pair slot of every record                                    0.25 KB
+    float2 pair[kPairCap + 64];       // (q, w) of every pair, RECORD-major: a record's pairs are consecutive  5.5 KB
+                                      // (+ 64: one scratch slot per lane, where a lane without a pair reads and writes)
+#ifdef FR_BWD_LDS_PAD                 // (occupancy experiments: fewer waves per CU)
+    char pad[FR_BWD_LDS_PAD];
+#endif
 };
 
 // maximum over the 64 lanes, in every lane's SGPR-able form (result is wave-uniform)
@@ -1357,7 +1362,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
     uint2 fm = make_uint2(0u, 0u);
     if (ui.base + (uint32_t)lane < ui.n) {
         fm = footprint_mask(rr.q0.x, rr.q0.y, rr.q0.z, rr.q0.w, rr.q1.x, rr.q1.y,
-                            (float)((int)(ui.tile % (uint32_t)tiles_x) * kTile), (float)((int)(ui.tile / (uint32_t)tiles_x) * kTile));
+                            (float)((int)ui.tx * kTile), (float)((int)ui.ty * kTile));
         rr.q2.z = __uint_as_float(fm.x), rr.q2.w = __uint_as_float(fm.y);
         masks[(size_t)ui.start + ui.base + (uint32_t)lane] = fm;
     }
@@ -1455,7 +1460,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("" ::: "memory");
-    gather_tile<true>(v, ui.tile, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
+    gather_tile<true>(v, ui.ty * (uint32_t)v.tiles_x + ui.tx, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
 }
 
 // the gather as its own launch (FR_BLEND_FWD=gather): one wave per tile
@@ -1500,105 +1505,139 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                                                               uint32_t dense_pairs)
 {
     __shared__ SparseLds s_all[kWavesPerWG];
-    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FR_STAMP(0);
+    FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
+    // The first unit's descriptor is requested BEFORE the counts are known (one round trip less in front of every
+    // wave's first loads): the descriptors sit at the head of the binning buffer whatever its capacity, and there are at
+    // least T + 1 of them (BinningView::units_for), so index min(u, T) is always inside the buffer.
+    const uint32_t n_tiles = (uint32_t)v.tiles_x * (uint32_t)v.tiles_y;
+    const uint32_t u_first = blockIdx.x * kWavesPerWG + wave_in_wg;
+    const uint32_t nu = counts->num_units, capacity = counts->capacity;
+    const uint4 d_first = BinningView::make(binning, 0, (size_t)n_tiles).unit_tile[min(u_first, n_tiles)];
+    // (pinned together: the descriptor load is issued before anything waits for the counts — without this the compiler
+    // parks it behind the loop's entry test, i.e. behind the counts' round trip)
+    asm volatile("" ::"v"(d_first.x), "s"(nu), "s"(capacity));
+    const BinningView b = BinningView::make(binning, (size_t)capacity, (size_t)n_tiles);
     SparseLds& S = s_all[wave_in_wg];
     const TransposeConsts tc = transpose_consts(lane);
-    const uint32_t nu = counts->num_units;
     const uint32_t wave_stride = gridDim.x * kWavesPerWG;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    // which (record-in-septet, component) this lane flushes: lanes 0..62 = 7 records x 9 components
+    // flush: lanes 0..62 = 7 records x 9 components; lane l of a septet starting at record r0 reads word r0 * 9 + l of
+    // the [record][9] sums and adds it to component l % 9 of record r0 + l / 9
     const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;
+    float* const accum_c = accum + fl_c;
     // the same for the all-pairs form (bwd_unit_all_pairs): 4 records x 9 components after its reduce-scatter
     const int vv = bitrev6(lane);
     const int own_u = vv / 9, own_c = vv - own_u * 9;
-    FR_STAMP(0);
-    FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
-    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
-        const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
-        const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
-        const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
+    const size_t HW = (size_t)H * W;
+    for (uint32_t u = u_first; u < nu; u += wave_stride) {
+        // ---- every load below depends on the descriptor only: all of them are in flight together (clamped indices keep
+        // them unconditional; the compiler serialises loads that sit behind exec-masked branches)
+        uint4 d = d_first;
+        if (u != u_first || u > n_tiles) d = b.unit_tile[u];
+        const uint32_t base = d.y * kUnit, start = d.z, n = d.w;
+        const uint32_t m = min((uint32_t)kUnit, n - base);
+        const int tx0 = (int)(d.x & 0xFFFFu) * kTile, ty0 = (int)(d.x >> 16) * kTile;
+        const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const size_t pix = inside ? (size_t)py * W + px : 0;
+        const uint32_t ridx = min(base + (uint32_t)lane, n - 1u);
+        const float4* rsrc = b.recs + ((size_t)start + ridx) * kRecQuads;
+        const uint32_t last_raw = v.n_contrib[pix];
+        const float4 rq0 = rsrc[0], rq1 = rsrc[1];
+        const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
+        const uint2 mraw = b.masks[(size_t)start + ridx];
+        const float4 st = b.unit_state[(size_t)u * kUnit + lane];
+        const float Tf_raw = v.final_T[pix];
+        const float d0 = dL_dpix[pix], d1 = dL_dpix[HW + pix], d2 = dL_dpix[2 * HW + pix];
+        // (pinned: otherwise everything but n_contrib is sunk below the early exit, a second round trip)
+        asm volatile("" ::"v"(last_raw), "v"(rq0.x), "v"(rq1.x), "v"(rq2.x), "v"(mraw.x), "v"(st.x), "v"(Tf_raw), "v"(d0), "v"(d1), "v"(d2));
         FR_STAMP(1);
+        const uint32_t last = inside ? last_raw : 0u;
         // nothing at or behind the deepest contributor of any pixel of the tile can matter
-        if (!__any(last > ui.base)) continue;
+        if (!__any(last > base)) continue;
         FR_STAMP(2);
 
         // ---- lane = record: stage the records; this lane keeps what phase B needs of its own
-        const RecRegs rr = fetch_record(b.recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
-        // ---- lane = pixel: per-pixel inputs (requested together with the record)
-        const float T_final = ui.inside ? v.final_T[pix] : 0.f;
-        const float4 st = b.unit_state[(size_t)u * kUnit + lane];
-        float dpr = 0.f, dpg = 0.f, dpb = 0.f;
-        if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
-        S.rec[lane * kRecQuads + 0] = rr.q0;
-        S.rec[lane * kRecQuads + 1] = rr.q1;
-        const uint2 mj = (ui.base + (uint32_t)lane < ui.n) ? b.masks[(size_t)ui.start + ui.base + (uint32_t)lane] : make_uint2(0u, 0u);
-        S.rec[lane * kRecQuads + 2] = make_float4(rr.q2.x, rr.q2.y, __uint_as_float(mj.x), __uint_as_float(mj.y));
+        const bool valid_rec = base + (uint32_t)lane < n;
+        const uint2 mj = valid_rec ? mraw : make_uint2(0u, 0u);
         const u64 Mj = ((u64)mj.y << 32) | mj.x;
         const uint32_t cnt = (uint32_t)__popcll(Mj);
         const uint32_t cum = wave_incl_scan_u32(cnt);             // pairs of records [0, lane]
-        S.sbase[lane] = cum - cnt;
+        const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)cum, 63);
+        // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
+        // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
+        const bool dense = npairs > dense_pairs;
+        const uint32_t my_id = __float_as_uint(rq2.y);
+        // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch)
+        S.rec[lane * kRecQuads + 0] = make_float4(valid_rec ? rq0.x : 0.f, valid_rec ? rq0.y : 0.f, valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
+        S.rec[lane * kRecQuads + 1] = make_float4(valid_rec ? rq1.x : 0.f, valid_rec ? rq1.y : 0.f, valid_rec ? rq1.z : 0.f, valid_rec ? rq1.w : 0.f);
+        // the walks read (colour b, first pair slot, mask) from the third quad, the all-pairs form (colour b, id)
+        S.rec[lane * kRecQuads + 2] = make_float4(rq2.x, dense ? rq2.y : __uint_as_float(cum - cnt), __uint_as_float(mj.x), __uint_as_float(mj.y));
         // record-major masks -> pixel-major walk sets, limited to the records in front of the pixel's last contributor
         const uint2 bt = transpose_bits64(mj, lane, tc);
-        const int lim = (int)last - (int)ui.base;      // records [0, lim) of this unit can contribute to this pixel
+        const int lim = (int)last - (int)base;      // records [0, lim) of this unit can contribute to this pixel
         u64 Bp = ((u64)bt.y << 32) | bt.x;
         Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
         FR_STAMP(3);
-        FR_STAMPV(9, __builtin_amdgcn_readlane((int)cum, 63));
+        FR_STAMPV(9, npairs);
 
-        const float fx = (float)ui.px, fy = (float)ui.py;
-        const float tfb = -T_final * ((bg0 * dpr + bg1 * dpg) + bg2 * dpb);   // -T_final * (bg . dL_dpixel)
+        const float T_final = inside ? Tf_raw : 0.f;
+        const float dpr = inside ? d0 : 0.f, dpg = inside ? d1 : 0.f, dpb = inside ? d2 : 0.f;
+        const float fx = (float)px, fy = (float)py;
+        const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
+        const float tfb = -T_final * bgd;                                      // -T_final * (bg . dL_dpixel)
         float T = lim > 0 ? st.w : 0.f;
         float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel (see k_unit_blend_bwd)
-        const float tile_x0 = (float)((int)(ui.tile % (uint32_t)v.tiles_x) * kTile);
-        const float tile_y0 = (float)((int)(ui.tile / (uint32_t)v.tiles_x) * kTile);
-        // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
-        // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
-        if ((uint32_t)__builtin_amdgcn_readlane((int)cum, 63) > dense_pairs) {
+        if (dense) {
 #ifdef FR_BWD_STATS
             if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[4], 1u);   // units in the all-pairs form
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            bwd_unit_all_pairs(S.rec, (int)ui.m, lim, fx, fy, T, A, T_final, (bg0 * dpr + bg1 * dpg) + bg2 * dpb, dpr, dpg, dpb,
-                               accum, lane, vv, own_u, own_c);
+            bwd_unit_all_pairs(S.rec, (int)m, lim, fx, fy, T, A, T_final, bgd, dpr, dpg, dpb, accum, lane, vv, own_u, own_c);
             __builtin_amdgcn_wave_barrier();   // (S.rec is restaged by the next unit)
             continue;
         }
         S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
-        const float rxl = rr.q0.x - tile_x0, ryl = rr.q0.y - tile_y0;           // own record centre, tile-local
+        const float rxl = rq0.x - (float)tx0, ryl = rq0.y - (float)ty0;           // own record centre, tile-local
 
         // ---- record ranges [lo, hi), from the back, each with at most kPairCap mask bits
-        int hi = (int)ui.m;
+        int hi = (int)m;
         while (hi > 0) {
             const uint32_t cum_hi = (uint32_t)__builtin_amdgcn_readlane((int)cum, hi - 1);
-            // smallest lo with pairs[lo, hi) <= kPairCap: lanes are monotone in that predicate
-            const bool fits = (lane < hi) && (cum_hi - (cum - cnt) <= (uint32_t)kPairCap);
-            const int lo = (int)__builtin_ctzll(__ballot(fits));   // hi - 1 always fits (a record has <= 64 bits)
+            int lo = 0;
+            if (cum_hi > (uint32_t)kPairCap) {   // (rare: the whole unit normally fits)
+                // smallest lo with pairs[lo, hi) <= kPairCap: lanes are monotone in that predicate
+                const bool fits = (lane < hi) && (cum_hi - (cum - cnt) <= (uint32_t)kPairCap);
+                lo = (int)__builtin_ctzll(__ballot(fits));   // hi - 1 always fits (a record has <= 64 bits)
+            }
             const u64 range = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
             const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)(cum - cnt), lo);   // first slot of the range
-            const uint32_t npairs = cum_hi - slot0;
-            // pairs no pixel walks (record behind the pixel's last contributor) must read as zero in phase B
-            for (uint32_t z = (uint32_t)lane; z * 2u < npairs; z += 64u)
-                reinterpret_cast<float4*>(S.pair)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t np = cum_hi - slot0;
+            // pairs no pixel walks (record behind the pixel's last contributor, pixel outside the image) must read as
+            // zero in phase B: only then is anything left unwritten by phase A
+            if (!__all(inside && lim >= hi))
+                for (uint32_t z = (uint32_t)lane; z * 2u < np; z += 64u)
+                    reinterpret_cast<float4*>(S.pair)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
             // ---- phase A: lane = pixel, back to front over the records its mask column names.  Two records per
-            // iteration: their alpha evaluations and slot computations are independent instruction streams (the kernel is
-            // bound by the latency of its LDS round trips, not by issue slots); only the T / accum_rec recurrence is serial
+            // iteration: their alpha evaluations and slot computations are independent instruction streams; only the
+            // T / accum_rec recurrence is serial
             u64 Bg = Bp & range;
-            const uint32_t nA = (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1;
 #ifdef FR_BWD_STATS   // development build (tools/diag/bwd_stats.sh): where do the kernel's iterations go?
             if (lane == 0) {
                 DeviceCounts* dc = const_cast<DeviceCounts*>(counts);
                 atomicAdd(&dc->pair_hist[0], 1u);      // record ranges processed
-                atomicAdd(&dc->pair_hist[1], nA);      // phase A iterations (two records each)
-                atomicAdd(&dc->pair_hist[3], npairs);  // pair slots
+                atomicAdd(&dc->pair_hist[1], (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1);      // phase A iterations (two records each)
+                atomicAdd(&dc->pair_hist[3], np);      // pair slots
             }
 #endif
-            for (uint32_t it = 0; it < nA; it++) {
+            if (__any(Bg != 0ull)) do {   // (do-while: as a while loop the compiler copies the loop-carried registers every trip)
                 bool act[2];
                 int j[2];
 #pragma unroll
@@ -1614,7 +1653,6 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                     const float4 q0 = S.rec[j[k] * kRecQuads + 0];
                     const float4 q1 = S.rec[j[k] * kRecQuads + 1];
                     const float4 q2 = S.rec[j[k] * kRecQuads + 2];
-                    const uint32_t sb = S.sbase[j[k]];
                     const float dx = q0.x - fx, dy = q0.y - fy;
                     const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
                     const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
@@ -1624,7 +1662,8 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                     // rank of this pixel among the record's pixels: mask bits below this lane (v_mbcnt: popcount of
                     // (operand & lanes-below-mine) + accumulator, two instructions for the 64 bits)
                     slot[k] = __builtin_amdgcn_mbcnt_hi(__float_as_uint(q2.w),
-                                                        __builtin_amdgcn_mbcnt_lo(__float_as_uint(q2.z), sb - slot0));
+                                                        __builtin_amdgcn_mbcnt_lo(__float_as_uint(q2.z), __float_as_uint(q2.y) - slot0));
+                    slot[k] = act[k] ? slot[k] : (uint32_t)kPairCap + (uint32_t)lane;   // (idle lane: its own scratch slot, no exec games)
                 }
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -1634,77 +1673,71 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                     const float e = cd[k] - A;
                     const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
                     A += a_e * e;
-                    if (act[k]) S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
+                    S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
                 }
-            }
+            } while (__any(Bg != 0ull));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (hi == (int)m) FR_STAMP(4);
 
-            if (hi == (int)ui.m) { FR_STAMP(4); FR_STAMPV(10, nA); }
             // ---- phase B: lane = record, over its own pixels (two per iteration); its pairs are consecutive slots
-            float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f s_m = {0.f, 0.f}, s_ab = {0.f, 0.f}, s_rg = {0.f, 0.f};   // (MX, MY) (CA, CB) (R, G)
+            float s_cc = 0.f, s_op = 0.f, s_b = 0.f;
             u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
             uint32_t slot = (cum - cnt) - slot0;
-            const uint32_t nB = (wave_max_u32((uint32_t)__popcll(Mg)) + 1u) >> 1;
 #ifdef FR_BWD_STATS
-            if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[2], nB);   // phase B iterations (two pixels each)
+            if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[2], (wave_max_u32((uint32_t)__popcll(Mg)) + 1u) >> 1);   // phase B iterations
 #endif
-            for (uint32_t it = 0; it < nB; it++) {
-                float2 qw[2];
-                float4 dp[2];
-                float dx[2], dy[2];
+            if (__any(Mg != 0ull)) do {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const bool act = Mg != 0ull;
                     const int p = act ? (int)__builtin_ctzll(Mg) : 0;
                     Mg &= Mg - 1ull;
-                    qw[k] = S.pair[act ? slot : 0u];
-                    qw[k].x = act ? qw[k].x : 0.f;
-                    qw[k].y = act ? qw[k].y : 0.f;
+                    float2 qw = S.pair[act ? slot : (uint32_t)kPairCap + (uint32_t)lane];
+                    const float q = act ? qw.x : 0.f, wgt = act ? qw.y : 0.f;
                     slot += act ? 1u : 0u;
-                    dp[k] = S.pix[p];
-                    dx[k] = rxl - (float)(p & 7), dy[k] = ryl - (float)(p >> 3);
+                    const float4 dp = S.pix[p];
+                    const v2f dd = {rxl - (float)(p & 7), ryl - (float)(p >> 3)};
+                    const v2f qd = q * dd;
+                    s_m += qd;
+                    s_ab += qd.x * dd;
+                    s_cc += qd.y * dd.y;
+                    s_op += q;
+                    s_rg += wgt * (v2f){dp.x, dp.y};
+                    s_b += wgt * dp.z;
                 }
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const float qdx = qw[k].x * dx[k], qdy = qw[k].x * dy[k];
-                    sm[ACC_MX] += qdx;
-                    sm[ACC_MY] += qdy;
-                    sm[ACC_CA] += qdx * dx[k];
-                    sm[ACC_CB] += qdx * dy[k];
-                    sm[ACC_CC] += qdy * dy[k];
-                    sm[ACC_OP] += qw[k].x;
-                    sm[ACC_R] += qw[k].y * dp[k].x;
-                    sm[ACC_G] += qw[k].y * dp[k].y;
-                    sm[ACC_B] += qw[k].y * dp[k].z;
-                }
-            }
+            } while (__any(Mg != 0ull));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (hi == (int)ui.m) { FR_STAMP(5); FR_STAMPV(11, nB); }
+            if (hi == (int)m) FR_STAMP(5);
             // ---- flush: [record][9] through LDS (the pair slots are dead now), then 7 records x 9 components per atomic
             float* fl = reinterpret_cast<float*>(S.pair);
-#pragma unroll
-            for (int c = 0; c < 9; c++) fl[lane * 9 + c] = sm[c];
+            {
+                float* o = fl + lane * 9;
+                o[ACC_MX] = s_m.x, o[ACC_MY] = s_m.y, o[ACC_CA] = s_ab.x, o[ACC_CB] = s_ab.y, o[ACC_CC] = s_cc, o[ACC_OP] = s_op;
+                o[ACC_R] = s_rg.x, o[ACC_G] = s_rg.y, o[ACC_B] = s_b;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int r0 = lo; r0 < hi; r0 += 7) {
                 const int rj = r0 + fl_rec;
-                if (lane < 63 && rj < hi) {
-                    const uint32_t id = __float_as_uint(S.rec[rj * kRecQuads + 2].y);
-                    const float val = fl[rj * 9 + fl_c];
+                const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute(min(rj, 63) << 2, (int)my_id);
+                const float val = fl[r0 * 9 + lane];
+                if (lane < 63 && rj < hi && val != 0.f) {
 #if defined(FR_BWD_ABLATE) && FR_BWD_ABLATE == 1      // (timing experiments: plain stores instead of atomics / no flush at all)
-                    if (val != 0.f) accum[(size_t)id * kAccumStride + fl_c] = val;
+                    accum_c[(size_t)id * kAccumStride] = val;
 #elif defined(FR_BWD_ABLATE) && FR_BWD_ABLATE == 2
-                    if (val == 12345.f) accum[(size_t)id * kAccumStride + fl_c] = val;
+                    if (val == 12345.f) accum_c[(size_t)id * kAccumStride] = val;
 #else
-                    if (val != 0.f) atomic_add_f32(accum + (size_t)id * kAccumStride + fl_c, val);
+                    atomic_add_f32(accum_c + (size_t)id * kAccumStride, val);
 #endif
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (hi == (int)ui.m) FR_STAMP(6);
+            if (hi == (int)m) FR_STAMP(6);
             hi = lo;
         }
         FR_STAMP(7);
@@ -1772,9 +1805,9 @@ __global__ void __launch_bounds__(64 * kBU, 4) k_batch_blend_bwd(const DeviceCou
 
     // ---- this wave's unit: every load below depends on the descriptor only, and all of them are in flight together
     const uint4 d = b.unit_tile[has ? u : 0u];
-    const uint32_t tile = d.x, base = d.y * kUnit, start = d.z, n = d.w;
+    const uint32_t base = d.y * kUnit, start = d.z, n = d.w;
     const uint32_t m = has ? min((uint32_t)kUnit, n - base) : 0u;
-    const int tx0 = (int)(tile % (uint32_t)v.tiles_x) * kTile, ty0 = (int)(tile / (uint32_t)v.tiles_x) * kTile;
+    const int tx0 = (int)(d.x & 0xFFFFu) * kTile, ty0 = (int)(d.x >> 16) * kTile;
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const bool inside = has && px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0, HW = (size_t)H * W;

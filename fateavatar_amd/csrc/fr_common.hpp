@@ -47,8 +47,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 template <typename T>
 __host__ __device__ static inline T* carve(char*& p, size_t count)
 {
-    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
-    T* r = reinterpret_cast<T*>(a);
+    // (pointer arithmetic, not an integer round trip: inside a kernel the compiler then still knows that the result points
+    // to GLOBAL memory and emits global_load / global_store — a pointer rebuilt from an integer is generic: flat_* accesses,
+    // which also count against lgkmcnt and so tie every LDS wait to the outstanding memory loads)
+    T* r = reinterpret_cast<T*>(p + ((uintptr_t(0) - reinterpret_cast<uintptr_t>(p)) & uintptr_t(255)));
     p = reinterpret_cast<char*>(r + count);
     return r;
 }
@@ -171,7 +173,7 @@ struct BinningView {
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
     float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
     uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_chained writes it, the backward reads it)
-    uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile, segment, list start, list length)
+    uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile y << 16 | tile x, segment, list start, list length)
     uint32_t* unit_done;  // [unit_cap] k_unit_blend_chained: the unit's final contribution is in memory (zeroed by k_tile_sort)
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
     float* unit_out;      // [unit_cap*5*64] forward partials per pixel: Cr, Cg, Cb, T_out, (last | done<<31)
@@ -183,10 +185,12 @@ struct BinningView {
         BinningView b;
         b.cap = cap;
         b.unit_cap = units_for(cap, T);
+        // (the descriptors come FIRST: their address does not depend on the capacity, so the blend backward, which
+        // learns the capacity from the device counts, can request a unit's descriptor together with the counts)
+        b.unit_tile = carve<uint4>(p, b.unit_cap);
         b.recs = carve<float4>(p, cap * 3);
         b.keys = carve<uint64_t>(p, cap);
         b.masks = carve<uint2>(p, cap);
-        b.unit_tile = carve<uint4>(p, b.unit_cap);
         b.unit_done = carve<uint32_t>(p, b.unit_cap);
         b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
         b.unit_out = carve<float>(p, b.unit_cap * 5 * kUnit);
