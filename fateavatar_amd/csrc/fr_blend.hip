@@ -923,6 +923,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __re
 // LDS per wave decides how many units are in flight per CU (the kernel is latency-bound: a unit is a chain of
 // dependent LDS round trips): 9.25 KB -> 16 waves per CU, enough for every unit of BASELINE config 2 to be resident.
 constexpr int kPairCap = 640;    // (q, w) slots per wave; denser units are processed in several record ranges
+constexpr int kARecs = 2;         // records per phase-A iteration (3 and 4 measured: no faster, the T / accum_rec chain is the iteration)
 
 struct SparseLds {
     float4 rec[kBatch * kRecQuads];   // the unit's records: (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, hi)   3 KB
@@ -1638,18 +1639,18 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
             }
 #endif
             if (__any(Bg != 0ull)) do {   // (do-while: as a while loop the compiler copies the loop-carried registers every trip)
-                bool act[2];
-                int j[2];
+                bool act[kARecs];
+                int j[kARecs];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < kARecs; k++) {
                     act[k] = Bg != 0ull;
                     j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
                     Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
                 }
-                float ar_e[2], cd[2];
-                uint32_t slot[2];
+                float ar_e[kARecs], cd[kARecs];
+                uint32_t slot[kARecs];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < kARecs; k++) {
                     const float4 q0 = S.rec[j[k] * kRecQuads + 0];
                     const float4 q1 = S.rec[j[k] * kRecQuads + 1];
                     const float4 q2 = S.rec[j[k] * kRecQuads + 2];
@@ -1666,7 +1667,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
                     slot[k] = act[k] ? slot[k] : (uint32_t)kPairCap + (uint32_t)lane;   // (idle lane: its own scratch slot, no exec games)
                 }
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < kARecs; k++) {
                     const float a_e = __builtin_amdgcn_fmed3f(ar_e[k], 0.f, 0.99f);
                     const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
                     T *= inv;                                                   // backward.cu:503
