@@ -7,13 +7,19 @@ With N > 1 and no torchrun environment the script re-executes itself through
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
 (one rank per GPU, RCCL); launched by torchrun directly it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
-A step = ONE frame of the hot path per GPU: `render(camera, gaussians, bg)` through the reference's Python API
-(activations inside the HIP preprocess kernels by default, `--torch-activations` for the reference's stock PyTorch ops)
-followed by the backward pass down to the raw Gaussian parameters, replayed as one HIP graph.  At N > 1 each rank
-renders its own view of the replicated Gaussians and every step ends with ONE RCCL all-reduce(AVG) of the flat gradient
-buffer.  The collective runs on RCCL's stream on a copy of the gradient and overlaps the next frame's
-kernels; step k+2 waits for the collective of step k (two buffers), and the timed region ends when the last one has
-finished — no all-reduce is skipped or left outside the clock.
+A FRAME is `render(camera, gaussians, bg)` through the reference's Python API (activations inside the HIP preprocess
+kernels by default, `--torch-activations` for the reference's stock PyTorch ops) followed by the backward pass down to the
+raw Gaussian parameters, replayed as one HIP graph.
+  N = 1: a step is `--rounds` (4) rounds of the views in flight (3, calibrated): the metric's configuration, configs[1].
+  N > 1: TWO modes are timed in the same run, each with its own K steps, and both are in the line (`dp.modes`):
+    literal    BASELINE configs[3] as written — every rank renders ONE view of the replicated Gaussians, then ONE RCCL
+               all-reduce(AVG) of the flat gradient buffer, and only then the next step starts (a synchronous
+               data-parallel optimisation step: the next frame needs the averaged gradient's update).  THIS is `value`.
+    amortised  `--rounds` x (views in flight) frames per rank and exchange, their mean folded into one of two exchange
+               buffers and all-reduced while the next step's frames render (local gradient accumulation; step k+2 waits
+               for the collective of step k; the timed region ends when the last one has finished).
+  The un-overlapped all-reduce time is reported for both payloads of SURVEY.md §8e: the generic parameter set (59 floats
+  per Gaussian, 23.6 MB at 100 k) and FateAvatar's 'gs' group (12 floats, 4.8 MB; train/optim.py:15-21).
 Workload (config.workload): BASELINE.json configs[1] — 100 000 Gaussians sampled on the head template, 512x512,
 SH degree 3 (M=16), synthetic data, random-init appearance.  Inputs are resident in HBM before the timed region.
 
@@ -28,8 +34,8 @@ The JSON line carries
   stage_frac   — every stage's algorithmic bytes / its measured time / 8 TB/s (formulas: STAGE_BYTES below).
   cpu_baseline — the CPU oracle (oracle/fr_oracle.c, OpenMP, kind "port": the reference has no CPU rasterizer) on a
                  bounded sample of the same frames: best thread count of a quick sweep, and one thread.
-  dp           — N > 1: ranks seen, backend, RCCL version, per-rank num_rendered, all-reduce payload and its
-                 un-overlapped duration.
+  dp           — N > 1: ranks seen, backend, RCCL version, per-rank num_rendered, both modes' frame rates, and the
+                 un-overlapped all-reduce duration per payload.
 
 FR_BENCH_STUB=1 replaces the rasterizer by a deterministic CPU gradient generator so that the N > 1 control flow can
 be exercised without GPUs (tests/test_bench_dp.py); such a line says "data": "stub" and is not a measurement.
@@ -156,9 +162,16 @@ class HipEngine:
         from fateavatar_amd.streams import concurrent_streams
         for v, st in zip(self.views, concurrent_streams(K, self.dev, also_with=[torch.cuda.current_stream(self.dev)])):
             v.stream = st
+        self.all_views = self.views
         self._render = render
         self.graph = None
         self.grads_read = [None, None]   # events: the exchange has read the gradient buffers of set 0 / 1
+
+    def set_mode(self, K, rounds):
+        """Which views take part in a step and how many rounds a step has (bench modes: literal = 1 view, 1 round)."""
+        self.views = self.all_views[:K]
+        self.K, self.rounds, self.round_no = K, max(1, rounds), 0
+        self.grads_read = [None, None]
 
     def frame(self, v=None, which=0, add=False):
         v = v or self.views[0]
@@ -226,6 +239,7 @@ class HipEngine:
             torch.distributed.all_reduce(r)
         self.K = int(torch.argmax(r).item()) + 1
         self.views = self.views[:self.K]
+        self.all_views = self.views
         self.calibration = {str(k + 1): round(float(x) / world, 1) for k, x in enumerate(r.tolist())}
 
     def enqueue_frame(self, views=None, count=True):
@@ -301,7 +315,7 @@ class StubEngine:
         self.rounds = max(1, args.rounds)
         self.K = max(1, args.in_flight)
         self.calibration = None
-        self.grads = [torch.zeros(1 << 12) for _ in range(self.K)]
+        self.grads = self.all_grads = [torch.zeros(1 << 12) for _ in range(self.K)]
         self.scene = None
         self.grads_read = None
 
@@ -310,6 +324,10 @@ class StubEngine:
 
     def calibrate(self, world):
         pass
+
+    def set_mode(self, K, rounds):
+        self.K, self.rounds, self.k = K, max(1, rounds), 0
+        self.grads = self.all_grads[:K]
 
     def enqueue_frame(self, views=None, count=True):
         for j, g in enumerate(self.grads):   # like the engine: a step's first round overwrites, the others add
@@ -444,37 +462,63 @@ def main():
     eng = (StubEngine if STUB else HipEngine)(args, rank, world, local)
     eng.prepare()
     eng.calibrate(world)
-    rounds = max(1, args.rounds)
     exchanging = world > 1 or args.exchange_at_1
-    xchg = GradExchange(eng.flat_grads()[0], rounds) if exchanging else None
+    K_best = eng.K
 
-    def step():
-        for _ in range(rounds):
-            eng.enqueue_frame()
+    def run_mode(K, rounds, overlap):
+        """`--warmup` untimed and `--steps` timed steps of one mode; returns (seconds, max over the ranks; exchange)."""
+        eng.set_mode(K, rounds)
+        xchg = GradExchange(eng.flat_grads()[0], rounds) if exchanging else None
+
+        def step():
+            for _ in range(rounds):
+                eng.enqueue_frame()
+            if xchg is not None:
+                xchg.submit(eng)
+                if not overlap:
+                    xchg.drain()
+
+        for _ in range(args.warmup):
+            step()
         if xchg is not None:
-            xchg.submit(eng)
-            if not args.overlap:
-                xchg.drain()
+            xchg.drain()
+        eng.sync()
+        dp.barrier()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if xchg is not None:
+            xchg.drain()          # the last collectives are inside the clock
+        eng.sync()
+        dp.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item()), xchg
 
-    for _ in range(args.warmup):
-        step()
-    if xchg is not None:
-        xchg.drain()
-    eng.sync()
-    dp.barrier()
-    eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if xchg is not None:
-        xchg.drain()          # the last collectives are inside the clock
-    eng.sync()
-    dp.barrier()
-    elapsed = time.perf_counter() - t0
+    rounds = max(1, args.rounds)
+    modes = {}
+    if exchanging:
+        # BASELINE configs[3] as written: one view per rank, exchange, then the next step (see the module docstring)
+        el, xl = run_mode(1, 1, False)
+        modes["literal"] = {"frames_per_step_per_gpu": 1, "rounds_per_step": 1, "frames_in_flight_per_gpu": 1, "overlap": False,
+                            "ms_per_step": round(el / args.steps * 1e3, 4), "value": round(world * args.steps / el, 2),
+                            "unit": "frames/s", "grad_checksum": float(xl.latest().double().abs().sum().item())}
+        ea, xchg = run_mode(K_best, rounds, args.overlap)
+        modes["amortised"] = {"frames_per_step_per_gpu": K_best * rounds, "rounds_per_step": rounds,
+                              "frames_in_flight_per_gpu": K_best, "overlap": bool(args.overlap),
+                              "ms_per_step": round(ea / args.steps * 1e3, 4),
+                              "value": round(world * K_best * rounds * args.steps / ea, 2), "unit": "frames/s"}
+        elapsed, frames_per_step = el, 1
+    else:
+        elapsed, xchg = run_mode(K_best, rounds, False)
+        frames_per_step = K_best * rounds
 
     # the same engine with ONE view in flight (what `value` measured until views overlapped): a reference point
     single = None
-    if not STUB and eng.K > 1 and not exchanging:
+    if not STUB and K_best > 1 and not exchanging:
         eng.sync()
         t1 = time.perf_counter()
         for _ in range(args.steps * rounds):
@@ -489,21 +533,31 @@ def main():
     if exchanging:
         import torch.distributed as dist
         reduced = xchg.latest().clone()
-        buf = torch.empty_like(reduced)
-        for _ in range(3):
-            dp.allreduce_mean_async(buf).wait()
-        eng.sync()
-        dp.barrier()
-        t1 = time.perf_counter()
-        n_ar = 20
-        for _ in range(n_ar):
-            dp.allreduce_mean_async(buf).wait()
-        eng.sync()
-        ar_s = (time.perf_counter() - t1) / n_ar
+
+        def time_allreduce(numel):
+            buf = torch.zeros(numel, dtype=reduced.dtype, device=reduced.device)
+            for _ in range(3):
+                dp.allreduce_mean_async(buf).wait()
+            eng.sync()
+            dp.barrier()
+            t1 = time.perf_counter()
+            n_ar = 20
+            for _ in range(n_ar):
+                dp.allreduce_mean_async(buf).wait()
+            eng.sync()
+            sec = (time.perf_counter() - t1) / n_ar
+            nbytes = numel * buf.element_size()
+            return {"payload_bytes": nbytes, "us": round(sec * 1e6, 1),
+                    "busbw_GBps": round(2 * (world - 1) / world * nbytes / sec / 1e9, 1)}
+
+        # the payload the steps exchanged (the generic set: 59 floats per Gaussian at SH degree 3), and FateAvatar's own
+        # optimizer group (opacity 1 + offset 1 + colour 3 + rotation 4 + scaling 3 = 12 floats, train/optim.py:15-21)
+        table = [dict(time_allreduce(reduced.numel()), what="flat gradient of the timed steps (generic parameter set)")]
+        if not STUB:
+            table.append(dict(time_allreduce(12 * args.P), what="FateAvatar 'gs' optimizer group, 12 floats per Gaussian"))
         mine = torch.tensor([counts["num_rendered"]], dtype=torch.int64, device=eng.dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        payload = reduced.numel() * reduced.element_size()
         rccl = None
         if dist.get_backend() == "nccl":
             try:
@@ -511,20 +565,17 @@ def main():
             except Exception:
                 rccl = None
         dpinfo = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
-                  "num_rendered_per_rank": [int(t.item()) for t in allr], "allreduce_payload_bytes": payload,
-                  "allreduce_us": round(ar_s * 1e6, 1),
-                  "allreduce_busbw_GBps": round(2 * (world - 1) / world * payload / ar_s / 1e9, 1),
+                  "num_rendered_per_rank": [int(t.item()) for t in allr],
+                  "allreduce_payload_bytes": table[0]["payload_bytes"], "allreduce_us": table[0]["us"],
+                  "allreduce_busbw_GBps": table[0]["busbw_GBps"], "allreduce_table": table,
                   "group_of_one": bool(args.exchange_at_1),
                   "overlap": bool(args.overlap),
+                  "modes": modes,
+                  "value_is": "modes.literal (BASELINE configs[3]: one view per rank per exchange, no overlap with the next step)",
                   "grad_checksum": float(reduced.double().abs().sum().item())}
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-
     if rank == 0:
-        fps = world * eng.K * rounds * args.steps / elapsed
+        fps = world * frames_per_step * args.steps / elapsed
         H = W = args.res
         M = (args.sh_degree + 1) ** 2
         R = counts["num_rendered"]
@@ -572,15 +623,15 @@ def main():
             "config": {"workload": f"{cfg_name}: {args.P} Gaussians on the head template, "
                                    f"{args.res}x{args.res}, SH deg {args.sh_degree} (M={M}), "
                                    "forward+backward through render() with a fixed dL/dpixel",
-                       "frames_per_step_per_gpu": eng.K * rounds,
-                       "rounds_per_step": rounds,
-                       "frames_in_flight_per_gpu": eng.K,
+                       "frames_per_step_per_gpu": frames_per_step,
+                       "rounds_per_step": 1 if exchanging else rounds,
+                       "frames_in_flight_per_gpu": 1 if exchanging else K_best,
                        "in_flight_calibration_frames_per_s": eng.calibration,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
-                       "parallelism": f"dp{world} ({rounds} round(s) of {eng.K} view(s) per GPU and step, each view on its own "
-                                      "stream; ONE flat-grad all-reduce of the step's mean gradient"
-                                      + (", overlapped with the next step's frames)" if world > 1 and args.overlap else ")"),
+                       "parallelism": (f"dp{world}: one view per GPU and step, then ONE flat-grad RCCL all-reduce(AVG), then the next "
+                                       "step (BASELINE configs[3]); the amortised mode is in dp.modes" if exchanging else
+                                       f"dp1 ({rounds} round(s) of {K_best} view(s) in flight per step, each view on its own stream)"),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,

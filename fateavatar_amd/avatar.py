@@ -29,7 +29,7 @@ from .model import TorchCamera
 from .optim import FusedAdam
 from .rasterizer import GradOut
 from .render import render
-from .loss import l1_loss_and_grad
+from .loss import l1_loss_and_grad, l1_workspace
 from .train import TrainStep
 
 # config/fateavatar.yaml:34-39 (group names of train/optim.py:15-21)
@@ -170,6 +170,7 @@ class AvatarStep(TrainStep):
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
         self._dimage = torch.zeros_like(self.gt)   # dL/dimage of the step
+        self._l1_ws = l1_workspace(self.dev)       # scratch of this frame's loss kernel (one per lane: loss.py)
         self.out = None
         self.use_graph = bool(use_graph)
         self._graph, self._eager_steps, self.overflows = None, 0, 0
@@ -195,7 +196,7 @@ class AvatarStep(TrainStep):
                                        pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
         frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom))
         out = render(L.cam, frame, self.bg)
-        _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage)   # see TrainStep
+        _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage, workspace=L._l1_ws)   # see TrainStep
         out["render"].backward(g)
         L.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
 
@@ -364,11 +365,12 @@ class AvatarBatchStep(AvatarStep):
             L.k = k
             if k == 0:     # lane 0 IS this object's own frame state
                 L.pc, L.cam, L.verts, L.gt, L.loss, L._dimage = self.pc, self.cam, self.verts, self.gt, self.loss, self._dimage
-                L.xyz_gradient_accum, L.denom = self.xyz_gradient_accum, self.denom
+                L.xyz_gradient_accum, L.denom, L._l1_ws = self.xyz_gradient_accum, self.denom, self._l1_ws
             else:
                 L.pc, L.cam, L.verts = self.pc.lane(), self.cam.clone(), self.verts.clone()
                 L.gt, L.loss, L._dimage = torch.zeros_like(self.gt), torch.zeros_like(self.loss), torch.zeros_like(self._dimage)
                 L.xyz_gradient_accum, L.denom = torch.zeros_like(self.xyz_gradient_accum), torch.zeros_like(self.denom)
+                L._l1_ws = l1_workspace(self.dev)   # (the lanes' loss kernels overlap: one scratch each, loss.py)
             L.out, L.graph = None, None
             L.stream, L.done = streams[k], torch.cuda.Event()
             self.lanes.append(L)

@@ -63,13 +63,33 @@ int launch_zero(void* ptr, size_t bytes, hipStream_t s)
     return FR_OK;
 }
 
+bool note_capture(fr_handle_impl* h, hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &st);
+    if (st != hipStreamCaptureStatusNone) h->captured = true;
+    return st != hipStreamCaptureStatusNone;
+}
+
+int release_buffer(fr_handle_impl* h, void* p, hipStream_t s)
+{
+    if (!p) return FR_OK;
+    if (h->captured) {   // a captured graph may replay on it: kept until fr_destroy
+        h->retired.push_back(p);
+        return FR_OK;
+    }
+    // (frames in flight still hold the old pointer in kernels already enqueued on this stream: free behind them)
+    FR_HIP(hipStreamSynchronize(s));
+    FR_HIP(hipFree(p));
+    return FR_OK;
+}
+
 int ensure_accum(fr_handle_impl* h, size_t P, hipStream_t s)
 {
     if (P <= h->accum_rows) return FR_OK;
-    // (frames in flight still hold the old pointer in kernels already enqueued on this stream: free behind them)
-    if (h->accum) {
-        FR_HIP(hipStreamSynchronize(s));
-        FR_HIP(hipFree(h->accum));
+    {
+        int rc = release_buffer(h, h->accum, s);
+        if (rc) return rc;
     }
     h->accum = nullptr, h->accum_rows = 0;
     const size_t rows = P + P / 4 + 1024;
@@ -98,17 +118,12 @@ int fr_create(fr_handle** out)
     FR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_counts_dev), h->host_counts, 0));
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&h->bwd_done, hipEventDisableTiming));
     FR_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     FR_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
     const char* bf = getenv("FR_BLEND_FWD");
-    h->dense_blend_fwd = bf && strcmp(bf, "dense") == 0;
     h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
-    const char* bb = getenv("FR_BLEND_BWD");
-    h->dense_blend_bwd = bb && strcmp(bb, "dense") == 0;
-    h->batch_blend_bwd = bb && strcmp(bb, "batch") == 0;
-    // the sparse backward reads the footprint masks the sparse forward leaves in the records
-    if (h->dense_blend_fwd) h->dense_blend_bwd = true;
     const char* pf = getenv("FR_DENSE_PAIRS_FWD");
     const char* pb = getenv("FR_DENSE_PAIRS_BWD");
     h->dense_pairs_fwd = pf ? (uint32_t)strtoul(pf, nullptr, 10) : kDensePairsFwd;
@@ -126,6 +141,7 @@ int fr_destroy(fr_handle* hh)
     if (!h) return FR_OK;
     (void)hipEventDestroy(h->counts_ready);
     if (h->frame_done) (void)hipEventDestroy(h->frame_done);
+    if (h->bwd_done) (void)hipEventDestroy(h->bwd_done);
     if (h->side_fork) (void)hipEventDestroy(h->side_fork);
     if (h->side_join) (void)hipEventDestroy(h->side_join);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -138,6 +154,7 @@ int fr_destroy(fr_handle* hh)
     if (h->tile_counters) (void)hipFree(h->tile_counters);
     if (h->accum) (void)hipFree(h->accum);
     if (h->key_buckets) (void)hipFree(h->key_buckets);
+    for (void* p : h->retired) (void)hipFree(p);
     delete h;
     return FR_OK;
 }
@@ -194,7 +211,11 @@ int fr_read_counts(fr_handle* hh, fr_counts* counts)
     fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(hh);
     if (!h || !counts) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument");
     *counts = *h->host_counts;
-    return FR_OK;   // (valid once the frame's stream has been synchronised: the caller's responsibility)
+    // (valid once the frame's stream has been synchronised: the caller's responsibility.)  A handle driven only with
+    // FR_FLAG_NO_WAIT learns here that the pinned slot holds a completed frame's counts: the next eager frame sizes the
+    // key buckets from them (word 4) and decides about the big-list sorter.
+    h->counts_seen = true;
+    return FR_OK;
 }
 
 int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const int32_t* radii, void* geometry,

@@ -4,13 +4,13 @@
 // Execution model: 8x8-pixel tiles = one 64-lane wavefront, one pixel per lane.  The sort runs in registers
 // (bitonic network across lanes and registers) and leaves, per tile, a contiguous array of 48-byte splat RECORDS in
 // blend order, cut into UNITS of 64 records — the independent work items of the blend kernels.
-//   * default blend path (sparse): k_unit_blend_chained (forward, ONE launch) and k_unit_blend_bwd_sparse (backward) walk
-//     only the (pixel, record) pairs named by the records' footprint masks, and switch to all-pairs loops for the
-//     units in which most pairs are named — see the section headers below;
-//   * all-pairs path (round 1; FR_BLEND_FWD=dense / FR_BLEND_BWD=dense): k_unit_tseg + k_unit_blend + k_tile_combine and
-//     k_unit_blend_bwd stream every record past every pixel with wave-uniform LDS reads and reduce the gradient
-//     partials across the wave (reduce_scatter_36).  Kept as the reference implementation the sparse kernels were
-//     validated against on the GPU, and for scenes whose splats cover whole tiles.
+//   * k_unit_blend_chained (forward, ONE launch) and k_unit_blend_bwd_sparse (backward) walk only the (pixel, record) pairs
+//     named by the records' footprint masks, and switch to an all-pairs loop for the units in which most pairs are named
+//     (blend_unit_dense_local / bwd_unit_all_pairs: wave-uniform record reads, and in the backward a reduce-scatter of the
+//     36 gradient partials of four records, reduce_scatter_36) — see the section headers below.
+// Round 1's all-pairs kernels (k_unit_tseg + k_unit_blend + k_tile_combine, k_unit_blend_bwd) and round 3's batched
+// length-sorted backward experiment (four units per workgroup, -44 % walk iterations but slower: its long waves ran
+// latency-bound) are in the git history, not here.
 #include "fr_common.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -531,25 +531,9 @@ __device__ __forceinline__ RecRegs fetch_record(const float4* __restrict__ src, 
 // ================================================================== unit-parallel blending
 // A tile's sorted list is cut into UNITS of 64 records.  Every unit is an independent wavefront-sized
 // work item, so the serial instruction stream of a wave is bounded by 64 records no matter how long a
-// tile's list is (a wave issues roughly one instruction per 4 cycles: with one wave per TILE the longest
-// list set the kernel time).  Front-to-back compositing is a scan, so three light passes restore the
-// exact sequential semantics of the reference:
-//   A  k_unit_tseg     per unit and pixel: product of (1 - alpha) over the unit's blendable records
-//   B  k_unit_blend    per unit: T_in = product of the previous units' products; blend the unit's records
-//                      with the reference's tests (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) starting
-//                      from T_in; leave partial colour, running T, last contributor, termination flag
-//   C  k_tile_combine  per tile: sum the partial colours, pick final T / contributor count at the first
-//                      terminated unit, write the image, and leave for each unit the backward's entry state
-// The backward then runs every unit independently from that state.
-
-__device__ __forceinline__ void stage_unit(float4* s_rec, const float4* __restrict__ src, uint32_t base, uint32_t n,
-                                           int lane)
-{
-    const RecRegs r = fetch_record(src, base + (uint32_t)lane, n);
-    s_rec[lane * kRecQuads + 0] = r.q0;
-    s_rec[lane * kRecQuads + 1] = r.q1;
-    s_rec[lane * kRecQuads + 2] = r.q2;
-}
+// tile's list is (with one wave per TILE the longest list set the kernel time).  Front-to-back compositing is a
+// scan over the units of a tile: the forward resolves it inside one launch (k_unit_blend_chained) and leaves, per
+// unit and pixel, the state the backward starts from, so that the backward runs every unit independently.
 
 struct UnitInfo {
     uint32_t tx, ty, seg, start, n, base, m;  // tile position, segment index, list start, list length, first record, records in unit
@@ -578,165 +562,8 @@ __device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint4* __restric
     return i;
 }
 
-// The unit kernels run 4 independent waves per workgroup (workgroup dispatch rate, not work, bounded the
-// one-wave-per-workgroup version) and stride over the units by the number of waves in the grid.
-constexpr int kWavesPerWG = 4;
-#define FR_UNIT_LOOP_BEGIN                                                                       \
-    __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];                                \
-    const int lane = threadIdx.x & 63;                                                           \
-    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                     \
-    float4* s_rec = s_rec_all[wave_in_wg];                                                       \
-    const uint32_t nu = counts->num_units;                                                       \
-    const uint32_t wave_stride = gridDim.x * kWavesPerWG;                                        \
-    for (uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg; u < nu; u += wave_stride) {
-
-// ---- pass A
-__global__ void __launch_bounds__(256) k_unit_tseg(const DeviceCounts* __restrict__ counts,
-                                                  const uint4* __restrict__ unit_tile,
-                                                  const uint32_t* __restrict__ unit_offset,
-                                                  const uint32_t* __restrict__ tile_offset,
-                                                  const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                  float* __restrict__ unit_tseg)
-{
-    FR_UNIT_LOOP_BEGIN
-    const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
-    if (ui.base + kUnit >= ui.n) continue;  // the last unit's product is never needed
-    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
-    const float fx = (float)ui.px, fy = (float)ui.py;
-    float t = 1.0f;
-    for (uint32_t j = 0; j < (uint32_t)kUnit; j += kGroup) {
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
-            const float2 q1 = *reinterpret_cast<const float2*>(&s_rec[(j + k) * kRecQuads + 1]);
-            const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-            const float alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
-            const bool ok = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            t = ok ? t * (1.f - alpha) : t;
-        }
-    }
-    unit_tseg[(size_t)u * kUnit + lane] = t;
-    }
-}
-
-// ---- pass B (reference: renderCUDA, forward.cu:261-374, restricted to one unit)
-__global__ void __launch_bounds__(256) k_unit_blend(const DeviceCounts* __restrict__ counts,
-                                                   const uint4* __restrict__ unit_tile,
-                                                   const uint32_t* __restrict__ unit_offset,
-                                                   const uint32_t* __restrict__ tile_offset,
-                                                   const float4* __restrict__ recs, int W, int H, int tiles_x,
-                                                   const float* __restrict__ unit_tseg, float* __restrict__ unit_out)
-{
-    FR_UNIT_LOOP_BEGIN
-    const UnitInfo ui = unit_info(u, unit_tile, unit_offset, tile_offset, W, H, tiles_x, lane);
-    stage_unit(s_rec, recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
-    const float fx = (float)ui.px, fy = (float)ui.py;
-
-    float T = 1.0f;
-    for (uint32_t p = u - ui.seg; p < u; p++) T *= unit_tseg[(size_t)p * kUnit + lane];
-    // T_in < 1e-4 means an earlier unit already terminated this pixel: nothing here can be blended
-    bool dead = !ui.inside || (T < 0.0001f);
-    bool term = false;  // terminated inside THIS unit
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f;
-    uint32_t last = 0;
-    for (uint32_t j = 0; j < ui.m; j += kGroup) {
-        if (__all(dead)) break;
-        float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
-        bool ok[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            const float4 q0 = s_rec[(j + k) * kRecQuads + 0];
-            const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
-            const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
-            const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
-            ok[k] = !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
-            cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
-        }
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            bool c = !dead && ok[k];
-            const float test_T = T * (1.f - alpha[k]);
-            const bool fin = c && (test_T < 0.0001f);
-            term = term || fin;
-            dead = dead || fin;
-            c = c && !fin;
-            const float w = c ? alpha[k] * T : 0.f;
-            Cr += cr[k] * w;
-            Cg += cg[k] * w;
-            Cb += cb[k] * w;
-            T = c ? test_T : T;
-            last = c ? (ui.base + j + k + 1u) : last;
-        }
-    }
-    float* o = unit_out + (size_t)u * 5 * kUnit + lane;
-    o[0] = Cr;
-    o[kUnit] = Cg;
-    o[2 * kUnit] = Cb;
-    o[3 * kUnit] = T;
-    o[4 * kUnit] = __uint_as_float(last | (term ? 0x80000000u : 0u));
-    }
-}
-
-// ---- pass C: one wave per tile
-__global__ void __launch_bounds__(256) k_tile_combine(const DeviceCounts* __restrict__ counts,
-                                                     const uint32_t* __restrict__ unit_offset,
-                                                     const uint32_t* __restrict__ tile_total, uint32_t n_tiles, int W,
-                                                     int H, int tiles_x, const float* __restrict__ bg,
-                                                     const float* __restrict__ unit_out,
-                                                     float4* __restrict__ unit_state, float* __restrict__ out_color,
-                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
-{
-    if (counts->overflow) return;
-    const uint32_t tile = blockIdx.x * kWavesPerWG + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const int lane = threadIdx.x & 63;
-    const int px = (int)(tile % (uint32_t)tiles_x) * kTile + (lane & 7);
-    const int py = (int)(tile / (uint32_t)tiles_x) * kTile + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const uint32_t u0 = unit_offset[tile], u1 = u0 + (tile_total[tile] + kUnit - 1) / kUnit;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
-    uint32_t ncon = 0;
-    bool finished = false;
-    for (uint32_t u = u0; u < u1; u++) {
-        const float* o = unit_out + (size_t)u * 5 * kUnit + lane;
-        Cr += o[0];
-        Cg += o[kUnit];
-        Cb += o[2 * kUnit];
-        const uint32_t lf = __float_as_uint(o[4 * kUnit]);
-        if (!finished) {
-            Tf = o[3 * kUnit];
-            if (lf & 0x7fffffffu) ncon = lf & 0x7fffffffu;
-            finished = (lf & 0x80000000u) != 0;
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = Tf;
-        n_contrib[pix] = ncon;
-        out_color[pix] = Cr + Tf * bg[0];
-        out_color[HW + pix] = Cg + Tf * bg[1];
-        out_color[2 * HW + pix] = Cb + Tf * bg[2];
-    }
-    // backward entry state of each unit: colour accumulated BEHIND the unit, normalised by the
-    // transmittance at the unit's far boundary (= what the reference's accum_rec recurrence yields there)
-    float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-    for (uint32_t u = u1; u-- > u0;) {
-        const float* o = unit_out + (size_t)u * 5 * kUnit + lane;
-        const float To = o[3 * kUnit];
-        // A pixel that was already dead when it entered unit u carries To = the plain product of the earlier units'
-        // (1 - alpha) products, which is below 1e-4 and may have underflowed to 0 or a denormal: its state is
-        // (0, 0, 0, To) — nothing behind it contributes — not 0 * rcp(0) = NaN.  A pixel that was alive at the
-        // unit's entry has To >= 1e-4 (T only ever takes values that passed the reference's T test).
-        const float inv = (To >= 0.0001f) ? __builtin_amdgcn_rcpf(To) : 0.f;
-        unit_state[(size_t)u * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To);
-        Sr += o[0];
-        Sg += o[kUnit];
-        Sb += o[2 * kUnit];
-    }
-}
+constexpr int kWavesPerWG = 4;   // the unit kernels run 4 independent waves per workgroup (workgroup dispatch rate, not work,
+                                 // bounded the one-wave-per-workgroup version)
 
 // ------------------------------------------------------------------ blend backward
 // reference: renderCUDA, backward.cu:399-557.  Per (pixel, Gaussian) pair the arithmetic is the
@@ -810,7 +637,7 @@ __device__ __forceinline__ int bitrev6(int l)
 
 // All 64 x 64 pairs of one staged unit, back to front, four records at a time: every lane (= pixel) evaluates the four
 // records, the 36 partial sums are reduce-scattered over the wave and 36 lanes issue one atomic each.  T / A enter as
-// the state behind the unit (see k_unit_blend_bwd); lanes with lim <= 0 carry T = A = 0.
+// the state behind the unit (see k_unit_blend_bwd_sparse); lanes with lim <= 0 carry T = A = 0.
 __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_rec, int m, int lim, float fx, float fy, float T,
                                                    float A, float T_final, float bg_dot_dpixel, float dpr, float dpg,
                                                    float dpb, float* __restrict__ accum, int lane, int vv, int own_u, int own_c)
@@ -870,46 +697,9 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
     }
 }
 
-__global__ void __launch_bounds__(256) k_unit_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                       void* binning, int W, int H, const float* __restrict__ bg,
-                                                       const float* __restrict__ dL_dpix, float* __restrict__ accum)
-{
-    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
-    // which (Gaussian-in-group, component) total this lane owns after the reduce-scatter
-    const int vv = bitrev6((int)(threadIdx.x & 63));
-    const int own_u = vv / 9, own_c = vv - own_u * 9;
-    FR_UNIT_LOOP_BEGIN
-    const UnitInfo ui = unit_info(u, b.unit_tile, v.unit_offset, v.tile_offset, W, H, v.tiles_x, lane);
-    const size_t pix = ui.inside ? (size_t)ui.py * W + ui.px : 0, HW = (size_t)H * W;
-    const uint32_t last = ui.inside ? v.n_contrib[pix] : 0u;
-    // nothing at or behind the deepest contributor of any pixel of the tile can matter
-    if (!__any(last > ui.base)) continue;
-
-    stage_unit(s_rec, b.recs + (size_t)ui.start * kRecQuads, ui.base, ui.n, lane);
-    const float fx = (float)ui.px, fy = (float)ui.py;
-    const float T_final = ui.inside ? v.final_T[pix] : 0.f;
-    const float4 st = b.unit_state[(size_t)u * kUnit + lane];
-    float T = st.w;
-    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
-    if (ui.inside) dpr = dL_dpix[pix], dpg = dL_dpix[HW + pix], dpb = dL_dpix[2 * HW + pix];
-    const float bg_dot_dpixel = (bg[0] * dpr + bg[1] * dpg) + bg[2] * dpb;
-    // The reference's accum_rec (colour blended behind the current Gaussian, backward.cu:515) only ever enters
-    // through its dot product with dL/dpixel, and its recurrence is linear: carry that scalar instead of three
-    // channels.  A = accum_rec . dL_dpixel, entering the unit from behind.
-    const int m = (int)ui.m;
-    const int lim = (int)last - (int)ui.base;  // records of this unit at or behind the pixel's last contributor do nothing
-    // a lane with nothing to do in this unit (pixel terminated earlier, or outside the image) must carry FINITE
-    // state: its alpha is forced to 0 below, and 0 * NaN would still poison the wave reduction
-    float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;
-    if (lim <= 0) T = 0.f;
-
-    bwd_unit_all_pairs(s_rec, m, lim, fx, fy, T, A, T_final, bg_dot_dpixel, dpr, dpg, dpb, accum, lane, vv, own_u, own_c);
-    }
-}
-
 // ================================================================== sparse blend backward
 // Only ~1 in 7 (pixel, record) pairs of an 8x8 tile passes the alpha test at BASELINE config 2 (splats a few pixels
-// wide); k_unit_blend_bwd above still evaluates all 64 x 64 of a unit and reduces 36 mostly-zero values across the
+// wide); the all-pairs form above evaluates all 64 x 64 of a unit and reduces 36 mostly-zero values across the
 // wave for every four records.  This kernel only touches the pairs the records' footprint masks name
 // (footprint_mask(), a superset of the pairs that pass; the exact tests are applied to each), in two phases per unit:
 //   A  lane = PIXEL: walks the records whose mask holds the pixel, back to front (the reference's order), carrying
@@ -1004,9 +794,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 }
 
 // ================================================================== sparse forward: one launch per frame
-// k_unit_tseg + k_unit_blend + k_tile_combine above evaluate all 64 x 64 (pixel, record) pairs of a unit, twice, in
-// three launches.  The sparse forward walks only the pairs the records' footprint masks name (see the sparse backward
-// below), and walks them ONCE: compositing is linear in the transmittance entering a unit, so every unit, as an
+// Round 1 evaluated all 64 x 64 (pixel, record) pairs of a unit, twice, in three launches.  The sparse forward walks
+// only the pairs the records' footprint masks name (see the sparse backward above), and walks them ONCE: compositing is linear in the transmittance entering a unit, so every unit, as an
 // independent wave, first blends its records LOCALLY (T starts at 1, no termination test: partial colour, product of
 // (1 - alpha), last blended record), then learns the transmittance entering it from the products of the units in front
 // of it and scales.  Only a pixel whose transmittance crosses the reference's 1e-4 threshold INSIDE the unit
@@ -1134,7 +923,7 @@ __device__ __forceinline__ float load_row(const float* p)
     return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
-// One wave, one tile: the image, and the backward entry state of every unit (see k_tile_combine), from the units' final
+// One wave, one tile: the image, and the backward entry state of every unit, from the units' final
 // contributions.  Pure loads and adds: the rows of 8 units are requested together.
 template <bool COHERENT>
 __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, uint32_t u0, uint32_t nu, const float* g_out,
@@ -1178,7 +967,7 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
 #pragma unroll
             for (int k = R - 1; k >= 0; k--) {
                 if ((uint32_t)k < nu) {
-                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // guard: k_tile_combine
+                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // (dead on entry: T may have underflowed)
                     unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
                     Sr += cr[k], Sg += cg[k], Sb += cb[k];
                 }
@@ -1584,6 +1373,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
         FR_STAMP(3);
         FR_STAMPV(9, npairs);
+#ifdef FR_BWD_TRACE   // (tools/diag/bwd_lens.py: the walk lengths of every unit, for scheduling simulations)
+        if (u < 8192u) g_bwd_lens[u * 128u + lane] = (unsigned char)__popcll(Bp), g_bwd_lens[u * 128u + 64u + lane] = (unsigned char)cnt;
+#endif
 
         const float T_final = inside ? Tf_raw : 0.f;
         const float dpr = inside ? d0 : 0.f, dpg = inside ? d1 : 0.f, dpb = inside ? d2 : 0.f;
@@ -1591,7 +1383,7 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
         const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
         const float tfb = -T_final * bgd;                                      // -T_final * (bg . dL_dpixel)
         float T = lim > 0 ? st.w : 0.f;
-        float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel (see k_unit_blend_bwd)
+        float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel: the recurrence is linear, one scalar is carried
         if (dense) {
 #ifdef FR_BWD_STATS
             if (lane == 0) atomicAdd(&const_cast<DeviceCounts*>(counts)->pair_hist[4], 1u);   // units in the all-pairs form
@@ -1746,331 +1538,6 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
     }
 }
 
-// ================================================================== batched sparse blend backward
-// k_unit_blend_bwd_sparse above gives every unit its own wave: in both of its walks the wave runs for as long as its
-// LONGEST lane (the pixel with the most records, the record with the most pixels), and at BASELINE config 2 the average
-// lane holds a pair in only 31 % / 33 % of those iterations.  Here a WORKGROUP takes four units together and deals the
-// 256 pixel chains (phase A) and the 256 record walks (phase B) out again BY LENGTH: a counting sort over the lengths
-// (one returning LDS atomic per task, a 65-bin scan) puts the 64 longest tasks into wave 0, the next 64 into wave 1,
-// and so on, so the lanes of a wave finish together and a wave's trip count is simply its first lane's.  The walks
-// themselves are those of the per-unit kernel (same expressions, same order per pixel and per record, so the sums only
-// differ by the order of the atomics); what changes is which lane walks what.
-//   LDS per workgroup (40.8 KB -> four workgroups = 16 waves per CU): the four units' records (48 B each; a unit's
-//   region later holds its 64 x 9 gradient sums), the (q, w) pair slots of the whole batch, per (unit, pixel) the walk
-//   set and the entry state, the two task orders and histograms.
-//   A batch whose units name more pairs than there are slots is processed in several groups of consecutive units; a
-//   unit above the all-pairs threshold is left to its own wave (bwd_unit_all_pairs) after the sparse ones.
-constexpr int kBU = 4;                  // units per workgroup (= waves per workgroup)
-constexpr int kBatchPairCap = 2400;     // (q, w) slots per workgroup
-
-struct BatchLds {
-    float4 rec[kBU][kBatch * kRecQuads];   // (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, mask hi)   12 KB
-    float2 pair[kBatchPairCap + 2];        // (q, w) of every pair, record-major within a unit, units of a group in a row   18.75 KB
-                                           // (+ 2: the 16-byte zeroing stores may reach one slot past the last)
-    float4 pst[kBU * 64][2];               // per (unit, pixel): (walk set lo, hi, T, A) (dL_dpixel r, g, b, tfb)   8 KB
-    uint32_t hist[2][68];                  // task lengths 0..64: counts, then start positions (descending length)
-    uint8_t order[2][kBU * 64];            // tasks by descending length: phase A (unit << 6 | pixel), phase B (unit << 6 | record)
-    float2 origin[kBU];                    // tile origin of every unit
-    uint32_t unit_pairs[kBU];              // pair slots every unit needs (0: nothing to walk)
-};
-static_assert(sizeof(BatchLds) <= 40960, "four workgroups per CU");
-
-#ifdef FR_BWD_TRACE
-#define FR_BSTAMP(K) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kBU + w) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
-#define FR_BSTAMPV(K, V) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kBU + w) * 16 + (K)] = (unsigned long long)(V); } while (0)
-#else
-#define FR_BSTAMP(K) do { } while (0)
-#define FR_BSTAMPV(K, V) do { } while (0)
-#endif
-
-__global__ void __launch_bounds__(64 * kBU, 4) k_batch_blend_bwd(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                                  void* binning, int W, int H, const float* __restrict__ bg,
-                                                                  const float* __restrict__ dL_dpix, float* __restrict__ accum,
-                                                                  uint32_t dense_pairs)
-{
-    __shared__ BatchLds S;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FR_BSTAMP(0);
-    const uint32_t nu = counts->num_units;
-    if (blockIdx.x * (uint32_t)kBU >= nu) return;   // (the whole workgroup)
-    const BinningView b = BinningView::make(binning, (size_t)counts->capacity, (size_t)v.tiles_x * v.tiles_y);
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const TransposeConsts tc = transpose_consts(lane);
-    // (normally one batch per workgroup: the grid covers the units of BASELINE config 2 four times over)
-    for (uint32_t batch = blockIdx.x; batch * (uint32_t)kBU < nu; batch += gridDim.x) {
-    if (batch != blockIdx.x) __syncthreads();   // (the previous batch is flushed: LDS is free again)
-    const uint32_t u = batch * kBU + (uint32_t)w;
-    const bool has = u < nu;
-    if (threadIdx.x < 2 * 68) (&S.hist[0][0])[threadIdx.x] = 0u;
-
-    // ---- this wave's unit: every load below depends on the descriptor only, and all of them are in flight together
-    const uint4 d = b.unit_tile[has ? u : 0u];
-    const uint32_t base = d.y * kUnit, start = d.z, n = d.w;
-    const uint32_t m = has ? min((uint32_t)kUnit, n - base) : 0u;
-    const int tx0 = (int)(d.x & 0xFFFFu) * kTile, ty0 = (int)(d.x >> 16) * kTile;
-    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-    const bool inside = has && px < W && py < H;
-    const size_t pix = inside ? (size_t)py * W + px : 0, HW = (size_t)H * W;
-    const uint32_t ridx = min(base + (uint32_t)lane, n ? n - 1u : 0u);    // (clamped: the loads stay unconditional)
-    const float4* rsrc = b.recs + ((size_t)start + ridx) * kRecQuads;
-    const uint32_t last_raw = v.n_contrib[pix];
-    const float4 rq0 = rsrc[0], rq1 = rsrc[1];
-    const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
-    const uint2 mraw = b.masks[(size_t)start + ridx];
-    const float4 st = b.unit_state[(size_t)(has ? u : 0u) * kUnit + lane];
-    const float Tf_raw = v.final_T[pix];
-    const float d0 = dL_dpix[pix], d1 = dL_dpix[HW + pix], d2 = dL_dpix[2 * HW + pix];
-    __syncthreads();   // (the histograms are zero)
-    FR_BSTAMP(1);
-
-    const uint32_t last = inside ? last_raw : 0u;
-    const bool live = has && __any(last > base);   // nothing at or behind the deepest contributor of the tile can matter
-    const bool valid_rec = live && base + (uint32_t)lane < n;
-    const uint2 mj = valid_rec ? mraw : make_uint2(0u, 0u);
-    const u64 Mj = ((u64)mj.y << 32) | mj.x;
-    const uint32_t cnt = (uint32_t)__popcll(Mj);
-    const uint32_t cum = wave_incl_scan_u32(cnt);
-    const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)cum, 63);
-    // all-pairs form, by this wave alone, at the end (also whatever would not fit the pair slots on its own)
-    const bool dense = live && npairs > min(dense_pairs, (uint32_t)kBatchPairCap);
-    const bool sparse = live && !dense;
-    const uint32_t my_id = __float_as_uint(rq2.y);
-    {
-        // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch)
-        S.rec[w][lane * kRecQuads + 0] = make_float4(valid_rec ? rq0.x : 0.f, valid_rec ? rq0.y : 0.f, valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
-        S.rec[w][lane * kRecQuads + 1] = make_float4(valid_rec ? rq1.x : 0.f, valid_rec ? rq1.y : 0.f, valid_rec ? rq1.z : 0.f, valid_rec ? rq1.w : 0.f);
-        // the all-pairs form reads (colour b, id) from here; the walks read (colour b, first slot, mask)
-        S.rec[w][lane * kRecQuads + 2] = make_float4(rq2.x, dense ? rq2.y : __uint_as_float(cum - cnt), __uint_as_float(sparse ? mj.x : 0u),
-                                                     __uint_as_float(sparse ? mj.y : 0u));
-    }
-    const uint2 bt = transpose_bits64(sparse ? mj : make_uint2(0u, 0u), lane, tc);
-    const int lim = (int)last - (int)base;      // records [0, lim) of this unit can contribute to this pixel
-    u64 Bp = ((u64)bt.y << 32) | bt.x;
-    Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
-    const float T_final = inside ? Tf_raw : 0.f;
-    const float dpr = inside ? d0 : 0.f, dpg = inside ? d1 : 0.f, dpb = inside ? d2 : 0.f;
-    const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
-    const float T_in = lim > 0 ? st.w : 0.f;
-    const float A_in = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;   // accum_rec . dL_dpixel (see k_unit_blend_bwd)
-    S.pst[w * 64 + lane][0] = make_float4(__uint_as_float((uint32_t)Bp), __uint_as_float((uint32_t)(Bp >> 32)), T_in, A_in);
-    S.pst[w * 64 + lane][1] = make_float4(dpr, dpg, dpb, -T_final * bgd);
-    if (lane == 0) {
-        S.unit_pairs[w] = sparse ? npairs : 0u;
-        S.origin[w] = make_float2((float)tx0, (float)ty0);
-    }
-    // every slot a record's mask names is read in phase B; phase A leaves out the pairs behind a pixel's last contributor
-    const bool all_written = __all(inside && lim >= (int)m);
-    __syncthreads();   // (records, pixel states and pair counts of the four units are in LDS)
-    FR_BSTAMP(2);
-    FR_BSTAMPV(9, npairs);
-
-    const uint32_t up0 = S.unit_pairs[0], up1 = S.unit_pairs[1], up2 = S.unit_pairs[2], up3 = S.unit_pairs[3];
-    const int fl_rec = lane / 9, fl_c = lane - fl_rec * 9;   // which (record-in-septet, component) this lane flushes
-    float* sums = reinterpret_cast<float*>(&S.rec[0][0]);    // unit g's sums: the first 64 x 9 floats of ITS record region
-    constexpr int kRecFloats = kBatch * kRecQuads * 4;       // floats per unit region
-
-    if (up0 + up1 + up2 + up3 != 0u) {
-        // ---- groups of consecutive units whose pairs fit the slots (normally ONE group: all four)
-        for (int g0 = 0; g0 < kBU;) {
-            // slot0[g]: first pair slot of unit g inside the group (units outside the group: unused)
-            uint32_t slot0[kBU] = {0u, 0u, 0u, 0u};
-            int g1 = g0;
-            {
-                const uint32_t up[kBU] = {up0, up1, up2, up3};
-                uint32_t acc = 0;
-#pragma unroll
-                for (int g = 0; g < kBU; g++) {
-                    const bool take = g >= g0 && g == g1 && (g == g0 || acc + up[g] <= (uint32_t)kBatchPairCap);
-                    slot0[g] = acc;
-                    acc += take ? up[g] : 0u;
-                    g1 = take ? g + 1 : g1;
-                }
-            }
-            const bool mine = w >= g0 && w < g1 && sparse;   // this wave's unit is part of the group
-            const uint32_t my_slot0 = w == 0 ? slot0[0] : w == 1 ? slot0[1] : w == 2 ? slot0[2] : slot0[3];
-            if (g0 > 0) {   // (a further group: the histograms start from zero again)
-                __syncthreads();
-                if (threadIdx.x < 2 * 68) (&S.hist[0][0])[threadIdx.x] = 0u;
-                __syncthreads();
-            }
-            // ---- counting sort of the tasks by length, longest first: rank inside the length's bin ...
-            const uint32_t lenA = mine ? (uint32_t)__popcll(Bp) : 0u, lenB = mine ? cnt : 0u;
-#ifdef FR_BWD_TRACE
-            if (mine && u < 8192u) g_bwd_lens[u * 128u + lane] = (unsigned char)lenA, g_bwd_lens[u * 128u + 64u + lane] = (unsigned char)lenB;
-#endif
-            // (tasks of length 0 need no place: hundreds of lanes adding to ONE LDS word take ~100 cycles each)
-            const uint32_t rankA = lenA ? atomicAdd(&S.hist[0][lenA], 1u) : 0u, rankB = lenB ? atomicAdd(&S.hist[1][lenB], 1u) : 0u;
-            if (mine && !all_written)
-                for (uint32_t z = (uint32_t)lane; z * 2u < npairs + 1u; z += 64u) {
-                    float2* zp = S.pair + ((my_slot0 + z * 2u) & ~1u);   // (16-byte aligned: may clear the slot in front, still unwritten)
-                    *reinterpret_cast<float4*>(zp) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            __syncthreads();
-            // ... bin starts: bins in descending length order (waves 0 and 1, one histogram each)
-            if (w < 2) {
-                const uint32_t c = S.hist[w][64 - lane];           // lane l <-> length 64 - l
-                const uint32_t inc = wave_incl_scan_u32(c);
-                const uint32_t c0 = S.hist[w][0];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                S.hist[w][64 - lane] = inc - c;
-                if (lane == 63) S.hist[w][0] = inc, (void)c0;      // length 0 comes last
-            }
-            __syncthreads();
-            if (lenA) S.order[0][S.hist[0][lenA] + rankA] = (uint8_t)(w * 64 + lane);
-            if (lenB) S.order[1][S.hist[1][lenB] + rankB] = (uint8_t)(w * 64 + lane);
-            const uint32_t totalA = S.hist[0][0], totalB = S.hist[1][0];   // tasks with something to walk
-            __syncthreads();
-            FR_BSTAMP(3);
-
-            // ---- phase A: lane = one (unit, pixel) chain, back to front over the records its walk set names.  Two
-            // records per iteration (independent alpha evaluations; only the T / accum_rec recurrence is serial).
-            {
-                const bool have = (uint32_t)(w * 64 + lane) < totalA;
-                const uint32_t t = have ? S.order[0][w * 64 + lane] : 0u;
-                const uint32_t g = t >> 6, p = t & 63u;
-                const float4 s0 = S.pst[t][0], s1 = S.pst[t][1];
-                const float2 org = S.origin[g];
-                u64 Bg = ((u64)__float_as_uint(s0.y) << 32) | __float_as_uint(s0.x);
-                Bg = have ? Bg : 0ull;
-                // the pixels of a record's mask below this one: its rank among the record's pairs
-                const uint32_t below_lo = p < 32u ? (1u << p) - 1u : ~0u, below_hi = p < 32u ? 0u : (1u << (p - 32u)) - 1u;
-                float T = s0.z, A = s0.w;
-                const float ar = s1.x, ag = s1.y, ab = s1.z, tfb = s1.w;
-                const float fx = org.x + (float)(p & 7u), fy = org.y + (float)(p >> 3);
-                const float4* R = &S.rec[0][0] + g * (kBatch * kRecQuads);
-                uint32_t gs0 = slot0[0];
-#pragma unroll
-                for (int k = 1; k < kBU; k++) gs0 = g == (uint32_t)k ? slot0[k] : gs0;
-                const uint32_t nA = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(Bg)) + 1u) >> 1;
-                FR_BSTAMPV(10, nA);
-                for (uint32_t it = 0; it < nA; it++) {
-                    bool act[2];
-                    int j[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        act[k] = Bg != 0ull;
-                        j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
-                        Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
-                    }
-                    float ar_e[2], cd[2];
-                    uint32_t slot[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const float4 q0 = R[j[k] * kRecQuads + 0];
-                        const float4 q1 = R[j[k] * kRecQuads + 1];
-                        const float4 q2 = R[j[k] * kRecQuads + 2];
-                        const float dx = q0.x - fx, dy = q0.y - fy;
-                        const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-                        const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
-                        const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
-                        cd[k] = (q1.z * ar + q1.w * ag) + q2.x * ab;                 // colour . dL_dpixel
-                        ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity
-                        // slot = unit's first slot + record's first slot + rank of this pixel among the record's pixels
-                        slot[k] = (uint32_t)__popc(__float_as_uint(q2.w) & below_hi) +
-                                  ((uint32_t)__popc(__float_as_uint(q2.z) & below_lo) + (__float_as_uint(q2.y) + gs0));
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const float a_e = __builtin_amdgcn_fmed3f(ar_e[k], 0.f, 0.99f);
-                        const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
-                        T *= inv;                                                   // backward.cu:503
-                        const float e = cd[k] - A;
-                        const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
-                        A += a_e * e;
-                        if (act[k]) S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
-                    }
-                }
-            }
-            __syncthreads();   // (every pair of the group is in its slot)
-            FR_BSTAMP(4);
-
-            // ---- phase B: lane = one (unit, record): walks the pixels of its mask (two per iteration), its pairs are
-            // consecutive slots; nine sums in registers
-            {
-                const bool have = (uint32_t)(w * 64 + lane) < totalB;
-                const uint32_t t = have ? S.order[1][w * 64 + lane] : 0u;
-                const uint32_t g = t >> 6;
-                const float4* R = &S.rec[0][0] + g * (kBatch * kRecQuads);
-                const float4 q0 = R[(t & 63u) * kRecQuads + 0];
-                const float4 q2 = R[(t & 63u) * kRecQuads + 2];
-                const float2 org = S.origin[g];
-                u64 Mg = have ? (((u64)__float_as_uint(q2.w) << 32) | __float_as_uint(q2.z)) : 0ull;
-                uint32_t gs0 = slot0[0];
-#pragma unroll
-                for (int k = 1; k < kBU; k++) gs0 = g == (uint32_t)k ? slot0[k] : gs0;
-                uint32_t slot = gs0 + __float_as_uint(q2.y);
-                const float rxl = q0.x - org.x, ryl = q0.y - org.y;       // record centre, tile-local
-                const float4* P = &S.pst[g * 64][1];
-                const uint32_t nB = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(Mg)) + 1u) >> 1;
-                FR_BSTAMPV(11, nB);
-                __syncthreads();   // (every lane has read its record: the record regions may now take the sums)
-                float sm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (uint32_t it = 0; it < nB; it++) {
-                    float2 qw[2];
-                    float4 dp[2];
-                    float dx[2], dy[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const bool act = Mg != 0ull;
-                        const int pp = act ? (int)__builtin_ctzll(Mg) : 0;
-                        Mg &= Mg - 1ull;
-                        qw[k] = S.pair[act ? slot : 0u];
-                        qw[k].x = act ? qw[k].x : 0.f;
-                        qw[k].y = act ? qw[k].y : 0.f;
-                        slot += act ? 1u : 0u;
-                        dp[k] = P[pp * 2];
-                        dx[k] = rxl - (float)(pp & 7), dy[k] = ryl - (float)(pp >> 3);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const float qdx = qw[k].x * dx[k], qdy = qw[k].x * dy[k];
-                        sm[ACC_MX] += qdx;
-                        sm[ACC_MY] += qdy;
-                        sm[ACC_CA] += qdx * dx[k];
-                        sm[ACC_CB] += qdx * dy[k];
-                        sm[ACC_CC] += qdy * dy[k];
-                        sm[ACC_OP] += qw[k].x;
-                        sm[ACC_R] += qw[k].y * dp[k].x;
-                        sm[ACC_G] += qw[k].y * dp[k].y;
-                        sm[ACC_B] += qw[k].y * dp[k].z;
-                    }
-                }
-                if (have) {
-                    float* o = sums + g * kRecFloats + (t & 63u) * 9u;
-#pragma unroll
-                    for (int c = 0; c < 9; c++) o[c] = sm[c];
-                }
-            }
-            __syncthreads();   // (the sums of the group's records are in LDS)
-            FR_BSTAMP(5);
-            // ---- flush: wave = unit, 7 records x 9 components per atomic instruction (one 64-byte line per record)
-            for (int r0 = 0; r0 < (int)m; r0 += 7) {
-                const int rj = min(r0 + fl_rec, 63);
-                // (a record without pairs had no phase-B lane: nothing was written to its row)
-                const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute(rj << 2, (int)(cnt ? my_id : ~0u));
-                if (mine && lane < 63 && r0 + fl_rec < (int)m && id != ~0u) {
-                    const float val = sums[w * kRecFloats + rj * 9 + fl_c];
-                    if (val != 0.f) atomic_add_f32(accum + (size_t)id * kAccumStride + fl_c, val);
-                }
-            }
-            FR_BSTAMP(6);
-            g0 = g1;
-        }
-    }
-    // ---- a unit in which most pairs are named: all 64 x 64, by this wave alone (see bwd_unit_all_pairs)
-    if (dense) {
-        const int vv = bitrev6(lane);
-        const int own_u = vv / 9, own_c = vv - own_u * 9;
-        bwd_unit_all_pairs(S.rec[w], (int)m, lim, (float)px, (float)py, T_in, A_in, T_final, bgd, dpr, dpg, dpb, accum, lane, vv,
-                           own_u, own_c);
-    }
-    FR_BSTAMP(7);
-    FR_BSTAMPV(8, 1);
-    }
-}
-
 // test hook: run the 36-value reduce-scatter on in[lane*36 + k] and return each lane's result
 __global__ void __launch_bounds__(64) k_selftest_reduce(const float* in, float* out)
 {
@@ -2100,9 +1567,7 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
     const uint32_t small_blocks = (T + 3) / 4;
     const uint32_t unit_wgs = (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG);
-    const uint32_t unit_grid = unit_wgs < kUnitGrid ? unit_wgs : kUnitGrid;
     int rc;
-    const bool chained = !h->dense_blend_fwd;   // the sparse forward: k_unit_blend_chained
     {
         StageScope sc(h, ST_SORT, s);
         // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
@@ -2118,17 +1583,17 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         }
         hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
                            (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           chained ? b.unit_tseg : nullptr, launch_big ? 0 : 1,
+                           b.unit_tseg, launch_big ? 0 : 1,
                            h->host_counts_dev,  // small_blocks == Q
-                           (chained && h->gather_in_chain) ? b.unit_done : nullptr,
-                           (chained && h->gather_in_chain) ? out_color : nullptr, in.background, prm.W, prm.H);
+                           h->gather_in_chain ? b.unit_done : nullptr,
+                           h->gather_in_chain ? out_color : nullptr, in.background, prm.W, prm.H);
         // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
         if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
         if (launch_big) FR_HIP(hipStreamWaitEvent(s, h->side_join, 0));
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
-    if (chained) {
+    {
         StageScope sc(h, ST_BLEND_FWD, s);
         // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
         hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
@@ -2138,16 +1603,6 @@ int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inpu
         if (!h->gather_in_chain)
             hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
                                v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
-    } else {
-        StageScope sc(h, ST_BLEND_FWD, s);
-        hipLaunchKernelGGL(k_unit_tseg, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg);
-        hipLaunchKernelGGL(k_unit_blend, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           v.unit_offset, v.tile_offset, (const float4*)b.recs, prm.W, prm.H, v.tiles_x, b.unit_tseg,
-                           b.unit_out);
-        hipLaunchKernelGGL(k_tile_combine, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s,
-                           v.counts, v.unit_offset, v.tile_total, T, prm.W, prm.H, v.tiles_x,
-                           in.background, b.unit_out, b.unit_state, out_color, v.final_T, v.n_contrib);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "blend_fwd"))) return rc;
@@ -2158,28 +1613,15 @@ int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inpu
                           void* binning, const float* dL_dpix, hipStream_t s, bool debug)
 {
     // the unit count lives on the device: fixed grid, grid-stride loop over the units
-    uint32_t unit_grid = kUnitGrid;
-    if (const char* e = getenv("FR_BWD_GRID")) unit_grid = (uint32_t)atoi(e);   // (tuning experiments)
+    const uint32_t unit_grid = kUnitGrid;
     hipEvent_t ev_a, ev_b;
-    if (!h->dense_blend_bwd && next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
+    if (next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
         // the graded kernel, timed the way a profiler times it: events taken from the dispatch itself
-        if (h->batch_blend_bwd)
-            hipExtLaunchKernelGGL(k_batch_blend_bwd, dim3(unit_grid), dim3(64 * kBU), 0, s, ev_a, ev_b, 0, v.counts, v, binning,
-                                  prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
-        else
-            hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts,
-                                  v, binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts, v,
+                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
     } else {
-        StageScope sc(h, ST_BLEND_BWD, s);
-        if (h->dense_blend_bwd)
-            hipLaunchKernelGGL(k_unit_blend_bwd, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,
-                               prm.H, in.background, dL_dpix, g.accum);
-        else if (h->batch_blend_bwd)
-            hipLaunchKernelGGL(k_batch_blend_bwd, dim3(unit_grid), dim3(64 * kBU), 0, s, v.counts, v, binning, prm.W, prm.H,
-                               in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
-        else
-            hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning,
-                               prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,
+                           prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
     }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");

@@ -241,14 +241,22 @@ struct fr_handle_impl {
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
-    bool dense_blend_fwd = false; // FR_BLEND_FWD=dense: the three all-pairs launches (k_unit_tseg / k_unit_blend / k_tile_combine)
+    // ... and their backward passes share the gradient accumulators: a backward enqueued on a different stream than the
+    // handle's previous backward first waits for `bwd_done`, recorded behind that one's last kernel
+    hipEvent_t bwd_done = nullptr;
+    hipStream_t last_bwd_stream = nullptr;
+    bool have_last_bwd = false;
+    // A captured graph bakes the handle's buffer pointers (and the bucket capacity) into its kernel arguments.  Once a
+    // frame of this handle has been captured, outgrown buffers are therefore RETIRED, not freed: replays keep working on
+    // the buffers they were captured with (every invariant — counters and accumulators zero between frames — holds per
+    // buffer), eager frames use the new ones, and fr_destroy frees them all.  Capacities grow geometrically, so the
+    // retired memory stays below the live memory.
+    bool captured = false;
+    std::vector<void*> retired;
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
     uint32_t chain_spins = 1u << 16;   // polls before a blend unit stops waiting for another one and computes its product / row itself (FR_CHAIN_SPINS)
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
-    bool dense_blend_bwd = false; // FR_BLEND_BWD=dense in the environment: the all-pairs k_unit_blend_bwd instead of the sparse one
-    bool batch_blend_bwd = false; // FR_BLEND_BWD=batch: four units per workgroup with length-sorted walks (k_batch_blend_bwd: fewer
-                                  // instructions, but slower — see the kernel's header) instead of one wave per unit
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events
     StageEvents ev[ST_COUNT];
 };
@@ -308,6 +316,10 @@ size_t knn_workspace_bytes(int P);
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
 // make h->accum hold at least P zeroed rows (hipMalloc when it grows: not while the stream is being captured)
 int ensure_accum(fr_handle_impl* h, size_t P, hipStream_t s);
+// remember that frames of this handle are being captured into a graph (see fr_handle_impl::captured); true while capturing
+bool note_capture(fr_handle_impl* h, hipStream_t s);
+// give up a handle-owned device buffer: freed behind the stream's work, or retired if a captured graph may still name it
+int release_buffer(fr_handle_impl* h, void* p, hipStream_t s);
 int launch_bind_forward(const fr_binding& b, float* xyz, float* rot, float* scale, hipStream_t s);
 int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g_rot, const float* g_scale, float* d_verts,
                          float* d_offset, float* d_rotation, float* d_scaling, hipStream_t s);

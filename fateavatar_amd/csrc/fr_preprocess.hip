@@ -620,9 +620,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     BinningView b = BinningView::make(binning, (size_t)cap, (size_t)T);
     const bool debug = prm.debug != 0;
     int rc;
-    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap_status);
-    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    const bool capturing = note_capture(h, s);
     // The handle's buffers (gradient accumulators, per-tile counters, key buckets) grow with the scene and the tile
     // grid.  Growing means hipStreamSynchronize + hipFree + hipMalloc, none of which a capturing stream allows — and
     // trying would invalidate the caller's capture.  Say so before touching the stream.
@@ -649,10 +647,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     // stream is being captured into a graph: run one eager frame of the same size first.
     const size_t counter_words = (size_t)kXcds * v.tpad;   // 8 XCD copies
     if (v.tpad > h->tile_counter_tiles) {   // (tile_counter_tiles holds the largest pitch allocated so far)
-        if (h->tile_counters) {
-            FR_HIP(hipStreamSynchronize(s));
-            FR_HIP(hipFree(h->tile_counters));
-        }
+        if ((rc = release_buffer(h, h->tile_counters, s))) return rc;
         h->tile_counters = nullptr, h->tile_counter_tiles = 0;
         FR_HIP(hipMalloc(&h->tile_counters, counter_words * sizeof(uint32_t)));
         h->tile_counter_tiles = v.tpad;
@@ -672,10 +667,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
         const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
         while (want < need + need / 4) want <<= 1;
         if (want != h->bucket_cap || (size_t)T > h->bucket_tiles) {
-            if (h->key_buckets) {
-                FR_HIP(hipStreamSynchronize(s));
-                FR_HIP(hipFree(h->key_buckets));
-            }
+            if ((rc = release_buffer(h, h->key_buckets, s))) return rc;
             h->key_buckets = nullptr;
             const size_t tiles = (size_t)T > h->bucket_tiles ? (size_t)T : h->bucket_tiles;
             FR_HIP(hipMalloc(reinterpret_cast<void**>(&h->key_buckets), tiles * kXcds * want * sizeof(uint64_t)));

@@ -34,6 +34,7 @@ struct PreBwdArgs {
     fr_grads out;
     float* grad_accum;  // optional (fr_aux): += ||dL_dmeans2D[:, :2]|| of visible Gaussians
     float* denom;       // optional (fr_aux): += 1 for visible Gaussians
+    const DeviceCounts* counts;   // the frame's counts: an overflowed frame (nothing was blended) adds nothing to the statistics
     uint32_t acc;       // bit k: ADD into the k-th array of fr_grads instead of overwriting it (FR_FLAG_ACCUMULATE)
 };
 
@@ -107,8 +108,11 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
     store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f, adds(G_MEANS2D));
     // fused _add_densification_stats (model/fateavatar.py:734-737); this branch is radii > 0
-    if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
-    if (a.denom) a.denom[i] += 1.0f;
+    // (a replayed frame that overflowed its captured binning capacity back-propagates zeros: it must not count as a view)
+    if (!a.counts->overflow) {
+        if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
+        if (a.denom) a.denom[i] += 1.0f;
+    }
     store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2], adds(G_COLORS));
     // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
     if (a.out.dL_dopacity) a.out.dL_dopacity[i] = old_op + (a.raw ? dop * co.w * (1.0f - co.w) : dop);
@@ -466,6 +470,11 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     const int P = prm.P;
     if (P <= 0) return FR_OK;
     GeomView g = GeomView::make(geometry, (size_t)P);
+    const bool capturing = note_capture(h, s);
+    // backward passes of one handle share its gradient accumulators (the blend backward adds rows, k_preprocess_bwd reads
+    // and re-zeroes them): order this one behind the previous one if that ran on another stream.  (Not inside a capture:
+    // a capture is ordered by its own stream, replays by whoever launches them — as for the forward.)
+    if (!capturing && h->have_last_bwd && h->last_bwd_stream != s) FR_HIP(hipStreamWaitEvent(s, h->bwd_done, 0));
     {   // gradient accumulators: handle-owned, zero between backward passes (normally sized by the forward already)
         int rc0 = ensure_accum(h, (size_t)P, s);
         if (rc0) return rc0;
@@ -489,6 +498,7 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
     a.radii = radii, a.g = g, a.out = gr;
     a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
     a.denom = prm.aux ? prm.aux->denom : nullptr;
+    a.counts = v.counts;
     a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
     {
         StageScope sc(h, ST_PREPROCESS_BWD, s);
@@ -497,6 +507,10 @@ int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + wg - 1) / wg), dim3(wg), lds, s, a);
     }
     FR_HIP(hipGetLastError());
+    if (!capturing) {
+        FR_HIP(hipEventRecord(h->bwd_done, s));
+        h->last_bwd_stream = s, h->have_last_bwd = true;
+    }
     if (debug) FR_HIP(hipStreamSynchronize(s));
     return FR_OK;
 }

@@ -13,13 +13,25 @@ import torch
 
 from . import _lib
 
-_workspace = {}   # device index -> zeroed scratch (the kernel leaves it zeroed)
+# (device index, stream handle) -> zeroed scratch (the kernel leaves it zeroed).  One workspace PER STREAM: the kernel
+# elects its last workgroup through counters in the workspace and sums per-workgroup partials left there, so two launches
+# that overlap on the device — the lanes of AvatarBatchStep run on their own streams, each from its own captured graph —
+# must not share one (the loss scalars would mix; include/fr_rasterizer.h says the same of fr_l1_loss_grad).
+_workspace = {}
+
+
+def l1_workspace(dev: torch.device) -> torch.Tensor:
+    """A fresh zeroed workspace for `l1_loss_and_grad(..., workspace=)`: for callers that launch from several streams or
+    graphs at once and want to own the scratch explicitly."""
+    return torch.zeros((_lib.lib().fr_l1_workspace_bytes(),), dtype=torch.uint8, device=dev)
 
 
 def l1_loss_and_grad(img: torch.Tensor, gt: torch.Tensor, loss_out: Optional[torch.Tensor] = None,
-                     grad_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     grad_out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
     """mean |img - gt| (0-dim device tensor) and its gradient with respect to `img`.  `loss_out` / `grad_out`: write into
-    these tensors instead of fresh ones (buffers of a captured step)."""
+    these tensors instead of fresh ones (buffers of a captured step).  `workspace`: scratch from `l1_workspace()`; by
+    default one is kept per (device, current stream) — launches that may overlap must not share one."""
     if not (img.is_cuda and gt.is_cuda):
         raise RuntimeError("l1_loss_and_grad needs device tensors (there is no CPU path)")
     if img.shape != gt.shape:
@@ -35,12 +47,22 @@ def l1_loss_and_grad(img: torch.Tensor, gt: torch.Tensor, loss_out: Optional[tor
     if grad.shape != img.shape or grad.dtype != torch.float32 or not grad.is_contiguous() or loss.numel() != 1:
         raise RuntimeError("l1_loss_and_grad: bad output buffers")
     L = _lib.lib()
-    ws = _workspace.get(dev.index)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = workspace
     if ws is None:
-        ws = _workspace[dev.index] = torch.zeros((L.fr_l1_workspace_bytes(),), dtype=torch.uint8, device=dev)
+        key = (dev.index, stream)
+        ws = _workspace.get(key)
+        if ws is None:
+            # (allocated on a side stream-independent path: torch.zeros inside a capture would become part of the graph)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("l1_loss_and_grad: first call on this stream happens inside a graph capture; call it once "
+                                   "eagerly on the stream first, or pass workspace=l1_workspace(device)")
+            ws = _workspace[key] = l1_workspace(dev)
+    elif not (ws.is_cuda and ws.device == dev and ws.dtype == torch.uint8 and ws.numel() >= L.fr_l1_workspace_bytes()):
+        raise RuntimeError("l1_loss_and_grad: workspace must come from l1_workspace() on the image's device")
     with torch.cuda.device(dev):
         rc = L.fr_l1_loss_grad(img.numel(), img.data_ptr(), gt.data_ptr(), grad.data_ptr(), loss.data_ptr(), ws.data_ptr(),
-                               torch.cuda.current_stream(dev).cuda_stream)
+                               stream)
     if rc != _lib.FR_OK:
         raise RuntimeError(f"fr_l1_loss_grad failed: {_lib.last_error()}")
     return loss, grad

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 
 from . import dp
-from .loss import l1_loss_and_grad, multi_copy
+from .loss import l1_loss_and_grad, l1_workspace, multi_copy
 from .model import FlatGaussians, TorchCamera
 from .optim import FusedAdam
 from .render import render
@@ -53,6 +53,7 @@ class TrainStep:
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
         self._dimage = torch.zeros_like(self.gt)   # dL/dimage of the step
+        self._l1_ws = l1_workspace(self.dev)       # scratch of this step's loss kernel (not shared with launches that may overlap)
         self.out = None
         self.use_graph = bool(use_graph)
         self._graph = None       # render .. backward (.. Adam when world == 1)
@@ -65,7 +66,7 @@ class TrainStep:
         out = render(self.cam, self.pc, self.bg)               # activations + rasterizer (fused)
         # nn.L1Loss(reduction='mean') (loss.py:92) + loss.backward(): the loss and the gradient autograd would hand to the
         # rasterizer in one launch, written straight into the step's buffers; then the rasterizer backward (stats fused)
-        _, g = l1_loss_and_grad(out["render"], self.gt, loss_out=self.loss, grad_out=self._dimage)
+        _, g = l1_loss_and_grad(out["render"], self.gt, loss_out=self.loss, grad_out=self._dimage, workspace=self._l1_ws)
         out["render"].backward(g)
         # keep the step's outputs WITHOUT their autograd graph: a graph kept alive across steps keeps its
         # AccumulateGrad nodes (and the stream they were created on) alive, which breaks a later stream capture

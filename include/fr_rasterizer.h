@@ -63,10 +63,15 @@ extern "C" {
 /* Per-device context: pinned count slot, event, and the per-tile binning counters (device memory, kept zero
  * between frames so that a frame needs no zeroing launch), the key buckets and the gradient accumulators.  Calls on
  * one handle must not overlap on the host (one thread at a time); on the device, frames enqueued on one stream are
- * ordered by it and a frame on another stream first waits for the previous frame's event.  The handle's device memory
+ * ordered by it and a frame on another stream first waits for the previous frame's event (forward passes wait for the
+ * previous forward, backward passes for the previous backward: they share the counters resp. the accumulators).  Frames
+ * enqueued while a stream is being CAPTURED are ordered by the capture; replays of the graph by whoever launches them —
+ * give frames that are to run concurrently their own handles.  The handle's device memory
  * grows with the tile grid / Gaussian count / longest per-XCD tile sub-list (hipMalloc — not while the stream is being
  * captured into a hipGraph: run one eager frame of that size first; fr_forward on a capturing stream that would have
- * to grow something returns FR_ERR_UNSUPPORTED before enqueuing anything, which leaves the capture valid). */
+ * to grow something returns FR_ERR_UNSUPPORTED before enqueuing anything, which leaves the capture valid).  A captured
+ * graph holds the handle's buffer pointers: once a frame of the handle has been captured, buffers that a later eager
+ * frame outgrows are retired (kept until fr_destroy) instead of freed, so replays stay valid. */
 typedef struct fr_handle fr_handle;
 
 /* Optional fused side outputs: per-Gaussian values the caller's step otherwise derives
@@ -223,7 +228,9 @@ int fr_adam_step_multi(const fr_adam_config* cfg, float* param, const float* con
 /* ---- the image loss of the optimisation step (reference nn.L1Loss(reduction='mean') on the rendered
  * image, model/loss.py:92, followed by loss.backward()): loss = mean |img - gt| and grad = sign(img - gt) / n (what
  * autograd hands to the rasterizer's backward for a unit upstream gradient) in ONE launch.  `grad` may be NULL.
- * `workspace`: fr_l1_workspace_bytes() bytes of device memory, zeroed ONCE by the caller (the kernel leaves it zeroed);
+ * `workspace`: fr_l1_workspace_bytes() bytes of device memory, zeroed ONCE by the caller (the kernel leaves it zeroed).
+ * A workspace must NOT be shared by launches that can overlap on the device (other streams, other graphs): the kernel
+ * elects its last workgroup and sums per-workgroup partials through it;
  * `loss`: one device float.  All arrays on the device, n floats each. */
 size_t fr_l1_workspace_bytes(void);
 int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, float* loss, void* workspace,

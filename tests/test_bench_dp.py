@@ -24,7 +24,10 @@ def _run(extra, env_extra=None):
 
 
 @pytest.mark.parametrize("overlap,K,R", [(True, 3, 1), (False, 3, 2), (True, 1, 1), (True, 2, 3), (True, 1, 4)])
-def test_bench_spawns_two_ranks_and_averages_every_step(overlap, K, R):
+def test_bench_spawns_two_ranks_and_reports_both_modes(overlap, K, R):
+    """N > 1: the line's `value` is the LITERAL BASELINE configs[3] shape (one view per rank per exchange, the exchange
+    finished before the next step), and the amortised mode (R rounds of K views per exchange, overlapped) sits beside it in
+    dp.modes; every step of both modes averages its gradient over the ranks."""
     steps, warm = 7, 3
     j = _run(["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--in-flight", str(K), "--rounds", str(R)]
              + ([] if overlap else ["--no-overlap"]))
@@ -33,15 +36,26 @@ def test_bench_spawns_two_ranks_and_averages_every_step(overlap, K, R):
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["overlap"] is overlap
     assert d["num_rendered_per_rank"] == [1000, 1001]
     assert d["allreduce_payload_bytes"] == 4 * 4096 and d["allreduce_us"] > 0
-    # the stub gradient of (rank r, view v of its K, round k counted from the start) is i * 1e-3 + (r * K + v + 1) * (k + 1).
+    assert d["allreduce_table"][0]["payload_bytes"] == 4 * 4096 and d["allreduce_table"][0]["us"] > 0
+    lit, amo = d["modes"]["literal"], d["modes"]["amortised"]
+    # ---- the literal mode is the headline
+    assert (lit["frames_per_step_per_gpu"], lit["rounds_per_step"], lit["frames_in_flight_per_gpu"], lit["overlap"]) == (1, 1, 1, False)
+    assert j["value"] == lit["value"] and j["ms_per_step"] == lit["ms_per_step"]
+    assert j["config"]["frames_per_step_per_gpu"] == 1 and j["config"]["rounds_per_step"] == 1
+    assert abs(lit["value"] - 2 * steps / (lit["ms_per_step"] * steps * 1e-3)) <= 0.02 * lit["value"]
+    # the stub gradient of (rank r, view v of its K, round k counted from the mode's start) is
+    # i * 1e-3 + (r * K + v + 1) * (k + 1); literal mode: K = 1, one round per step -> mean over the two ranks 1.5 * (k + 1)
+    want = sum(i * 1e-3 + 1.5 * (warm + steps) for i in range(4096))
+    assert abs(lit["grad_checksum"] - want) <= 1e-4 * want, (lit["grad_checksum"], want)
+    # ---- the amortised mode beside it
+    assert (amo["frames_per_step_per_gpu"], amo["rounds_per_step"], amo["frames_in_flight_per_gpu"], amo["overlap"]) == (K * R, R, K, overlap)
+    assert abs(amo["value"] - 2 * K * R * steps / (amo["ms_per_step"] * steps * 1e-3)) <= 0.02 * amo["value"]
     # A step is R rounds; the exchange buffer must hold the mean over the R rounds of the LAST step, the K views of each
     # rank and the two ranks: the mean of 1 .. 2K is (2K + 1) / 2, the mean of (k + 1) over the last step's rounds is
     # (warm + steps - 1) * R + (R + 1) / 2
     kmean = (warm + steps - 1) * R + (R + 1) / 2
     want = sum(i * 1e-3 + (2 * K + 1) / 2 * kmean for i in range(4096))
     assert abs(d["grad_checksum"] - want) <= 1e-4 * want, (d["grad_checksum"], want)
-    assert j["config"]["frames_per_step_per_gpu"] == K * R and j["config"]["rounds_per_step"] == R
-    assert j["value"] > 0 and abs(j["value"] - 2 * K * R * steps / (j["ms_per_step"] * steps * 1e-3)) <= 0.02 * j["value"]
 
 
 def test_bench_single_rank_stub_line_is_well_formed():

@@ -429,6 +429,63 @@ def test_graph_replay_survives_interleaved_eager_kernels(gpu_device):
     assert util.rel_l2(pc.flat_grad.cpu().numpy(), ref_grad.cpu().numpy()) < 1e-5
 
 
+def test_graph_replay_survives_an_eager_frame_that_outgrows_the_handle_buffers(gpu_device):
+    """A captured frame bakes the handle's buffer pointers and bucket capacity into its kernels.  An eager frame on the
+    SAME handle that needs bigger key buckets / more accumulator rows (a denser pose, a bigger model) must not free what
+    the graph replays on: outgrown buffers of a handle that has been captured are retired until fr_destroy
+    (fr_handle_impl::captured).  Runs in a subprocess with its own handle state."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from fateavatar_amd import scenes, rasterizer\n"
+        "from fateavatar_amd.model import FlatGaussians, TorchCamera\n"
+        "from fateavatar_amd.render import render\n"
+        "dev = torch.device('cuda:0')\n"
+        "def setup(P, scale, seed):\n"
+        "    s = scenes.head_scene(P=P, res=256, sh_degree=1, seed=seed, scale=scale)\n"
+        "    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 1, dev, fused_activations=True)\n"
+        "    return pc, TorchCamera(s.camera, dev), torch.from_numpy(s.bg).to(dev)\n"
+        "pc, cam, bg = setup(20000, None, 0)\n"
+        "g = torch.rand(3, 256, 256, device=dev) / (3 * 256 * 256)\n"
+        "img = torch.zeros(3, 256, 256, device=dev)\n"
+        "def frame():\n"
+        "    pc.begin_step(); out = render(cam, pc, bg)\n"
+        "    torch.autograd.backward(out['render'], grad_tensors=g); img.copy_(out['render'].detach())\n"
+        "for _ in range(2): frame()\n"
+        "torch.cuda.synchronize(); ref_img = img.clone(); ref_grad = pc.collect_grads().clone()\n"
+        "rasterizer.set_no_wait(True)\n"
+        "side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())\n"
+        "with torch.cuda.stream(side): frame()\n"
+        "torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()\n"
+        "graph = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(graph): frame()\n"
+        "graph.replay(); torch.cuda.synchronize()\n"
+        "assert torch.equal(img, ref_img)\n"
+        "rasterizer.set_no_wait(False)\n"
+        "# an eager frame of a bigger, much denser model on the same handle: more accumulator rows, longer (tile, XCD) lists\n"
+        "pc2, cam2, bg2 = setup(60000, 6e-3, 1)\n"
+        "for _ in range(3):\n"
+        "    out2 = render(cam2, pc2, bg2); out2['render'].sum().backward(); pc2.begin_step()\n"
+        "torch.cuda.synchronize()\n"
+        "big = rasterizer.last_counts[0]\n"
+        "assert big.max_tile_list > 512, big.max_tile_list\n"
+        "junk = [torch.full((1 << 22,), float('nan'), device=dev) for _ in range(8)]   # whatever was freed gets reused\n"
+        "rasterizer.set_no_wait(True)\n"
+        "for _ in range(3): graph.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "assert not rasterizer.check_async_overflow(0)\n"
+        "rasterizer.set_no_wait(False)\n"
+        "assert torch.equal(img, ref_img), float((img - ref_img).abs().max())\n"
+        "d = (pc.flat_grad - ref_grad).norm() / ref_grad.norm()\n"
+        "assert float(d) < 1e-5, float(d)\n"
+        "print('replay-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "replay-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_capturing_a_size_the_handle_has_not_seen_is_refused_cleanly(gpu_device):
     """A handle grows its own buffers (accumulators, tile counters, key buckets) with the scene and the tile grid; that
     needs hipMalloc/hipFree, which a capturing stream does not allow.  fr_forward says so BEFORE touching the stream
@@ -814,13 +871,14 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device, fused, m
     assert not torch.equal(va[0], va[1])
 
 
-@pytest.mark.parametrize("mode", ["FR_BLEND_FWD=gather", "FR_BLEND_FWD=dense", "FR_BLEND_BWD=dense",
+@pytest.mark.parametrize("mode", ["FR_BLEND_FWD=gather",
                                   "FR_DENSE_PAIRS_FWD=0,FR_DENSE_PAIRS_BWD=0", "FR_DENSE_PAIRS_FWD=9999,FR_DENSE_PAIRS_BWD=9999",
                                   "FR_CHAIN_SPINS=0", "FR_CHAIN_SPINS=3"])
 def test_selectable_blend_paths_stay_correct(gpu_device, mode):
-    """The blend kernels the environment can select (the gather as its own launch, round 1's all-pairs
-    kernels, and the per-unit all-pairs / sparse choice forced either way) must keep matching the oracle for as long as
-    they stay in the tree.  FR_CHAIN_SPINS=0 / 3: the units of the one-launch forward give up waiting for each other at
+    """The blend paths the environment can select (the gather as its own launch, and the per-unit
+    all-pairs / sparse choice forced either way — 0: every unit takes the in-kernel all-pairs loops, 9999: none does, units
+    with more pairs than slots are walked in record ranges) must keep matching the oracle for as long as they stay in
+    the tree.  FR_CHAIN_SPINS=0 / 3: the units of the one-launch forward give up waiting for each other at
     once (after three polls) and compute the missing products and rows themselves — the path that makes the launch
     independent of dispatch order.  Run in a subprocess: the switches are read at handle creation."""
     import os

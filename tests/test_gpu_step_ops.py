@@ -102,3 +102,30 @@ def test_concurrent_streams_overlap(gpu_device):
         assert _overlap(cur, a, gpu_device, 400_000)
         for b in ss[i + 1:]:
             assert _overlap(a, b, gpu_device, 400_000) and _overlap(b, a, gpu_device, 400_000)
+
+
+@pytest.mark.gpu
+def test_l1_losses_of_overlapping_launches_do_not_mix(gpu_device):
+    """The loss kernel elects its last workgroup and sums per-workgroup partials through its workspace: launches that
+    overlap (the lanes of AvatarBatchStep, one stream each) must each have their own (loss.py keeps one per stream)."""
+    import torch
+    from fateavatar_amd.loss import l1_loss_and_grad, l1_workspace
+    torch.manual_seed(0)
+    K, n_rep = 3, 40
+    imgs = [torch.rand(3, 512, 512, device=gpu_device) for _ in range(K)]
+    gts = [torch.rand(3, 512, 512, device=gpu_device) * (k + 1) for k in range(K)]
+    want = [float((a - b).abs().mean()) for a, b in zip(imgs, gts)]
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(K)]
+    losses = [[torch.zeros((), device=gpu_device) for _ in range(n_rep)] for _ in range(K)]
+    explicit = [l1_workspace(gpu_device) for _ in range(K)]
+    for mode in ("per-stream default", "explicit"):
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(gpu_device))
+        for r in range(n_rep):
+            for k in range(K):
+                with torch.cuda.stream(streams[k]):
+                    l1_loss_and_grad(imgs[k], gts[k], loss_out=losses[k][r], workspace=explicit[k] if mode == "explicit" else None)
+        torch.cuda.synchronize()
+        for k in range(K):
+            got = torch.stack(losses[k]).cpu().numpy()
+            assert np.allclose(got, want[k], rtol=1e-5), (mode, k, got.min(), got.max(), want[k])

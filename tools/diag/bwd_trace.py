@@ -1,9 +1,9 @@
 """Per-wave phase timeline of the blend backward (GPU box).  Needs the -DFR_BWD_TRACE build:
     tools/diag/build_variant.sh trace -DFR_BWD_TRACE        (here)
     FR_HIP_LIB=$PWD/.ab/libfr_trace.so python tools/diag/bwd_trace.py [--P 100000 --res 512]   (GPU box)
-Stamps (shader cycles, s_memtime): 0 entry, 1 descriptor + pixel loads issued, 2 n_contrib arrived, 3 staged + scanned +
+Stamps (shader cycles, s_memtime): 0 entry, 1 every load of the unit landed, 2 the tile has live pixels, 3 staged + scanned +
 transposed, 4 phase A of the first range done, 5 phase B done, 6 flush done, 7 unit done; values: 8/12 s_memrealtime at
-entry / exit (100 MHz), 9 pair slots of the unit, 10/11 iterations of phase A / B of the first range."""
+entry / exit (100 MHz), 9 pair slots of the unit."""
 import argparse, ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -32,17 +32,10 @@ work = t[:, 7] > 0
 w = t[work]
 print(f"waves with a unit: {work.sum()} of 8192; instances {f.counts.num_instances}")
 rt0 = t[t[:, 8] > 0, 8].min()
-if os.environ.get("FR_BLEND_BWD") == "unit":
-    print(f"kernel span by s_memrealtime: first entry -> last unit exit {(w[:, 12].max() - rt0) / 100:.2f} us; "
-          f"entries spread over {(t[t[:, 8] > 0, 8].max() - rt0) / 100:.2f} us")
-else:
-    print(f"span of the working waves in shader cycles (one clock domain assumed): {w[:, 7].max() - w[:, 0].min()}")
-if os.environ.get("FR_BLEND_BWD") == "unit":
-    names = ["entry->descriptor", "descriptor->n_contrib", "n_contrib->staged+transposed", "staged->phase A done",
-             "phase A->phase B done", "phase B->flush done", "flush->unit done (further ranges)"]
-else:   # k_batch_blend_bwd: 0 entry, 1 loads issued + barrier, 2 staged + barrier, 3 tasks sorted, 4 A, 5 B, 6 flush, 7 end
-    names = ["entry->loads issued", "loads->staged (barrier)", "staged->tasks sorted", "sorted->phase A done (barrier)",
-             "phase A->phase B done (barrier)", "phase B->flush done", "flush->end (further groups, all-pairs units)"]
+print(f"kernel span by s_memrealtime: first entry -> last unit exit {(w[:, 12].max() - rt0) / 100:.2f} us; "
+      f"entries spread over {(t[t[:, 8] > 0, 8].max() - rt0) / 100:.2f} us")
+names = ["entry->all loads of the unit landed", "loads->tile has live pixels", "live->staged+transposed", "staged->phase A done",
+         "phase A->phase B done", "phase B->flush done", "flush->unit done (further ranges)"]
 d = np.diff(w[:, :8], axis=1)
 print(f"{'segment':38s} {'mean':>8s} {'p50':>8s} {'p90':>8s} {'max':>8s}  (shader cycles)")
 for k, n in enumerate(names):
@@ -50,11 +43,10 @@ for k, n in enumerate(names):
     print(f"{n:38s} {x.mean():8.0f} {np.percentile(x, 50):8.0f} {np.percentile(x, 90):8.0f} {x.max():8.0f}")
 tot = w[:, 7] - w[:, 0]
 print(f"{'whole unit':38s} {tot.mean():8.0f} {np.percentile(tot, 50):8.0f} {np.percentile(tot, 90):8.0f} {tot.max():8.0f}")
-print(f"pairs/unit mean {w[:, 9].mean():.0f} p90 {np.percentile(w[:, 9], 90):.0f} max {w[:, 9].max()};  nA mean {w[:, 10].mean():.1f} max {w[:, 10].max()};"
-      f"  nB mean {w[:, 11].mean():.1f} max {w[:, 11].max()}")
+print(f"pairs/unit mean {w[:, 9].mean():.0f} p90 {np.percentile(w[:, 9], 90):.0f} max {w[:, 9].max()}")
 # the slowest units: what made them slow
 idx = np.argsort(-tot)[:8]
 for i in idx:
-    print("slow unit: total", tot[i], "segments", d[i].tolist(), "pairs", w[i, 9], "nA", w[i, 10], "nB", w[i, 11])
+    print("slow unit: total", tot[i], "segments", d[i].tolist(), "pairs", w[i, 9])
 # correlation of unit duration with pairs
 print("corr(total, pairs) =", np.corrcoef(tot, w[:, 9])[0, 1])

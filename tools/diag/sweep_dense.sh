@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench scene, config 5 and two dense scenes under the per-unit all-pairs thresholds (FR_DENSE_PAIRS_FWD / _BWD;
-# 9999 = never) and with the all-pairs kernels of FR_BLEND_FWD=dense.
+# 9999 = never, 0 = always).
 cd "${GRAFT_REPO_ROOT:-.}"
 if [ "$1" = hist ]; then
   FR_DEBUG_PAIR_HIST=1 python tools/probe.py 2>/dev/null | grep -E "^units|^P="
@@ -15,4 +15,4 @@ run() {
 echo "== default"; run
 [ "$1" = default ] && exit 0
 echo "== never all-pairs"; FR_DENSE_PAIRS_FWD=9999 FR_DENSE_PAIRS_BWD=9999 run
-echo "== FR_BLEND_FWD=dense"; FR_BLEND_FWD=dense run
+echo "== always all-pairs"; FR_DENSE_PAIRS_FWD=0 FR_DENSE_PAIRS_BWD=0 run
