@@ -7,7 +7,10 @@ faces area-weighted.  These run once at model construction; they are host-side n
 has its centre at u = (2 xi + 1) / (2 S), v = 1 - (2 yi + 1) / (2 S) — the convention that results from the reference's
 NDC flips (mesh_sampling.py:31-33, 114-116) and pytorch3d's pixel centres; overlapping UV faces resolve to the lowest
 face index; back-face culling is not applied (the FLAME UV layout is consistently wound).  pytorch3d is not available
-in this image: the texel convention is restated, not pinned.
+in this image, so the convention cannot be pinned by running it; it is derived from pytorch3d 0.7.7's documented pixel ->
+NDC mapping (`rasterize_meshes` samples output pixel (yi, xi) at NDC (1 - (2 xi + 1) / W, 1 - (2 yi + 1) / H): pixel
+centres, +X left, +Y up, row 0 at the top) and pinned by a hand-computed two-triangle case that tells pixel-centre from
+pixel-corner sampling and a top-left from a bottom-left origin (tests/test_mesh_sampling.py).
 """
 from __future__ import annotations
 

@@ -17,8 +17,17 @@ blend / binning / backward arithmetic has no reference-held pin.  This script is
       - guard-band clamp (backward.cu:168-176,262-264): the clamped t.x / t.y are constants (stop-gradient);
       - dL_dmeans2D is the derivative w.r.t. the NDC-scaled pixel centre in the blend only (backward.cu:460-461,545-546):
         obtained by perturbing the 2D centres with everything else fixed, times 0.5 W / 0.5 H.
-    (The third, the 0.99 alpha clamp whose gradient the reference passes straight through, backward.cu:499-534, is kept
-    out of the gradient scenes — opacities <= 0.98 — and covered by a forward-only scene.)
+      - the 0.99 alpha clamp (forward.cu:343) whose gradient the reference passes straight through (backward.cu:499-534:
+        dL_dalpha goes on to opacity and G as if alpha = opacity * G): a pair clamped at the base point is evaluated as
+        alpha = 0.99 + (opacity * G - (opacity * G at the base point)) — the clamped VALUE, the unclamped DERIVATIVE
+        (scene "alpha_clamp_gradient"; the older forward-only clamp scene is kept).
+
+Two scenes go beyond a single tile: "big_lists" (450 Gaussians on 48 x 48 pixels = 3 x 3 reference tiles, 6 x 6 tiles of the
+8 x 8 implementation; a dense cluster gives lists of several hundred entries per tile, so the image depends on the 64-bit
+tile|depth key order across tiles, on lists longer than one 64-record blend unit and longer than the 256-key register sort)
+with its image, transmittance, radii and contributor counts, and finite-difference gradients of a sample of its
+Gaussians.  They are evaluated by a pixel-vectorised copy of the same forward (forward64v), which this script first
+checks against the scalar one on every small scene.
 
 Every scene is checked to sit far from the discrete decisions (power > 0, alpha < 1/255, T < 1e-4, radius ceil, tile
 rectangle, depth order), so that an fp32 implementation takes the same ones.  Output: tests/golden/known_answers.npz
@@ -117,8 +126,8 @@ def per_gaussian(sc, frozen=None, margins=None):
         x0, y0 = min(gx, max(0, int(e[0]))), min(gy, max(0, int(e[1])))     # int(): C truncation
         x1, y1 = min(gx, max(0, int(e[2]))), min(gy, max(0, int(e[3])))
         if margins is not None:
-            margins.append(("radius", abs(rr - round(rr))))
-            margins.extend(("rect", abs(v - round(v))) for v in e if -0.5 < v < max(gx, gy) + 0.5)
+            margins.append(("radius", abs(rr - round(rr)), i))
+            margins.extend(("rect", abs(v - round(v)), i) for v in e if -0.5 < v < max(gx, gy) + 0.5)
         if (x1 - x0) * (y1 - y0) == 0:
             continue
         if sc.get("colors_precomp") is not None:
@@ -159,17 +168,17 @@ def forward64(sc, frozen=None, d_xy=None, order=None, margins=None):
                 A, B, Cc = g["conic"][i]
                 power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
                 if margins is not None and A * Cc - B * B <= 0:   # a positive-definite conic cannot give power > 0
-                    margins.append(("power", abs(power)))
+                    margins.append(("power", abs(power), i))
                 if power > 0.0:
                     continue
                 alpha = min(0.99, op[i] * math.exp(power))
                 if margins is not None:
-                    margins.append(("alpha", abs(alpha * 255.0 - 1.0)))
+                    margins.append(("alpha", abs(alpha * 255.0 - 1.0), i))
                 if alpha < 1.0 / 255.0:
                     continue
                 test_T = T * (1.0 - alpha)
                 if margins is not None:
-                    margins.append(("T", abs(test_T / 1e-4 - 1.0)))
+                    margins.append(("T", abs(test_T / 1e-4 - 1.0), i))
                 if test_T < 0.0001:
                     break
                 C += g["rgb"][i] * alpha * T
@@ -183,11 +192,156 @@ def forward64(sc, frozen=None, d_xy=None, order=None, margins=None):
     return dict(color=color, final_T=final_T, n_contrib=n_contrib, radii=g["radii"], order=order, g=g, sig=sig)
 
 
+def per_gaussian_all(sc, frozen=None, margins=None, base=None, only=None):
+    """per_gaussian() for every Gaussian, or (base given) only for Gaussian `only` on top of the cached `base` — a finite
+    difference moves one Gaussian at a time."""
+    if base is None or only is None:
+        return per_gaussian(sc, frozen, margins)
+    one = {k: (np.asarray(v)[only:only + 1] if (isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == sc["means3D"].shape[0]
+                                               and k not in ("viewmatrix", "projmatrix", "campos", "bg", "dL_dpix")) else v)
+           for k, v in sc.items()}
+    fr = None if frozen is None else tuple(np.asarray(a)[only:only + 1] for a in frozen)
+    g1 = per_gaussian(one, fr)
+    g = {k: v.copy() for k, v in base.items()}
+    for k in g:
+        g[k][only] = g1[k][0]
+    return g
+
+
+def forward64v(sc, frozen=None, d_xy=None, order=None, margins=None, gcache=None, only=None, clamp_ref=None):
+    """forward64 with the per-pixel loop vectorised over the pixels (identical arithmetic per pixel, float64).
+    `clamp_ref`: (clamped [n, H, W] bool, raw0 [n, H, W]) of the base point — pairs clamped there take
+    alpha = 0.99 + (raw - raw0), see the module docstring.  Returns also `blended` [n, H, W] and `raw` [n, H, W]."""
+    g = per_gaussian_all(sc, frozen, margins, gcache, only)
+    W, H = sc["W"], sc["H"]
+    xy = g["xy"] + (d_xy if d_xy is not None else 0.0)
+    op = sc["opacities"].astype(np.float64).reshape(-1)
+    bg = sc["bg"].astype(np.float64)
+    vis = np.nonzero(g["radii"] > 0)[0]
+    if order is None:
+        order = sorted(vis.tolist(), key=lambda i: (np.float32(g["depth"][i]), i))
+    ys, xs = np.mgrid[0:H, 0:W]
+    tx_, ty_ = xs // TILE, ys // TILE
+    T = np.ones((H, W))
+    C = np.zeros((3, H, W))
+    contributor = np.zeros((H, W), np.int64)
+    last = np.zeros((H, W), np.int64)
+    done = np.zeros((H, W), bool)
+    n = len(order)
+    blended = np.zeros((n, H, W), bool)
+    raws = np.zeros((n, H, W))
+    for k, i in enumerate(order):
+        x0, y0, x1, y1 = g["rect"][i]
+        inrect = (tx_ >= x0) & (tx_ < x1) & (ty_ >= y0) & (ty_ < y1) & ~done
+        contributor = contributor + inrect
+        dx, dy = xy[i, 0] - xs, xy[i, 1] - ys
+        A, B, Cc = g["conic"][i]
+        power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+        ok = inrect & ~(power > 0.0)
+        raw = op[i] * np.exp(np.minimum(power, 0.0))
+        raws[k] = raw
+        alpha = np.minimum(0.99, raw)
+        if clamp_ref is not None:
+            alpha = np.where(clamp_ref[0][k], 0.99 + (raw - clamp_ref[1][k]), alpha)
+        if margins is not None:
+            if A * Cc - B * B <= 0:
+                margins.extend(("power", float(v), i) for v in np.abs(power[inrect]))
+            margins.extend(("alpha", float(v), i) for v in np.abs(alpha[ok] * 255.0 - 1.0))
+        ok2 = ok & ~(alpha < 1.0 / 255.0)
+        test_T = T * (1.0 - alpha)
+        if margins is not None:
+            margins.extend(("T", float(v), i) for v in np.abs(test_T[ok2] / 1e-4 - 1.0))
+        stop = ok2 & (test_T < 0.0001)
+        done = done | stop
+        take = ok2 & ~stop
+        C = C + np.where(take, alpha * T, 0.0)[None] * g["rgb"][i][:, None, None]
+        T = np.where(take, test_T, T)
+        last = np.where(take, contributor, last)
+        blended[k] = take
+    color = C + T[None] * bg[:, None, None]
+    sig = (blended.tobytes(), g["radii"].tobytes(), g["rect"].tobytes(), (g["rgb"] > 0).tobytes())
+    return dict(color=color, final_T=T, n_contrib=last, radii=g["radii"], order=order, g=g, sig=sig, blended=blended, raw=raws)
+
+
+def known_answer_big(sc, sample, clamp_model=False):
+    """Known answers of a scene too big for the scalar loops: forward by forward64v; finite differences for the
+    Gaussians in `sample` only (every parameter of those), one Gaussian re-projected per evaluation."""
+    margins = []
+    base = forward64v(sc, margins=margins)
+    need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
+    for m in margins:
+        assert m[1] > need[m[0]], (sc["name"], "scene sits on a discrete decision", m)
+    dep = [base["g"]["depth"][i] for i in base["order"]]
+    for a, b in zip(dep, dep[1:]):
+        assert a == b or b - a > 1e-5, (sc["name"], "depths too close", a, b)
+    res = dict(color=base["color"], final_T=base["final_T"], n_contrib=base["n_contrib"].astype(np.int32), radii=base["radii"])
+    if sample is None:
+        return res, base
+    g0 = base["g"]
+    frozen = (g0["clampx"], g0["tx"], g0["clampy"], g0["ty"])
+    G = sc["dL_dpix"].astype(np.float64)
+    order = base["order"]
+    clamp_ref = None
+    if clamp_model:
+        clamped = base["raw"] > 0.99
+        # (only pairs that are evaluated at all matter; a clamped pair must not sit on the clamp's edge either)
+        edge = np.abs(base["raw"][base["blended"]] - 0.99)
+        assert edge.min() > 1e-3, (sc["name"], "a blended pair sits on the 0.99 clamp", edge.min())
+        assert (clamped & base["blended"]).sum() > 0, (sc["name"], "no clamped pair")
+        clamp_ref = (clamped, base["raw"])
+        again = forward64v(sc, frozen, None, order, gcache=g0, clamp_ref=clamp_ref)
+        assert np.abs(again["color"] - base["color"]).max() < 1e-14
+    base_sig = forward64v(sc, frozen, None, order, gcache=g0, clamp_ref=clamp_ref)["sig"]
+    assert base_sig == base["sig"]
+
+    def loss(scene, only, d_xy=None):
+        f = forward64v(scene, frozen, d_xy, order, gcache=g0, only=only, clamp_ref=clamp_ref)
+        return float((f["color"] * G).sum()), f["sig"]
+
+    def central(make, scale):
+        for h in (1e-6 * scale, 1e-7 * scale, 1e-8 * scale, 1e-9 * scale):
+            (lp, sp), (lm, sm) = loss(*make(+h)), loss(*make(-h))
+            if sp == base["sig"] and sm == base["sig"]:
+                return (lp - lm) / (2 * h)
+        raise AssertionError((sc["name"], "no step keeps the discrete decisions"))
+
+    def fd_rows(key):
+        arr = sc[key].astype(np.float64)
+        a2 = arr.reshape(arr.shape[0], -1)
+        out = np.zeros((len(sample), a2.shape[1]))
+        for r, i in enumerate(sample):
+            for c in range(a2.shape[1]):
+                def make(h, i=i, c=c):
+                    a = a2.copy()
+                    a[i, c] += h
+                    return dict(sc, **{key: a.reshape(arr.shape)}), i
+                out[r, c] = central(make, max(1.0, abs(float(a2[i, c]))))
+        return out.reshape((len(sample),) + arr.shape[1:])
+
+    P = sc["means3D"].shape[0]
+    res["sample"] = np.asarray(sample, np.int32)
+    res["dL_dmeans3D"] = fd_rows("means3D")
+    res["dL_dopacity"] = fd_rows("opacities").reshape(len(sample), 1)
+    res["dL_dsh"] = fd_rows("shs")
+    res["dL_dscales"] = fd_rows("scales")
+    res["dL_drotations"] = fd_rows("rotations")
+    d2 = np.zeros((len(sample), 3))
+    for r, i in enumerate(sample):
+        for k, half in ((0, 0.5 * sc["W"]), (1, 0.5 * sc["H"])):
+            def make(h, i=i, k=k):
+                d = np.zeros((P, 2))
+                d[i, k] = h
+                return sc, None, d
+            d2[r, k] = central(make, 1.0) * half
+    res["dL_dmeans2D"] = d2
+    return res, base
+
+
 def known_answer(sc, grads=True):
     margins = []
     base = forward64(sc, margins=margins)
     worst = {}
-    for k, v in margins:
+    for k, v, _ in margins:
         worst[k] = min(worst.get(k, np.inf), v)
     need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
     for k, v in worst.items():
@@ -341,6 +495,65 @@ def scenes():
              rotations=np.stack([quat((0, 0, 1), 0)] * 2), opacities=np.asarray([1.0, 0.9], f32), shs=sh(2, 0, 1), D=0,
              forward_only=True)
     out.append(s)
+
+    # G: the 0.99 clamp WITH gradients (frozen-offset model, see the module docstring): an opaque Gaussian (opacity 1:
+    #    clamped within ~0.14 sigma of its centre) between a translucent one in front and a wide one behind
+    s = base("alpha_clamp_gradient", 32, 32, 0.25, bg=(0.1, 0.4, 0.2))
+    zc = 1.5   # (centre 3e-3 px off pixel (15, 15): that pixel and its four neighbours have opacity * G > 0.99)
+    s.update(means3D=np.asarray([[0.012, -0.01, 1.2], [ndc(15.003, 32) * s["tanfovx"] * zc, ndc(14.998, 32) * s["tanfovy"] * zc, zc],
+                                 [0.03, 0.02, 2.0]], f32),
+             scales=np.asarray([[0.05, 0.03, 0.04], [0.2, 0.2, 0.2], [0.12, 0.1, 0.1]], f32),
+             rotations=np.stack([quat((1, 1, 0), 30), quat((0, 0, 1), 0), quat((0, 1, 1), 60)]),
+             opacities=np.asarray([0.45, 1.0, 0.8], f32), shs=sh(3, 1, 4), D=1, big=True, clamp_model=True, sample=[0, 1, 2])
+    out.append(s)
+
+    # H: lists at the scale of a real frame (see the module docstring).  48 x 48 pixels; a dense cluster of 300 small,
+    #    faint splats over one 8 x 8 tile; 110 medium ones everywhere; 25 wide ones across several tiles; 15 opaque ones at
+    #    the back of the cluster, so that some pixels cross T < 1e-4 only hundreds of entries into their list.
+    s = base("big_lists", 48, 48, 0.3, T=(0.01, -0.02, 0.0), bg=(0.05, 0.1, 0.15))
+    P = 450
+    px_w = lambda zz: 2.0 * s["tanfovx"] * zz / 48.0     # noqa: E731  (world size of a pixel at depth zz)
+    slots = rng.permutation(P)
+    zs = 1.0 + 0.004 * slots + rng.uniform(0.0, 0.001, P)            # distinct depths, gaps > 1e-3
+
+    def draw(i):
+        zz = zs[i]
+        if i < 300:      # cluster over pixels 16..23
+            cx, cy, sig, opa = 19.5 + rng.uniform(-3.5, 3.5), 19.5 + rng.uniform(-3.5, 3.5), rng.uniform(0.8, 1.6), rng.uniform(0.008, 0.04)
+        elif i < 410:    # everywhere
+            cx, cy, sig, opa = rng.uniform(1, 47), rng.uniform(1, 47), rng.uniform(1.2, 3.5), rng.uniform(0.1, 0.6)
+        elif i < 435:    # wide
+            cx, cy, sig, opa = rng.uniform(4, 44), rng.uniform(4, 44), rng.uniform(5.0, 9.0), rng.uniform(0.04, 0.15)
+        else:            # opaque, at the back of the cluster
+            cx, cy, sig, opa = 21.0 + rng.uniform(-2.5, 2.5), 20.0 + rng.uniform(-2.5, 2.5), rng.uniform(1.0, 2.0), rng.uniform(0.85, 0.97)
+        if i >= 435:
+            zz = 3.0 + 0.01 * (i - 435) + rng.uniform(0.0, 0.002)
+        x = ((2 * cx + 1) / 48.0 - 1) * s["tanfovx"] * zz - 0.01
+        y = ((2 * cy + 1) / 48.0 - 1) * s["tanfovy"] * zz + 0.02
+        sc3 = sig * px_w(zz) * rng.uniform(0.6, 1.4, 3)
+        return (np.asarray([x, y, zz], f32), sc3.astype(f32), quat(rng.standard_normal(3), float(rng.uniform(0, 180))), f32(opa))
+
+    m3, sc3, rot, opa = np.zeros((P, 3), f32), np.zeros((P, 3), f32), np.zeros((P, 4), f32), np.zeros(P, f32)
+    for i in range(P):
+        m3[i], sc3[i], rot[i], opa[i] = draw(i)
+    s.update(means3D=m3, scales=sc3, rotations=rot, opacities=opa, shs=sh(P, 1, 4), D=1, big=True)
+    # keep every (pixel, Gaussian) pair and every radius / rectangle away from the discrete decisions: redraw the few
+    # Gaussians that sit on one
+    need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
+    for attempt in range(200):
+        margins = []
+        forward64v(s, margins=margins)
+        bad = sorted({int(mm[2]) for mm in margins if mm[1] <= 2.0 * need[mm[0]]})
+        if not bad:
+            break
+        for i in bad:
+            s["means3D"][i], s["scales"][i], s["rotations"][i], s["opacities"][i] = draw(i)
+    else:
+        raise AssertionError("big_lists: could not move every pair off the decisions")
+    pick = np.concatenate([rng.choice(300, 16, replace=False), 300 + rng.choice(110, 10, replace=False),
+                           410 + rng.choice(25, 5, replace=False), 435 + rng.choice(15, 5, replace=False)])
+    s["sample"] = sorted(int(v) for v in pick)
+    out.append(s)
     return out
 
 
@@ -348,17 +561,26 @@ def main():
     blob = {}
     names = []
     for sc in scenes():
-        ka = known_answer(sc, grads=not sc.get("forward_only", False))
         n = sc["name"]
+        if sc.get("big"):
+            ka, base = known_answer_big(sc, sc.get("sample"), clamp_model=sc.get("clamp_model", False))
+            if sc.get("clamp_model"):
+                print(n, "clamped blended pairs", int(((base["raw"] > 0.99) & base["blended"]).sum()))
+        else:
+            ka = known_answer(sc, grads=not sc.get("forward_only", False))
+            # the pixel-vectorised forward used for the big scenes is the same function
+            a, b = forward64(sc), forward64v(sc)
+            assert np.abs(a["color"] - b["color"]).max() < 1e-13 and np.array_equal(a["n_contrib"], b["n_contrib"]), n
+            assert np.abs(a["final_T"] - b["final_T"]).max() < 1e-14, n
         names.append(n)
         for k, v in sc.items():
-            if k in ("name", "forward_only") or v is None:
+            if k in ("name", "forward_only", "big", "clamp_model", "sample") or v is None:
                 continue
             blob[f"{n}/in/{k}"] = np.asarray(v)
         for k, v in ka.items():
             blob[f"{n}/out/{k}"] = np.asarray(v)
-        print(n, "radii", ka["radii"], "min final_T", float(ka["final_T"].min()), "max n_contrib", int(ka["n_contrib"].max()),
-              "terminated px", int(((ka["final_T"] < 1e-3)).sum()))
+        print(n, "P", sc["means3D"].shape[0], "radii max", int(ka["radii"].max()), "min final_T", float(ka["final_T"].min()),
+              "max n_contrib", int(ka["n_contrib"].max()), "terminated px", int(((ka["final_T"] < 1e-3)).sum()), flush=True)
     blob["names"] = np.asarray(names)
     np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **blob)
 

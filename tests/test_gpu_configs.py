@@ -61,7 +61,7 @@ def test_config2_head_100k_512_forward_backward(gpu_device):
     ll = _ref_tile_lists(h.radii.cpu().numpy(), h.geometry(0, 2), 512, 512)
     assert int((ll > 0).sum()) == 351 and int(ll.max()) == 1570 and int(ll.sum()) == h.counts.num_rendered
     assert 256 < h.counts.max_tile_list <= 1024  # the 4-wave medium sorter is the tier this configuration exercises
-    _check_backward(o, h, _dpix(512, 512), "config2")
+    _check_backward(o, h, _dpix(512, 512), "config2", max_skip_frac=0.005)
 
 
 @pytest.mark.parametrize("variant", ["init", "stress"])
@@ -79,7 +79,7 @@ def test_config5_head_500k_1024(variant, gpu_device):
     assert h.counts.num_rendered == o.num_rendered and abs(int(h.counts.num_rendered) - want_R) <= 2e-3 * want_R
     ll = _ref_tile_lists(h.radii.cpu().numpy(), h.geometry(0, 2), 1024, 1024)
     assert abs(int(ll.max()) - want_max) <= 0.03 * want_max and int(ll.sum()) == h.counts.num_rendered
-    _check_backward(o, h, _dpix(1024, 1024), "config5-" + variant)
+    _check_backward(o, h, _dpix(1024, 1024), "config5-" + variant, max_skip_frac=0.01)
 
 
 FUZZ = [(seed, False) for seed in range(16)] + [(100 + seed, True) for seed in range(8)]
@@ -105,7 +105,9 @@ def test_fuzz_random_configurations(seed, big, gpu_device):
     o = util.oracle_forward(s)
     h = util.HipFrame(s, gpu_device)
     _check_forward(o, h, name)
-    _check_backward(o, h, _dpix(H, W, seed), name)
+    # (one flip pixel exempts its whole 16x16 list from the tight test: with image-sized splats — scale_hi >= 0.05 — that
+    # list holds a third of the scene; otherwise a few per cent at most)
+    _check_backward(o, h, _dpix(H, W, seed), name, max_skip_frac=0.5 if kw["scale_hi"] >= 0.05 else 0.05)
 
 
 def test_dead_pixel_next_to_live_pixels_gives_finite_gradients(gpu_device):
@@ -277,6 +279,13 @@ def test_bench_exchange_machinery_on_one_gpu_accumulates_rounds_in_place(gpu_dev
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         last = r.stdout.strip().splitlines()[-1]
         j = json.loads(last)
-        assert j["config"]["frames_per_step_per_gpu"] == 2 * rounds and j["dp"]["group_of_one"] and j["dp"]["backend"] == "nccl"
-        sums[rounds] = j["dp"]["grad_checksum"]
-    assert sums[1] > 0 and abs(sums[3] - sums[1]) <= 2e-6 * sums[1], sums
+        d = j["dp"]
+        # the line's value is the literal configs[3] mode (one view per exchange); the amortised mode sits beside it
+        assert j["config"]["frames_per_step_per_gpu"] == 1 and d["group_of_one"] and d["backend"] == "nccl"
+        assert j["value"] == d["modes"]["literal"]["value"] > 0
+        assert d["modes"]["amortised"]["frames_per_step_per_gpu"] == 2 * rounds and d["modes"]["amortised"]["value"] > 0
+        assert [t["payload_bytes"] for t in d["allreduce_table"]] == [20000 * 59 * 4, 20000 * 12 * 4]
+        sums[rounds] = (d["grad_checksum"], d["modes"]["literal"]["grad_checksum"])
+    # (amortised: the mean over rounds x 2 views; literal: view 0 alone — each the same whatever the number of rounds)
+    assert sums[1][0] > 0 and abs(sums[3][0] - sums[1][0]) <= 2e-6 * sums[1][0], sums
+    assert sums[1][1] > 0 and abs(sums[3][1] - sums[1][1]) <= 2e-6 * sums[1][1], sums

@@ -79,12 +79,23 @@ def _flip_affected_gaussians(o, h):
     return mask, int(bad.sum())
 
 
-def _check_backward(o, h, dpix, name):
+SKIPPED = {}   # scene -> (flip pixels, rows exempted from the tight test, fraction of the visible rows): printed with -rP
+
+
+def _check_backward(o, h, dpix, name, max_skip_frac=0.02):
+    """`max_skip_frac`: the largest share of the VISIBLE Gaussians that threshold flips may exempt from the 1e-4 / 2e-4
+    test (they are still held to rel-L2 0.2).  A flip in a 16x16 list of thousands of entries exempts thousands of rows,
+    so dense stress scenes state a larger bound — but every scene states one, and it is asserted."""
     from oracle import oracle
     ob = oracle.backward(o, dpix)
     hb = h.backward(dpix)
     skip, n_flips = _flip_affected_gaussians(o, h)
     assert n_flips <= max(1, int(1e-4 * dpix.shape[1] * dpix.shape[2])), (name, n_flips)
+    n_vis = max(1, int((o.radii > 0).sum()))
+    frac = float(skip.sum()) / n_vis
+    SKIPPED[name] = (n_flips, int(skip.sum()), round(frac, 5))
+    print(f"[skipped rows] {name}: {n_flips} flip pixel(s) exempt {int(skip.sum())} of {n_vis} visible Gaussians ({frac:.4%}) from the tight test")
+    assert frac <= max_skip_frac, (name, "threshold flips exempt too many rows from the tight gradient test", n_flips, int(skip.sum()), n_vis, frac)
     keep = ~skip
     for k in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
               "dL_drotations"]:

@@ -24,6 +24,36 @@ def test_uv_raster_of_two_triangles():
     assert (np.fliplr(p2f).diagonal() == 0).all()             # texel centres ON the shared edge u = v: the lowest index wins
 
 
+def test_uv_raster_texel_convention_hand_computed():
+    """Pins the texel convention against numbers worked out by hand from pytorch3d 0.7.7's documented rasterizer
+    semantics and the reference's two sign flips (volume_rendering/mesh_sampling.py:31-33,114-116):
+      * the reference hands pytorch3d the vertices (x, y) = (-(2u - 1), -(-(2v - 1))) = (1 - 2u, 2v - 1);
+      * `rasterize_meshes` samples output pixel (yi, xi) at the NDC point (1 - (2 xi + 1) / W, 1 - (2 yi + 1) / H): pixel
+        CENTRES, +X to the left, +Y up, image row 0 at the top;
+      hence texel (yi, xi) <-> u = (2 xi + 1) / (2 S), v = 1 - (2 yi + 1) / (2 S).
+    Two tiny triangles, each containing exactly ONE texel centre of a 4 x 4 raster and no texel corner: corner sampling
+    would leave the raster empty, a bottom-left origin or a missing x flip would put them in other texels."""
+    S = 4
+    # triangle 0 around the centre of texel (row 0, column 0): u = 1/8, v = 7/8 (top-left of the UV square); counter-clockwise
+    # triangle 1 around the centre of texel (row 3, column 2): u = 5/8, v = 1/8; CLOCKWISE (no back-face culling in the UV raster)
+    uv = np.array([[0.075, 0.85], [0.2, 0.85], [0.125, 0.95],
+                   [0.575, 0.10], [0.625, 0.20], [0.70, 0.10]], np.float64)
+    faces = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    p2f, bary = ms.rasterize_uv(uv, faces, S)
+    want = np.full((S, S), -1, np.int32)
+    want[0, 0], want[3, 2] = 0, 1
+    assert np.array_equal(p2f, want), p2f
+    # barycentrics of the texel centre, by hand: P = (0.125, 0.875): v: 0.85 + 0.1 wC = 0.875 -> wC = 1/4;
+    # u: 0.075 wA + 0.2 wB + 0.125 / 4 = 0.125 with wA + wB = 3/4 -> wB = 0.3, wA = 0.45
+    assert np.allclose(bary[0, 0], [0.45, 0.3, 0.25], atol=1e-6), bary[0, 0]
+    # P = (0.625, 0.125): v: 0.10 + 0.10 wB = 0.125 -> wB = 1/4; u: 0.575 wA + 0.625 / 4 + 0.70 wC = 0.625 with
+    # wA + wC = 3/4 -> 0.575 * 0.75 + 0.125 wC = 0.46875 -> wC = 0.3, wA = 0.45
+    assert np.allclose(bary[3, 2], [0.45, 0.25, 0.3], atol=1e-6), bary[3, 2]
+    # the sampler lists covered texels in row-major order: the top-left triangle first
+    fi, bc = ms.uniform_sampling_barycoords(S * S, uv, faces, strict=False)
+    assert fi.tolist() == [0, 1] and np.allclose(bc, [[0.45, 0.3, 0.25], [0.45, 0.25, 0.3]], atol=1e-6)
+
+
 def test_uniform_sampling_counts_and_order():
     uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
     faces = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
