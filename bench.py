@@ -217,6 +217,52 @@ class HipEngine:
             v.graph = v.graphs[0]
         self.graph = self.views[0].graph
 
+    def batch_frame(self, views):
+        """The views' frames through ONE launch chain (render_batch -> fr_forward_batch / fr_backward_batch)."""
+        from fateavatar_amd.render import render_batch
+        for v in views:
+            v.pc.begin_step()
+        outs = render_batch([v.cam for v in views], [v.pc for v in views], [v.bg for v in views], slots=[v.k for v in views])
+        torch.autograd.backward([o["render"] for o in outs], grad_tensors=[v.dL_dpix for v in views])
+
+    def measure_batched(self, K, reps):
+        """K views per launch chain, one stream, one captured graph: frames/s (None if it cannot be set up here)."""
+        from fateavatar_amd import scenes
+        views = list(self.all_views[:K])
+        while len(views) < K:   # (more views than the stream mode uses: a further camera around the head)
+            k = len(views)
+            views.append(_View(self, k, scenes.head_scene(P=self.args.P, res=self.args.res, sh_degree=self.args.sh_degree, seed=0,
+                                                          view=self.rank * K + k, n_views=max(K, 1), scale=self.args.scale,
+                                                          opacity=self.args.opacity)))
+        for _ in range(3):
+            self.batch_frame(views)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=self.dev)
+        with self.rasterizer.no_wait():
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.batch_frame(views)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                self.batch_frame(views)
+        torch.cuda.synchronize()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for v in views:
+            with self.rasterizer.handle_slot(v.k):
+                if self.rasterizer.check_async_overflow(self.local):
+                    return None
+        return {"value": round(K * reps / dt, 2), "unit": "frames/s", "views_per_launch_chain": K, "streams": 1,
+                "launches_per_frame": round(6.0 / K, 2), "us_per_launch_chain": round(dt / reps * 1e6, 1)}
+
     def calibrate(self, world):
         """--in-flight 0 (default): how many views should be in flight?  It depends on how the runtime maps streams to
         hardware queues (three is best with its default four queues), so it is measured: 40 steps with 1,
@@ -526,6 +572,11 @@ def main():
         eng.sync()
         single = {"value": round(args.steps * rounds / (time.perf_counter() - t1), 2), "unit": "frames/s", "frames_in_flight": 1}
 
+    # K views through ONE launch chain (render_batch): the in-flight gain without any stream / hardware-queue arrangement
+    batched = None
+    if not STUB and not exchanging and args.graph:
+        batched = [b for b in (eng.measure_batched(K, max(20, args.steps * rounds // 2)) for K in (2, 3, 4)) if b is not None]
+
     prof, counts = eng.finish()
 
     # ---- data-parallel record: who took part, what was exchanged, how long one exchange takes on its own
@@ -636,6 +687,9 @@ def main():
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            # the same frames with K views per launch chain on ONE stream (fr_forward_batch / fr_backward_batch); `value`
+            # above is the stream mode (a stream, a handle and a graph per view)
+            "batched_views": batched,
             # every stage's algorithmic bytes over the measured frame rate: the whole path against HBM
             "frame_roofline": (None if not prof else {
                 "algorithmic_bytes_per_frame": int(sum(sb.values())), "achieved": round(sum(sb.values()) * fps / world / 1e9, 1),

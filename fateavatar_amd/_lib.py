@@ -38,6 +38,7 @@ class fr_params(C.Structure):
 FR_ADAM_MAX_SEGMENTS = 16
 FR_ADAM_STATE_FLOATS = 576
 FR_ADAM_MAX_GRADS = 4
+FR_MAX_BATCH = 4
 
 
 class fr_adam_config(C.Structure):
@@ -70,7 +71,7 @@ class fr_counts(C.Structure):
 
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
-           "fr_binning_bytes", "fr_forward", "fr_read_counts", "fr_backward", "fr_mark_visible", "fr_image_final_T",
+           "fr_binning_bytes", "fr_forward", "fr_forward_batch", "fr_read_counts", "fr_backward", "fr_backward_batch", "fr_mark_visible", "fr_image_final_T",
            "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_adam_step_multi", "fr_l1_workspace_bytes", "fr_l1_loss_grad", "fr_multi_copy", "fr_scaled_sum", "fr_face_scale",
            "fr_bind_forward", "fr_bind_backward"]
 
@@ -119,6 +120,14 @@ def lib():
     L.fr_forward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,
                              C.c_uint64, C.POINTER(fr_counts), C.c_void_p]
     L.fr_forward.restype = C.c_int
+    # batched frames: arrays (one entry per view) of what fr_forward / fr_backward take
+    _pp = C.POINTER(C.c_void_p)
+    L.fr_forward_batch.argtypes = [C.c_int32, _pp, C.POINTER(C.POINTER(fr_params)), C.POINTER(C.POINTER(fr_inputs)), _pp, _pp,
+                                   _pp, _pp, _pp, C.POINTER(C.c_uint64), C.POINTER(fr_counts), C.c_void_p]
+    L.fr_forward_batch.restype = C.c_int
+    L.fr_backward_batch.argtypes = [C.c_int32, _pp, C.POINTER(C.POINTER(fr_params)), C.POINTER(C.POINTER(fr_inputs)), _pp, _pp,
+                                    _pp, _pp, _pp, C.POINTER(C.POINTER(fr_grads)), C.c_void_p]
+    L.fr_backward_batch.restype = C.c_int
     L.fr_read_counts.argtypes = [C.c_void_p, C.POINTER(fr_counts)]
     L.fr_read_counts.restype = C.c_int
     L.fr_backward.argtypes = [C.c_void_p, C.POINTER(fr_params), C.POINTER(fr_inputs), _fp, _fp, _fp, _fp, _fp,

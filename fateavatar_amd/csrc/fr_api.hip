@@ -202,8 +202,33 @@ int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* 
     if (!out_color || !image || (prm->P > 0 && (!radii || !geometry)) || (binning_capacity > 0 && !binning))
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "null output / scratch pointer");
     if (binning_capacity >= (1ull << 32)) return fail_msg(FR_ERR_UNSUPPORTED, "binning capacity must be < 2^32 instances");
-    return launch_forward(h, *prm, *in, out_color, radii, geometry, image, binning, binning_capacity, counts,
-                          static_cast<hipStream_t>(stream));
+    const ForwardCall c = {h, prm, in, out_color, radii, geometry, image, binning, binning_capacity, counts};
+    return launch_forward(1, &c, static_cast<hipStream_t>(stream));
+}
+
+int fr_forward_batch(int32_t n_views, fr_handle* const* handles, const fr_params* const* prm, const fr_inputs* const* in,
+                     float* const* out_color, int32_t* const* radii, void* const* geometry, void* const* image,
+                     void* const* binning, const uint64_t* binning_capacity, fr_counts* counts, void* stream)
+{
+    if (n_views < 1 || n_views > kMaxBatch) return fail_msg(FR_ERR_INVALID_ARGUMENT, "n_views must be 1 .. FR_MAX_BATCH");
+    if (!handles || !prm || !in || !out_color || !radii || !geometry || !image || !binning || !binning_capacity)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument array");
+    ForwardCall c[kMaxBatch];
+    for (int k = 0; k < n_views; k++) {
+        fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(handles[k]);
+        if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
+        for (int j = 0; j < k; j++)
+            if (handles[j] == handles[k]) return fail_msg(FR_ERR_INVALID_ARGUMENT, "the views of a batch need a handle each");
+        int rc = check_frame(prm[k], in[k], true);
+        if (rc) return rc;
+        if (n_views > 1 && prm[k]->P <= 0) return fail_msg(FR_ERR_INVALID_ARGUMENT, "batched views need P > 0");
+        if (!out_color[k] || !image[k] || (prm[k]->P > 0 && (!radii[k] || !geometry[k])) || (binning_capacity[k] > 0 && !binning[k]))
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "null output / scratch pointer");
+        if (binning_capacity[k] >= (1ull << 32)) return fail_msg(FR_ERR_UNSUPPORTED, "binning capacity must be < 2^32 instances");
+        c[k] = ForwardCall{h, prm[k], in[k], out_color[k], radii[k], geometry[k], image[k], binning[k], binning_capacity[k],
+                           counts ? counts + k : nullptr};
+    }
+    return launch_forward(n_views, c, static_cast<hipStream_t>(stream));
 }
 
 int fr_read_counts(fr_handle* hh, fr_counts* counts)
@@ -228,7 +253,31 @@ int fr_backward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, const 
     if (prm->P == 0) return FR_OK;
     if (!radii || !geometry || !image || !binning || !dL_dpix || !grads)
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "null pointer");
-    return launch_backward(h, *prm, *in, radii, geometry, image, binning, dL_dpix, *grads, static_cast<hipStream_t>(stream));
+    const BackwardCall c = {h, prm, in, radii, geometry, image, binning, dL_dpix, grads};
+    return launch_backward(1, &c, static_cast<hipStream_t>(stream));
+}
+
+int fr_backward_batch(int32_t n_views, fr_handle* const* handles, const fr_params* const* prm, const fr_inputs* const* in,
+                      const int32_t* const* radii, void* const* geometry, const void* const* image, const void* const* binning,
+                      const float* const* dL_dpix, const fr_grads* const* grads, void* stream)
+{
+    if (n_views < 1 || n_views > kMaxBatch) return fail_msg(FR_ERR_INVALID_ARGUMENT, "n_views must be 1 .. FR_MAX_BATCH");
+    if (!handles || !prm || !in || !radii || !geometry || !image || !binning || !dL_dpix || !grads)
+        return fail_msg(FR_ERR_INVALID_ARGUMENT, "null argument array");
+    BackwardCall c[kMaxBatch];
+    for (int k = 0; k < n_views; k++) {
+        fr_handle_impl* h = reinterpret_cast<fr_handle_impl*>(handles[k]);
+        if (!h) return fail_msg(FR_ERR_INVALID_ARGUMENT, "null handle");
+        for (int j = 0; j < k; j++)
+            if (handles[j] == handles[k]) return fail_msg(FR_ERR_INVALID_ARGUMENT, "the views of a batch need a handle each");
+        int rc = check_frame(prm[k], in[k], false);
+        if (rc) return rc;
+        if (prm[k]->P <= 0) return fail_msg(FR_ERR_INVALID_ARGUMENT, "batched views need P > 0");
+        if (!radii[k] || !geometry[k] || !image[k] || !binning[k] || !dL_dpix[k] || !grads[k])
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "null pointer");
+        c[k] = BackwardCall{h, prm[k], in[k], radii[k], geometry[k], image[k], binning[k], dL_dpix[k], grads[k]};
+    }
+    return launch_backward(n_views, c, static_cast<hipStream_t>(stream));
 }
 
 int fr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

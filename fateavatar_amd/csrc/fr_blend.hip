@@ -378,11 +378,37 @@ __device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t b
 // than 1024 are left to k_tile_sort_big.
 constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
 
-__global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint32_t Q, u64* keys, float4* recs,
-                                                   GeomView g, uint4* unit_tile, uint32_t unit_cap, float* unit_tseg,
-                                                   int take_long_lists, fr_counts* host_counts, uint32_t* unit_done,
-                                                   float* empty_color, const float* __restrict__ bg, int W, int H)
+struct SortArgs {
+    ImageView v;
+    uint32_t T, Q;
+    u64* keys;
+    float4* recs;
+    GeomView g;
+    uint4* unit_tile;
+    uint32_t unit_cap;
+    float* unit_tseg;
+    int take_long_lists;
+    fr_counts* host_counts;
+    uint32_t* unit_done;
+    float* empty_color;
+    const float* bg;
+    int W, H;
+};
+
+__device__ __forceinline__ void tile_sort_body(const SortArgs& a)
 {
+    const ImageView v = a.v;
+    const uint32_t T = a.T, Q = a.Q, unit_cap = a.unit_cap;
+    u64* keys = a.keys;
+    float4* recs = a.recs;
+    const GeomView g = a.g;
+    uint4* unit_tile = a.unit_tile;
+    float* unit_tseg = a.unit_tseg;
+    const int take_long_lists = a.take_long_lists, W = a.W, H = a.H;
+    fr_counts* host_counts = a.host_counts;
+    uint32_t* unit_done = a.unit_done;
+    float* empty_color = a.empty_color;
+    const float* __restrict__ bg = a.bg;
     __shared__ SortXchgT<4> sx;
     const bool overflow = frame_overflow(v.counts, v.bucket_cap);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -426,7 +452,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     {
         const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
-        if (tile < T) {
+        if (blockIdx.x - kMediumSorters < Q && tile < T) {   // (a batched launch's grid is the largest view's)
             if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_total[tile];
@@ -463,13 +489,27 @@ __global__ void __launch_bounds__(256) k_tile_sort(ImageView v, uint32_t T, uint
     }
 }
 
+__global__ void __launch_bounds__(256) k_tile_sort(SortArgs a) { tile_sort_body(a); }
+__global__ void __launch_bounds__(256) k_tile_sort_batch(BatchOf<SortArgs> b) { tile_sort_body(b.v[blockIdx.y]); }
+
 // Lists longer than kSortGroupMax (dense / zoomed-in scenes): 4 waves x 16 keys per lane up to 4096, the
 // global-memory network beyond.  A separate kernel so that its register budget (16 keys per lane) does not
 // lower the occupancy of the common path.
 constexpr uint32_t kBigSorters = 512;
 
-__global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, float4* recs, GeomView g)
+struct BigSortArgs {
+    ImageView v;
+    u64* keys;
+    float4* recs;
+    GeomView g;
+};
+
+__device__ __forceinline__ void tile_sort_big_body(const BigSortArgs& a)
 {
+    const ImageView v = a.v;
+    u64* keys = a.keys;
+    float4* recs = a.recs;
+    const GeomView g = a.g;
     __shared__ SortXchgT<16> sx;
     SortXchgT<8>& sx8 = *reinterpret_cast<SortXchgT<8>*>(&sx);   // (lists up to 2048: half the network)
     if (frame_overflow(v.counts, v.bucket_cap)) return;
@@ -489,6 +529,9 @@ __global__ void __launch_bounds__(256) k_tile_sort_big(ImageView v, u64* keys, f
                          (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
     }
 }
+
+__global__ void __launch_bounds__(256) k_tile_sort_big(BigSortArgs a) { tile_sort_big_body(a); }
+__global__ void __launch_bounds__(256) k_tile_sort_big_batch(BatchOf<BigSortArgs> b) { tile_sort_big_body(b.v[blockIdx.y]); }
 
 // ------------------------------------------------------------------ LDS staging of a tile's list
 // A wavefront walks its tile's record array in batches of 64: lane i fetches record i of the
@@ -712,7 +755,10 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
 // record-major one, done in registers: v_permlane32_swap for the 32 x 32 blocks, rotate + v_bfi for the rest.
 // LDS per wave decides how many units are in flight per CU (the kernel is latency-bound: a unit is a chain of
 // dependent LDS round trips): 9.25 KB -> 16 waves per CU, enough for every unit of BASELINE config 2 to be resident.
-constexpr int kPairCap = 640;    // (q, w) slots per wave; denser units are processed in several record ranges
+#ifndef FR_PAIR_CAP
+#define FR_PAIR_CAP 640
+#endif
+constexpr int kPairCap = FR_PAIR_CAP;    // (q, w) slots per wave; denser units are processed in several record ranges
 constexpr int kARecs = 2;         // records per phase-A iteration (3 and 4 measured: no faster, the T / accum_rec chain is the iteration)
 
 struct SparseLds {
@@ -1130,15 +1176,39 @@ __device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __res
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __restrict__ counts,
-                                                           const uint4* __restrict__ unit_tile,
-                                                           const float4* __restrict__ recs, uint2* __restrict__ masks, int W,
-                                                           int H, int tiles_x, float* g_tseg, float* g_out,
-                                                           uint32_t dense_pairs, int pair_hist, uint32_t* unit_done,
-                                                           const ImageView v, float4* __restrict__ unit_state,
-                                                           const float* __restrict__ bg, float* __restrict__ out_color,
-                                                           uint32_t chain_spins)
+struct ChainArgs {
+    DeviceCounts* counts;
+    const uint4* unit_tile;
+    const float4* recs;
+    uint2* masks;
+    int W, H, tiles_x;
+    float* g_tseg;
+    float* g_out;
+    uint32_t dense_pairs;
+    int pair_hist;
+    uint32_t* unit_done;
+    ImageView v;
+    float4* unit_state;
+    const float* bg;
+    float* out_color;
+    uint32_t chain_spins;
+};
+
+__device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
 {
+    DeviceCounts* __restrict__ counts = a.counts;
+    const uint4* __restrict__ unit_tile = a.unit_tile;
+    const float4* __restrict__ recs = a.recs;
+    uint2* __restrict__ masks = a.masks;
+    const int W = a.W, H = a.H, tiles_x = a.tiles_x, pair_hist = a.pair_hist;
+    float* g_tseg = a.g_tseg;
+    float* g_out = a.g_out;
+    const uint32_t dense_pairs = a.dense_pairs, chain_spins = a.chain_spins;
+    uint32_t* unit_done = a.unit_done;
+    const ImageView v = a.v;
+    float4* __restrict__ unit_state = a.unit_state;
+    const float* __restrict__ bg = a.bg;
+    float* __restrict__ out_color = a.out_color;
     __shared__ float4 s_rec_all[kWavesPerWG][kBatch * kRecQuads];
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1253,6 +1323,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_chained(DeviceCounts* __rest
     gather_tile<true>(v, ui.ty * (uint32_t)v.tiles_x + ui.tx, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
 }
 
+__global__ void __launch_bounds__(256) k_unit_blend_chained(ChainArgs a) { unit_blend_chained_body(a); }
+__global__ void __launch_bounds__(256) k_unit_blend_chained_batch(BatchOf<ChainArgs> b) { unit_blend_chained_body(b.v[blockIdx.y]); }
+
 // the gather as its own launch (FR_BLEND_FWD=gather): one wave per tile
 __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restrict__ counts, const ImageView v,
                                                     const float* __restrict__ g_out, float4* __restrict__ unit_state, int W,
@@ -1289,11 +1362,27 @@ extern "C" int fr_debug_read_bwd_trace(void* dst, size_t bytes)
 #define FR_STAMPV(K, V) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCounts* __restrict__ counts, const ImageView v,
-                                                              void* binning, int W, int H, const float* __restrict__ bg,
-                                                              const float* __restrict__ dL_dpix, float* __restrict__ accum,
-                                                              uint32_t dense_pairs)
+struct BlendBwdArgs {
+    const DeviceCounts* counts;
+    ImageView v;
+    void* binning;
+    int W, H;
+    const float* bg;
+    const float* dL_dpix;
+    float* accum;
+    uint32_t dense_pairs;
+};
+
+__device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a)
 {
+    const DeviceCounts* __restrict__ counts = a.counts;
+    const ImageView v = a.v;
+    void* binning = a.binning;
+    const int W = a.W, H = a.H;
+    const float* __restrict__ bg = a.bg;
+    const float* __restrict__ dL_dpix = a.dL_dpix;
+    float* __restrict__ accum = a.accum;
+    const uint32_t dense_pairs = a.dense_pairs;
     __shared__ SparseLds s_all[kWavesPerWG];
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1538,6 +1627,9 @@ __global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(const DeviceCount
     }
 }
 
+__global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse(BlendBwdArgs a) { unit_blend_bwd_sparse_body(a); }
+__global__ void __launch_bounds__(256) k_unit_blend_bwd_sparse_batch(BatchOf<BlendBwdArgs> b) { unit_blend_bwd_sparse_body(b.v[blockIdx.y]); }
+
 // test hook: run the 36-value reduce-scatter on in[lane*36 + k] and return each lane's result
 __global__ void __launch_bounds__(64) k_selftest_reduce(const float* in, float* out)
 {
@@ -1561,67 +1653,98 @@ static int debug_sync(bool debug, hipStream_t s, const char* stage)
     return FR_OK;
 }
 
-int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          BinningView b, float* out_color, hipStream_t s, bool debug)
+int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
 {
-    const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
-    const uint32_t small_blocks = (T + 3) / 4;
-    const uint32_t unit_wgs = (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG);
+    fr_handle_impl* h0 = f[0].h;
     int rc;
+    SortArgs sa[kMaxBatch];
+    BigSortArgs ba[kMaxBatch];
+    ChainArgs ca[kMaxBatch];
+    uint32_t sort_blocks = 0, unit_wgs = 0, gather_blocks = 0;
+    // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
+    // longer than 1024 (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
+    // (A batch launches it if any of its views asks for it.)
+    bool launch_big = false;
+    for (int k = 0; k < n; k++) {
+        fr_handle_impl* h = f[k].h;
+        launch_big = launch_big || !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
+        if (n > 1 && (!h->gather_in_chain || h->gather_in_chain != h0->gather_in_chain))
+            return fail_msg(FR_ERR_UNSUPPORTED, "batched frames need the gather inside the forward blend (unset FR_BLEND_FWD)");
+    }
+    for (int k = 0; k < n; k++) {
+        fr_handle_impl* h = f[k].h;
+        const fr_params& prm = *f[k].prm;
+        const ImageView& v = f[k].v;
+        const BinningView& b = f[k].b;
+        const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
+        const uint32_t small_blocks = (T + 3) / 4;
+        sort_blocks = max(sort_blocks, small_blocks + kMediumSorters);
+        unit_wgs = max(unit_wgs, (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG));
+        gather_blocks = max(gather_blocks, (T + kWavesPerWG - 1) / kWavesPerWG);
+        SortArgs& a = sa[k];
+        a.v = v, a.T = T, a.Q = small_blocks, a.keys = (u64*)b.keys, a.recs = b.recs, a.g = f[k].g, a.unit_tile = b.unit_tile;
+        a.unit_cap = (uint32_t)b.unit_cap, a.unit_tseg = b.unit_tseg, a.take_long_lists = launch_big ? 0 : 1;
+        a.host_counts = h->host_counts_dev;
+        a.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
+        a.empty_color = h->gather_in_chain ? f[k].out_color : nullptr;
+        a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H;
+        ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].recs = b.recs, ba[k].g = f[k].g;
+        ChainArgs& c = ca[k];
+        c.counts = v.counts, c.unit_tile = b.unit_tile, c.recs = (const float4*)b.recs, c.masks = b.masks;
+        c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
+        c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;
+        c.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
+        c.v = v, c.unit_state = b.unit_state, c.bg = f[k].in->background, c.out_color = f[k].out_color;
+        c.chain_spins = h->chain_spins;
+    }
     {
-        StageScope sc(h, ST_SORT, s);
-        // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
-        // longer than 1024 (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
-        const bool launch_big = !h->counts_seen || h->host_counts->max_tile_list > (uint32_t)kSortGroupMax;
-        // ... and then NEXT TO k_tile_sort, on the handle's side stream: its few long lists take as long as all the
-        // short ones together (config 5: 48 us against 65), the two kernels touch different tiles
+        StageScope sc(h0, ST_SORT, s);
+        // ... and then NEXT TO k_tile_sort, on the (first view's) handle's side stream: its few long lists take as long as
+        // all the short ones together (config 5: 48 us against 65), the two kernels touch different tiles
         if (launch_big) {
-            FR_HIP(hipEventRecord(h->side_fork, s));
-            FR_HIP(hipStreamWaitEvent(h->side_stream, h->side_fork, 0));
-            hipLaunchKernelGGL(k_tile_sort_big, dim3(kBigSorters), dim3(256), 0, h->side_stream, v, (u64*)b.keys, b.recs, g);
-            FR_HIP(hipEventRecord(h->side_join, h->side_stream));
+            FR_HIP(hipEventRecord(h0->side_fork, s));
+            FR_HIP(hipStreamWaitEvent(h0->side_stream, h0->side_fork, 0));
+            launch_views(k_tile_sort_big, k_tile_sort_big_batch, n, ba, kBigSorters, 256, 0, h0->side_stream);
+            FR_HIP(hipEventRecord(h0->side_join, h0->side_stream));
         }
-        hipLaunchKernelGGL(k_tile_sort, dim3(small_blocks + kMediumSorters), dim3(256), 0, s, v, T, small_blocks,
-                           (u64*)b.keys, b.recs, g, b.unit_tile, (uint32_t)b.unit_cap,
-                           b.unit_tseg, launch_big ? 0 : 1,
-                           h->host_counts_dev,  // small_blocks == Q
-                           h->gather_in_chain ? b.unit_done : nullptr,
-                           h->gather_in_chain ? out_color : nullptr, in.background, prm.W, prm.H);
-        // the counts reach the pinned host slot with this kernel: the (waiting) forward blocks on them, not on the frame
-        if (!(prm.flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(h->counts_ready, s));
-        if (launch_big) FR_HIP(hipStreamWaitEvent(s, h->side_join, 0));
+        launch_views(k_tile_sort, k_tile_sort_batch, n, sa, sort_blocks, 256, 0, s);
+        // the counts reach the pinned host slots with this kernel: the (waiting) forward blocks on them, not on the frame
+        for (int k = 0; k < n; k++)
+            if (!(f[k].prm->flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(f[k].h->counts_ready, s));
+        if (launch_big) FR_HIP(hipStreamWaitEvent(s, h0->side_join, 0));
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
     {
-        StageScope sc(h, ST_BLEND_FWD, s);
+        StageScope sc(h0, ST_BLEND_FWD, s);
         // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
-        hipLaunchKernelGGL(k_unit_blend_chained, dim3(unit_wgs), dim3(64 * kWavesPerWG), 0, s, v.counts, b.unit_tile,
-                           (const float4*)b.recs, b.masks, prm.W, prm.H, v.tiles_x, b.unit_tseg, b.unit_out,
-                           h->dense_pairs_fwd, h->debug_pair_hist ? 1 : 0, h->gather_in_chain ? b.unit_done : nullptr, v,
-                           b.unit_state, in.background, out_color, h->chain_spins);
-        if (!h->gather_in_chain)
-            hipLaunchKernelGGL(k_tile_gather, dim3((T + kWavesPerWG - 1) / kWavesPerWG), dim3(64 * kWavesPerWG), 0, s, v.counts,
-                               v, b.unit_out, b.unit_state, prm.W, prm.H, in.background, out_color);
+        launch_views(k_unit_blend_chained, k_unit_blend_chained_batch, n, ca, unit_wgs, 64 * kWavesPerWG, 0, s);
+        if (!h0->gather_in_chain)   // (n == 1, see above)
+            hipLaunchKernelGGL(k_tile_gather, dim3(gather_blocks), dim3(64 * kWavesPerWG), 0, s, f[0].v.counts, f[0].v,
+                               f[0].b.unit_out, f[0].b.unit_state, f[0].prm->W, f[0].prm->H, f[0].in->background, f[0].out_color);
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "blend_fwd"))) return rc;
     return FR_OK;
 }
 
-int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          void* binning, const float* dL_dpix, hipStream_t s, bool debug)
+int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, const ImageView* v, hipStream_t s, bool debug)
 {
     // the unit count lives on the device: fixed grid, grid-stride loop over the units
     const uint32_t unit_grid = kUnitGrid;
+    BlendBwdArgs a[kMaxBatch];
+    for (int k = 0; k < n; k++) {
+        a[k].counts = v[k].counts, a[k].v = v[k], a[k].binning = const_cast<void*>(calls[k].binning);
+        a[k].W = calls[k].prm->W, a[k].H = calls[k].prm->H, a[k].bg = calls[k].in->background;
+        a[k].dL_dpix = calls[k].dL_dpix, a[k].accum = g[k].accum, a[k].dense_pairs = calls[k].h->dense_pairs_bwd;
+    }
     hipEvent_t ev_a, ev_b;
-    if (next_stage_events(h, ST_BLEND_BWD, &ev_a, &ev_b)) {
+    if (n == 1 && next_stage_events(calls[0].h, ST_BLEND_BWD, &ev_a, &ev_b)) {
         // the graded kernel, timed the way a profiler times it: events taken from the dispatch itself
-        hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, v.counts, v,
-                              binning, prm.W, prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        hipExtLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, ev_a, ev_b, 0, a[0]);
     } else {
-        hipLaunchKernelGGL(k_unit_blend_bwd_sparse, dim3(unit_grid), dim3(64 * kWavesPerWG), 0, s, v.counts, v, binning, prm.W,
-                           prm.H, in.background, dL_dpix, g.accum, h->dense_pairs_bwd);
+        StageScope sc(n > 1 ? calls[0].h : nullptr, ST_BLEND_BWD, s);
+        launch_views(k_unit_blend_bwd_sparse, k_unit_blend_bwd_sparse_batch, n, a, unit_grid, 64 * kWavesPerWG, 0, s);
     }
     FR_HIP(hipGetLastError());
     return debug_sync(debug, s, "blend_bwd");

@@ -166,6 +166,14 @@ struct ImageView {
 
 constexpr int kUnit = 64;  // records per blend unit (= one LDS batch of one wavefront)
 
+// Batched frames (fr_forward_batch / fr_backward_batch): up to kMaxBatch views share every launch of the frame; a
+// launch's grid is (largest per-view grid, views) and a workgroup takes the argument block of view blockIdx.y.
+constexpr int kMaxBatch = 4;
+template <typename A>
+struct BatchOf {
+    A v[kMaxBatch];
+};
+
 // A blend UNIT is one 64-record segment of one tile's sorted list: the independent work item of the
 // blend kernels.  Per unit and pixel (lane) the forward leaves what the other passes need.
 struct BinningView {
@@ -303,10 +311,56 @@ static inline bool next_stage_events(fr_handle_impl* h, int st, hipEvent_t* a, h
 }
 
 // ---- stage launchers (defined in the .hip files) ----
-int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, float* out_color, int32_t* radii,
-                   void* geometry, void* image, void* binning, uint64_t cap, fr_counts* counts, hipStream_t s);
-int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
-                    const void* image, const void* binning, const float* dL_dpix, const fr_grads& g, hipStream_t s);
+// One view of a (possibly batched) frame as the launchers see it: its handle, the caller's arguments and buffers.
+struct ForwardCall {
+    fr_handle_impl* h;
+    const fr_params* prm;
+    const fr_inputs* in;
+    float* out_color;
+    int32_t* radii;
+    void* geometry;
+    void* image;
+    void* binning;
+    uint64_t cap;
+    fr_counts* counts;   // may be null
+};
+struct BackwardCall {
+    fr_handle_impl* h;
+    const fr_params* prm;
+    const fr_inputs* in;
+    const int32_t* radii;
+    void* geometry;
+    const void* image;
+    const void* binning;
+    const float* dL_dpix;
+    const fr_grads* grads;
+};
+// n views (1 .. kMaxBatch) through the SAME launches: n == 1 uses the plain kernels, n > 1 their *_batch twins with a
+// (grid, n) launch.  Every view has its own handle and buffers; the views' frames are independent of each other.
+int launch_forward(int n, const ForwardCall* calls, hipStream_t s);
+int launch_backward(int n, const BackwardCall* calls, hipStream_t s);
+// what launch_forward has prepared per view when it hands over to the sort + blend launches (fr_blend.hip)
+struct FrameView {
+    fr_handle_impl* h;
+    const fr_params* prm;
+    const fr_inputs* in;
+    GeomView g;
+    ImageView v;
+    BinningView b;
+    float* out_color;
+};
+// kernel for one view, its *_batch twin for several: the twin takes BatchOf<A> and a (gx, n) grid
+template <typename A, typename KS, typename KB>
+static inline void launch_views(KS single, KB batch, int n, const A* args, uint32_t gx, uint32_t threads, size_t lds, hipStream_t s)
+{
+    if (n == 1) {
+        hipLaunchKernelGGL(single, dim3(gx), dim3(threads), lds, s, args[0]);
+    } else {
+        BatchOf<A> b;
+        for (int k = 0; k < kMaxBatch; k++) b.v[k] = args[k < n ? k : 0];
+        hipLaunchKernelGGL(batch, dim3(gx, (uint32_t)n), dim3(threads), lds, s, b);
+    }
+}
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int launch_knn(int P, const float* points, float* out, void* ws, size_t ws_bytes, hipStream_t s, int mode);
 size_t knn_workspace_bytes(int P);

@@ -143,13 +143,14 @@ __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, 
 constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
 constexpr int kCountLdsBytes = 2816 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
 
-__global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
+__device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the frame's device counts (cursors of k_tile_totals) start from zero: the image buffer is caller-owned scratch
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DeviceCounts) / 4) reinterpret_cast<uint32_t*>(a.counts)[threadIdx.x] = 0u;
+    if ((int)(blockIdx.x * kPreWG) >= a.P) return;   // (a batched launch's grid is the largest view's; P > 0: block 0 stays)
     const int M3 = a.M * 3, sh_stride = M3 | 1;
     const float* my_sh = nullptr;
     // every input of this thread is requested up front (camera, mean, scale, rotation, opacity — and the SH block
@@ -466,6 +467,10 @@ __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
     }
 }
 
+__global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a) { preprocess_fwd_body(a); }
+// batched frames: view blockIdx.y
+__global__ void __launch_bounds__(kPreWG) k_preprocess_fwd_batch(BatchOf<PreArgs> b) { preprocess_fwd_body(b.v[blockIdx.y]); }
+
 // Everything between the counting pass and the sort, in ONE wide launch (it used to be a totals kernel plus a
 // single-workgroup scan): per tile, add up the eight per-XCD counter copies, write the sub-list table and leave the
 // counters zeroed for the next frame; then ALLOCATE the tile's record range and blend-unit range.  Nothing needs the
@@ -475,9 +480,20 @@ __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a)
 // reference-semantics num_rendered) are reduced with a few atomics per workgroup; k_tile_sort's first thread turns
 // them into the overflow verdict and the host-visible counts.
 // reference counterparts: InclusiveSum + the blocking count read-back (rasterizer_impl.cu:277-281), identifyTileRanges.
-__global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T, uint64_t capacity,
-                                                     const uint32_t* __restrict__ block_ref_tiles, uint32_t n_blocks)
+struct TotalsArgs {
+    ImageView v;
+    uint32_t T;
+    uint64_t capacity;
+    const uint32_t* block_ref_tiles;
+    uint32_t n_blocks;
+};
+
+__device__ __forceinline__ void tile_totals_body(const TotalsArgs& a)
 {
+    const ImageView v = a.v;
+    const uint32_t T = a.T, n_blocks = a.n_blocks;
+    const uint64_t capacity = a.capacity;
+    const uint32_t* __restrict__ block_ref_tiles = a.block_ref_tiles;
     __shared__ uint32_t s_wave[2][4];     // per-wave totals: instances, units
     __shared__ uint32_t s_base[8];        // workgroup bases: instances, units, medium / big / large list heads
     __shared__ uint32_t s_heads[3];       // workgroup-local list counters
@@ -580,6 +596,9 @@ __global__ void __launch_bounds__(256) k_tile_totals(ImageView v, uint32_t T, ui
     (void)T;
 }
 
+__global__ void __launch_bounds__(256) k_tile_totals(TotalsArgs a) { tile_totals_body(a); }
+__global__ void __launch_bounds__(256) k_tile_totals_batch(BatchOf<TotalsArgs> b) { tile_totals_body(b.v[blockIdx.y]); }
+
 // reference: checkFrustum, rasterizer_impl.cu:54-66
 __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* means3D, const float* view, uint8_t* present)
 {
@@ -599,8 +618,7 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 }
 
 // implemented in fr_blend.hip
-int launch_sort_and_blend(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          BinningView b, float* out_color, hipStream_t s, bool debug);
+int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug);
 
 static int debug_sync(bool debug, hipStream_t s, const char* stage)
 {
@@ -610,20 +628,23 @@ static int debug_sync(bool debug, hipStream_t s, const char* stage)
     return FR_OK;
 }
 
-int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, float* out_color, int32_t* radii,
-                   void* geometry, void* image, void* binning, uint64_t cap, fr_counts* counts, hipStream_t s)
+// Everything one view's forward needs done on the host before its kernels can be enqueued: handle buffers sized, stream
+// ordered behind the handle's previous frame, views of the caller's buffers, the kernels' argument blocks.
+static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, FrameView& f, PreArgs& a, TotalsArgs& tot,
+                           size_t& pre_lds)
 {
+    fr_handle_impl* h = c.h;
+    const fr_params& prm = *c.prm;
+    const fr_inputs& in = *c.in;
     const int P = prm.P, W = prm.W, H = prm.H;
-    GeomView g = GeomView::make(geometry, (size_t)P);
-    ImageView v = ImageView::make(image, W, H);
+    GeomView g = GeomView::make(c.geometry, (size_t)P);
+    ImageView v = ImageView::make(c.image, W, H);
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
-    BinningView b = BinningView::make(binning, (size_t)cap, (size_t)T);
-    const bool debug = prm.debug != 0;
+    BinningView b = BinningView::make(c.binning, (size_t)c.cap, (size_t)T);
     int rc;
-    const bool capturing = note_capture(h, s);
     // The handle's buffers (gradient accumulators, per-tile counters, key buckets) grow with the scene and the tile
-    // grid.  Growing means hipStreamSynchronize + hipFree + hipMalloc, none of which a capturing stream allows — and
-    // trying would invalidate the caller's capture.  Say so before touching the stream.
+    // grid.  Growing means hipMalloc (and freeing or retiring the old buffer), which a capturing stream does not allow —
+    // and trying would invalidate the caller's capture.  Say so before touching the stream.
     if (capturing) {
         const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
         const bool grows = (size_t)P > h->accum_rows || v.tpad > h->tile_counter_tiles || !h->key_buckets
@@ -642,7 +663,7 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     // enqueued on a different stream (fr_common.hpp, fr_handle_impl::frame_done)
     if (!capturing && h->have_last && h->last_stream != s) FR_HIP(hipStreamWaitEvent(s, h->frame_done, 0));
 
-    // per-tile counters: handle-owned, zero between frames (k_tile_sort restores the zeros), so a frame normally
+    // per-tile counters: handle-owned, zero between frames (k_tile_totals restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
     const size_t counter_words = (size_t)kXcds * v.tpad;   // 8 XCD copies
@@ -676,7 +697,6 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
         v.buckets = h->key_buckets, v.bucket_cap = h->bucket_cap;
     }
 
-    PreArgs a;
     a.P = P, a.D = prm.D, a.M = prm.M, a.W = W, a.H = H;
     a.raw = (prm.flags & FR_FLAG_RAW_ACTIVATIONS) ? 1 : 0;
     a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
@@ -687,46 +707,78 @@ int launch_forward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in,
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.visible = prm.aux ? prm.aux->visible : nullptr;
-    a.radii = radii, a.g = g, a.tile_count = v.tile_count, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
+    a.radii = c.radii, a.g = g, a.tile_count = v.tile_count, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
     a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
-    if (P > 0) {
+    const size_t sh_bytes = (in.shs && !in.colors_precomp) ? (size_t)64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+    pre_lds = (kPreWG / 64) * (sh_bytes > (size_t)kCountLdsBytes ? sh_bytes : (size_t)kCountLdsBytes);
+    tot.v = v, tot.T = T, tot.capacity = c.cap, tot.block_ref_tiles = g.block_ref_tiles;
+    tot.n_blocks = (uint32_t)((P + kPreWG - 1) / kPreWG);
+    f.h = h, f.prm = c.prm, f.in = c.in, f.g = g, f.v = v, f.b = b, f.out_color = c.out_color;
+    return FR_OK;
+}
+
+int launch_forward(int n, const ForwardCall* calls, hipStream_t s)
+{
+    FrameView f[kMaxBatch];
+    PreArgs pre[kMaxBatch];
+    TotalsArgs tot[kMaxBatch];
+    int rc;
+    bool capturing = false;
+    for (int k = 0; k < n; k++) capturing = note_capture(calls[k].h, s) || capturing;
+    size_t pre_lds = 0;
+    uint32_t pre_blocks = 0, tot_blocks = 0;
+    bool debug = false, no_wait = true;
+    for (int k = 0; k < n; k++) {
+        size_t lds;
+        if ((rc = prepare_forward(calls[k], s, capturing, f[k], pre[k], tot[k], lds))) return rc;
+        pre_lds = lds > pre_lds ? lds : pre_lds;
+        pre_blocks = max(pre_blocks, (uint32_t)((calls[k].prm->P + kPreWG - 1) / kPreWG));
+        tot_blocks = max(tot_blocks, (f[k].v.tpad + 1023u) / 1024u);
+        debug = debug || calls[k].prm->debug != 0;
+        no_wait = no_wait && (calls[k].prm->flags & FR_FLAG_NO_WAIT) != 0;
+    }
+    fr_handle_impl* h0 = calls[0].h;   // (stage profiling of a batch goes to the first view's handle)
+    if (pre_blocks > 0) {
         {
-            StageScope sc(h, ST_PREPROCESS_FWD, s);
-            const size_t sh_bytes = (in.shs && !in.colors_precomp) ? (size_t)64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
-            const size_t lds = (kPreWG / 64) * (sh_bytes > (size_t)kCountLdsBytes ? sh_bytes : (size_t)kCountLdsBytes);
-            hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + kPreWG - 1) / kPreWG), dim3(kPreWG), lds, s, a);
+            StageScope sc(h0, ST_PREPROCESS_FWD, s);
+            launch_views(k_preprocess_fwd, k_preprocess_fwd_batch, n, pre, pre_blocks, kPreWG, pre_lds, s);
         }
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
     }
     {
-        StageScope sc(h, ST_SCAN, s);
-        if (P <= 0) {   // (k_preprocess_fwd, which zeroes the frame's device counts, did not run)
-            if ((rc = launch_zero(v.counts, sizeof(DeviceCounts), s))) return rc;
-        }
-        hipLaunchKernelGGL(k_tile_totals, dim3((v.tpad + 1023) / 1024), dim3(256), 0, s, v, T, cap, g.block_ref_tiles,
-                           (uint32_t)((P + kPreWG - 1) / kPreWG));
+        StageScope sc(h0, ST_SCAN, s);
+        for (int k = 0; k < n; k++)
+            if (calls[k].prm->P <= 0 || pre_blocks == 0)   // (k_preprocess_fwd, which zeroes the frame's device counts, did not run for it)
+                if ((rc = launch_zero(f[k].v.counts, sizeof(DeviceCounts), s))) return rc;
+        launch_views(k_tile_totals, k_tile_totals_batch, n, tot, tot_blocks, 256, 0, s);
     }
     FR_HIP(hipGetLastError());
-    const bool no_wait = (prm.flags & FR_FLAG_NO_WAIT) != 0;
     if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
-    if ((rc = launch_sort_and_blend(h, prm, in, g, v, b, out_color, s, debug))) return rc;
-    h->counters_clean = true;
-    if (!capturing) {
-        FR_HIP(hipEventRecord(h->frame_done, s));
-        h->last_stream = s, h->have_last = true;
+    if ((rc = launch_sort_and_blend(n, f, s, debug))) return rc;
+    for (int k = 0; k < n; k++) {
+        fr_handle_impl* h = calls[k].h;
+        h->counters_clean = true;
+        if (!capturing) {
+            FR_HIP(hipEventRecord(h->frame_done, s));
+            h->last_stream = s, h->have_last = true;
+        }
     }
-
     if (no_wait) return FR_OK;
     // The whole frame is enqueued; only now wait for the counts (GPU keeps working meanwhile).
-    FR_HIP(hipEventSynchronize(h->counts_ready));
-    h->counts_seen = true;
-    fr_counts c = *h->host_counts;
-    if (counts) *counts = c;
-    if (c.overflow) return FR_ERR_BINNING_CAPACITY;
-    return FR_OK;
+    int result = FR_OK;
+    for (int k = 0; k < n; k++) {
+        fr_handle_impl* h = calls[k].h;
+        if (calls[k].prm->flags & FR_FLAG_NO_WAIT) continue;
+        FR_HIP(hipEventSynchronize(h->counts_ready));
+        h->counts_seen = true;
+        fr_counts c = *h->host_counts;
+        if (calls[k].counts) *calls[k].counts = c;
+        if (c.overflow) result = FR_ERR_BINNING_CAPACITY;
+    }
+    return result;
 }
 
 }  // namespace fr

@@ -441,9 +441,10 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ dst, const floa
 #endif
 constexpr int kPreBwdWaves = FR_PREBWD_WAVES;  // waves per workgroup of k_preprocess_bwd
 
-__global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd(PreBwdArgs a)
+__device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    if ((int)(blockIdx.x * blockDim.x) >= a.P) return;   // (a batched launch's grid is the largest view's)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int M3 = a.M * 3, stride = M3 | 1;
@@ -461,56 +462,71 @@ __global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd(PreBwdArgs
     if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane, ((a.acc >> G_SH) & 1u) != 0u);
 }
 
-int launch_blend_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, GeomView g, ImageView v,
-                          void* binning, const float* dL_dpix, hipStream_t s, bool debug);
+__global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd(PreBwdArgs a) { preprocess_bwd_body(a); }
+__global__ void __launch_bounds__(64 * kPreBwdWaves) k_preprocess_bwd_batch(BatchOf<PreBwdArgs> b) { preprocess_bwd_body(b.v[blockIdx.y]); }
 
-int launch_backward(fr_handle_impl* h, const fr_params& prm, const fr_inputs& in, const int32_t* radii, void* geometry,
-                    const void* image, const void* binning, const float* dL_dpix, const fr_grads& gr, hipStream_t s)
+// implemented in fr_blend.hip: the blend backward of n views (their accumulators in g[k].accum)
+int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, const ImageView* v, hipStream_t s, bool debug);
+
+int launch_backward(int n, const BackwardCall* calls, hipStream_t s)
 {
-    const int P = prm.P;
-    if (P <= 0) return FR_OK;
-    GeomView g = GeomView::make(geometry, (size_t)P);
-    const bool capturing = note_capture(h, s);
-    // backward passes of one handle share its gradient accumulators (the blend backward adds rows, k_preprocess_bwd reads
-    // and re-zeroes them): order this one behind the previous one if that ran on another stream.  (Not inside a capture:
-    // a capture is ordered by its own stream, replays by whoever launches them — as for the forward.)
-    if (!capturing && h->have_last_bwd && h->last_bwd_stream != s) FR_HIP(hipStreamWaitEvent(s, h->bwd_done, 0));
-    {   // gradient accumulators: handle-owned, zero between backward passes (normally sized by the forward already)
-        int rc0 = ensure_accum(h, (size_t)P, s);
-        if (rc0) return rc0;
-        g.accum = h->accum;
+    GeomView g[kMaxBatch];
+    ImageView v[kMaxBatch];
+    PreBwdArgs args[kMaxBatch];
+    bool capturing = false, debug = false;
+    for (int k = 0; k < n; k++) capturing = note_capture(calls[k].h, s) || capturing;
+    size_t lds = 0;
+    uint32_t blocks = 0;
+    const int wg = 64 * kPreBwdWaves;
+    for (int k = 0; k < n; k++) {
+        fr_handle_impl* h = calls[k].h;
+        const fr_params& prm = *calls[k].prm;
+        const fr_inputs& in = *calls[k].in;
+        const int P = prm.P;
+        g[k] = GeomView::make(calls[k].geometry, (size_t)P);
+        // backward passes of one handle share its gradient accumulators (the blend backward adds rows, k_preprocess_bwd
+        // reads and re-zeroes them): order this one behind the previous one if that ran on another stream.  (Not inside a
+        // capture: a capture is ordered by its own stream, replays by whoever launches them — as for the forward.)
+        if (!capturing && h->have_last_bwd && h->last_bwd_stream != s) FR_HIP(hipStreamWaitEvent(s, h->bwd_done, 0));
+        {   // gradient accumulators: handle-owned, zero between backward passes (normally sized by the forward already)
+            int rc0 = ensure_accum(h, (size_t)P, s);
+            if (rc0) return rc0;
+            g[k].accum = h->accum;
+        }
+        v[k] = ImageView::make(const_cast<void*>(calls[k].image), prm.W, prm.H);
+        debug = debug || prm.debug != 0;
+        PreBwdArgs& a = args[k];
+        a.P = P, a.D = prm.D, a.M = prm.M, a.W = prm.W, a.H = prm.H;
+        a.raw = (prm.flags & FR_FLAG_RAW_ACTIVATIONS) ? 1 : 0;
+        a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
+        a.focal_y = prm.H / (2.0f * prm.tan_fovy);
+        a.focal_x = prm.W / (2.0f * prm.tan_fovx);
+        a.scale_modifier = prm.scale_modifier;
+        a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.shs = in.shs;
+        a.cov3D_precomp = in.cov3D_precomp, a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
+        a.radii = calls[k].radii, a.g = g[k], a.out = *calls[k].grads;
+        a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
+        a.denom = prm.aux ? prm.aux->denom : nullptr;
+        a.counts = v[k].counts;
+        a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
+        const size_t l = (in.shs && calls[k].grads->dL_dsh) ? (size_t)kPreBwdWaves * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
+        lds = l > lds ? l : lds;
+        blocks = max(blocks, (uint32_t)((P + wg - 1) / wg));
     }
-    ImageView v = ImageView::make(const_cast<void*>(image), prm.W, prm.H);
-    const bool debug = prm.debug != 0;
     // g.accum is all zero here: zeroed when allocated, and again by k_preprocess_bwd after every backward
-    int rc = launch_blend_backward(h, prm, in, g, v, const_cast<void*>(binning), dL_dpix, s, debug);
+    int rc = launch_blend_backward(n, calls, g, v, s, debug);
     if (rc) return rc;
-
-    PreBwdArgs a;
-    a.P = P, a.D = prm.D, a.M = prm.M, a.W = prm.W, a.H = prm.H;
-    a.raw = (prm.flags & FR_FLAG_RAW_ACTIVATIONS) ? 1 : 0;
-    a.tan_fovx = prm.tan_fovx, a.tan_fovy = prm.tan_fovy;
-    a.focal_y = prm.H / (2.0f * prm.tan_fovy);
-    a.focal_x = prm.W / (2.0f * prm.tan_fovx);
-    a.scale_modifier = prm.scale_modifier;
-    a.means3D = in.means3D, a.scales = in.scales, a.rotations = in.rotations, a.shs = in.shs;
-    a.cov3D_precomp = in.cov3D_precomp, a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
-    a.radii = radii, a.g = g, a.out = gr;
-    a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
-    a.denom = prm.aux ? prm.aux->denom : nullptr;
-    a.counts = v.counts;
-    a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
     {
-        StageScope sc(h, ST_PREPROCESS_BWD, s);
-        const size_t lds = (in.shs && gr.dL_dsh) ? (size_t)kPreBwdWaves * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
-        const int wg = 64 * kPreBwdWaves;
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + wg - 1) / wg), dim3(wg), lds, s, a);
+        StageScope sc(calls[0].h, ST_PREPROCESS_BWD, s);
+        launch_views(k_preprocess_bwd, k_preprocess_bwd_batch, n, args, blocks, (uint32_t)wg, lds, s);
     }
     FR_HIP(hipGetLastError());
-    if (!capturing) {
-        FR_HIP(hipEventRecord(h->bwd_done, s));
-        h->last_bwd_stream = s, h->have_last_bwd = true;
-    }
+    if (!capturing)
+        for (int k = 0; k < n; k++) {
+            fr_handle_impl* h = calls[k].h;
+            FR_HIP(hipEventRecord(h->bwd_done, s));
+            h->last_bwd_stream = s, h->have_last_bwd = true;
+        }
     if (debug) FR_HIP(hipStreamSynchronize(s));
     return FR_OK;
 }

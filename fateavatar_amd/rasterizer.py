@@ -250,6 +250,232 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return tuple(g.values())
 
 
+# ------------------------------------------------------------------ batched frames (fr_forward_batch / fr_backward_batch)
+def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None):
+    """K views through ONE launch chain (include/fr_rasterizer.h, fr_forward_batch): `views` is a list of the positional
+    argument tuples of `rasterize_gaussians` (background ... debug), one per view; view k uses the device's handle
+    `slots[k]` (default k).  Returns the list of `rasterize_gaussians` result tuples.  The results are those of K separate
+    calls; what changes is that every kernel of the frame is launched once for all views."""
+    K = len(views)
+    if not 1 <= K <= _lib.FR_MAX_BATCH:
+        raise RuntimeError(f"rasterize_gaussians_batch: 1 .. {_lib.FR_MAX_BATCH} views")
+    slots = list(range(K)) if slots is None else [int(x) for x in slots]
+    if len(set(slots)) != K:
+        raise RuntimeError("rasterize_gaussians_batch: the views of a batch need a handle slot each")
+    visibles = visibles or [None] * K
+    L = _lib.lib()
+    st = []
+    dev = None
+    for k, a in enumerate(views):
+        (background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+         tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug) = a
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        d = _dev_index(means3D)
+        if dev is None:
+            dev = d
+        elif d != dev:
+            raise RuntimeError("rasterize_gaussians_batch: the views of a batch live on one device")
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        if P == 0:
+            raise RuntimeError("rasterize_gaussians_batch: batched views need at least one Gaussian")
+        opts = dict(device=means3D.device)
+        background, means3D, opacity = _f32c(background), _f32c(means3D), _f32c(opacity)
+        colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        v = dict(P=P, H=H, W=W, opts=opts,
+                 keep=(background, means3D, opacity, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos),
+                 prm=_params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw, _aux(visible=visibles[k])),
+                 inp=_inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos),
+                 out_color=torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, **opts),
+                 radii=torch.empty((P,), dtype=torch.int32, **opts),
+                 geom=torch.empty((L.fr_geometry_bytes(P),), dtype=torch.uint8, **opts),
+                 img=torch.empty((L.fr_image_bytes(W, H),), dtype=torch.uint8, **opts),
+                 cap=max(_capacity_hint.get(d, 0), 4 * P + 65536))
+        st.append(v)
+    handles = (C.c_void_p * K)(*[_lib.handle(dev, sl) for sl in slots])
+    prm_p = (C.POINTER(_lib.fr_params) * K)(*[C.pointer(v["prm"]) for v in st])
+    inp_p = (C.POINTER(_lib.fr_inputs) * K)(*[C.pointer(v["inp"]) for v in st])
+    arr = lambda key: (C.c_void_p * K)(*[v[key].data_ptr() for v in st])  # noqa: E731
+    counts = (_lib.fr_counts * K)()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        while True:
+            for v in st:
+                v["binning"] = torch.empty((L.fr_binning_bytes(v["cap"], v["W"], v["H"]),), dtype=torch.uint8, **v["opts"])
+            caps = (C.c_uint64 * K)(*[v["cap"] for v in st])
+            rc = L.fr_forward_batch(K, handles, prm_p, inp_p, arr("out_color"), arr("radii"), arr("geom"), arr("img"),
+                                    arr("binning"), caps, counts, stream)
+            if rc == _lib.FR_ERR_BINNING_CAPACITY:
+                for k, v in enumerate(st):
+                    if counts[k].overflow:
+                        v["cap"] = int(counts[k].num_instances * 1.25) + 1024
+                continue
+            _check(rc, "fr_forward_batch")
+            break
+    out = []
+    for k, v in enumerate(st):
+        if _no_wait:
+            out.append((0, v["out_color"], v["radii"], v["geom"], v["binning"], v["img"]))
+            continue
+        c = _lib.fr_counts(counts[k].num_rendered, counts[k].num_instances, counts[k].max_tile_list, counts[k].overflow)
+        _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(c.num_instances * 1.25) + 1024)
+        last_counts[dev] = c
+        out.append((int(c.num_rendered), v["out_color"], v["radii"], v["geom"], v["binning"], v["img"]))
+    return out
+
+
+def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None, outs=None, stats=None, accumulates=None):
+    """`rasterize_gaussians_backward` for K views in ONE launch chain (fr_backward_batch): `views` is a list of its
+    positional argument tuples (background ... debug); `wants` / `outs` / `stats` / `accumulates`: per-view lists of the
+    corresponding keyword arguments.  Returns the list of gradient tuples."""
+    K = len(views)
+    if not 1 <= K <= _lib.FR_MAX_BATCH:
+        raise RuntimeError(f"rasterize_gaussians_backward_batch: 1 .. {_lib.FR_MAX_BATCH} views")
+    slots = list(range(K)) if slots is None else [int(x) for x in slots]
+    wants, outs, stats, accumulates = (x or [None] * K for x in (wants, outs, stats, accumulates))
+    L = _lib.lib()
+    st = []
+    dev = None
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    for k, a in enumerate(views):
+        (background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+         tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug) = a
+        d = _dev_index(means3D)
+        dev = d if dev is None else dev
+        P = means3D.size(0)
+        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        opts = dict(device=means3D.device, dtype=torch.float32)
+        shapes = dict(dL_dmeans2D=(P, 3), dL_dcolors=(P, NUM_CHANNELS), dL_dopacity=(P, 1), dL_dmeans3D=(P, 3),
+                      dL_dcov3D=(P, 6), dL_dsh=(P, M, 3), dL_dscales=(P, 3), dL_drotations=(P, 4))
+        acc = tuple(accumulates[k] or ())
+        out_k = outs[k] or {}
+        for n in acc:
+            if out_k.get(n) is None:
+                raise RuntimeError(f"rasterize_gaussians_backward_batch: cannot accumulate into {n}: no buffer was given for it")
+        acc_flags = sum(1 << (_lib.FR_FLAG_ACCUMULATE_SHIFT + names.index(n)) for n in acc)
+        g = {n: (torch.empty(sh_, **opts) if (wants[k] is None or n in wants[k]) else None) for n, sh_ in shapes.items()}
+        for n, buf in out_k.items():
+            if buf is not None:
+                assert buf.shape == shapes[n] and buf.is_contiguous() and buf.dtype == torch.float32, n
+                g[n] = buf.view(buf.shape)
+        background, means3D = _f32c(background), _f32c(means3D)
+        colors, scales, rotations, cov3D_precomp, sh = (_f32c(t) for t in (colors, scales, rotations, cov3D_precomp, sh))
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
+        dL_dout_color = _f32c(dL_dout_color)
+        radii = radii.contiguous()
+        aux = _aux(grad_accum=stats[k][0], denom=stats[k][1]) if stats[k] is not None else None
+        v = dict(g=g, keep=(background, means3D, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos,
+                            dL_dout_color, radii, geomBuffer, binningBuffer, imageBuffer),
+                 prm=_params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, raw, aux, acc_flags),
+                 inp=_inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos),
+                 grads=_lib.fr_grads(*[_ptr(g[n]) for n in names]),
+                 radii=radii, geom=geomBuffer, img=imageBuffer, binning=binningBuffer, dpix=dL_dout_color)
+        st.append(v)
+    handles = (C.c_void_p * K)(*[_lib.handle(dev, sl) for sl in slots])
+    prm_p = (C.POINTER(_lib.fr_params) * K)(*[C.pointer(v["prm"]) for v in st])
+    inp_p = (C.POINTER(_lib.fr_inputs) * K)(*[C.pointer(v["inp"]) for v in st])
+    grd_p = (C.POINTER(_lib.fr_grads) * K)(*[C.pointer(v["grads"]) for v in st])
+    arr = lambda key: (C.c_void_p * K)(*[v[key].data_ptr() for v in st])  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = L.fr_backward_batch(K, handles, prm_p, inp_p, arr("radii"), arr("geom"), arr("img"), arr("binning"), arr("dpix"),
+                                 grd_p, torch.cuda.current_stream(dev).cuda_stream)
+    _check(rc, "fr_backward_batch")
+    return [tuple(v["g"].values()) for v in st]
+
+
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """`_RasterizeGaussians` for K views rendered together.  Tensor arguments: per view (means3D, means2D, sh,
+    colors_precomp, opacities, scales, rotations, cov3Ds_precomp); outputs: per view (color, radii)."""
+
+    @staticmethod
+    def forward(ctx, settings, raw_activations, slots, *tensors):
+        K = len(settings)
+        assert len(tensors) == 8 * K
+        ctx.raw, ctx.K, ctx.settings, ctx.slots = bool(raw_activations), K, settings, slots
+        ctx.set_materialize_grads(False)
+        views, viss = [], []
+        for k, rs in enumerate(settings):
+            means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = tensors[8 * k:8 * k + 8]
+            views.append((rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                          rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                          rs.sh_degree, rs.campos, rs.prefiltered, rs.debug))
+            viss.append(torch.empty((means3D.shape[0],), dtype=torch.bool, device=means3D.device))
+        res = rasterize_gaussians_batch(views, slots=slots, raw=ctx.raw, visibles=viss)
+        ctx.stats, ctx.num_rendered, ctx.grad_slots, ctx.grad_owners = [], [], [], []
+        saved, outs = [], []
+        for k in range(K):
+            means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = tensors[8 * k:8 * k + 8]
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = res[k]
+            radii._fr_visible = viss[k]
+            ctx.stats.append(getattr(means2D, "_fr_densification_stats", None))
+            ctx.num_rendered.append(num_rendered)
+            slots_k = {"dL_dmeans3D": GradOut.of(means3D), "dL_dsh": GradOut.of(sh) if sh.numel() else None}
+            owners = {"dL_dmeans3D": means3D, "dL_dsh": sh}
+            if ctx.raw:
+                slots_k.update(dL_dopacity=GradOut.of(opacities), dL_dscales=GradOut.of(scales), dL_drotations=GradOut.of(rotations))
+                owners.update(dL_dopacity=opacities, dL_dscales=scales, dL_drotations=rotations)
+            ctx.grad_slots.append(slots_k)
+            ctx.grad_owners.append({n: t for n, t in owners.items() if slots_k.get(n) is not None and t.is_leaf})
+            saved += [colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer]
+            outs += [color, radii]
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(*outs[1::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        K = ctx.K
+        none = (None, None, None) + (None,) * (8 * K)
+        grad_colors = grad_outs[0::2]
+        if all(g is None for g in grad_colors):
+            return none
+        views, wants, outs, accs = [], [], [], []
+        for k, rs in enumerate(ctx.settings):
+            colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+                ctx.saved_tensors[10 * k:10 * k + 10]
+            g = grad_colors[k]
+            if g is None:   # (a view nobody differentiated: its frame still runs with a zero image gradient)
+                g = torch.zeros((NUM_CHANNELS, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+            views.append((rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                          rs.projmatrix, rs.tanfovx, rs.tanfovy, g, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered[k],
+                          binningBuffer, imgBuffer, rs.debug))
+            want = {"dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"}
+            if colors_precomp.numel():
+                want.add("dL_dcolors")
+            if cov3Ds_precomp.numel():
+                want.add("dL_dcov3D")
+            if sh.numel():
+                want.add("dL_dsh")
+            claims = {n: slot.claim(ctx.grad_owners[k].get(n)) for n, slot in ctx.grad_slots[k].items() if slot is not None}
+            # (in-kernel accumulation across the views of ONE batch would race: a later view of the same parameters gets a
+            # fresh tensor, which autograd adds)
+            wants.append(want)
+            outs.append({n: c[0] for n, c in claims.items() if not c[1]})
+            accs.append(())
+        res = rasterize_gaussians_backward_batch(views, slots=ctx.slots, raw=ctx.raw, wants=wants, outs=outs, stats=ctx.stats,
+                                                 accumulates=accs)
+        flat = [None, None, None]
+        for k in range(K):
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+             grad_rotations) = res[k]
+            flat += [grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                     grad_cov3Ds_precomp]
+        return tuple(flat)
+
+
+def rasterize_views_autograd(settings, per_view_tensors, raw_activations=False, slots=None):
+    """K views through one launch chain, differentiable: `settings` a list of GaussianRasterizationSettings,
+    `per_view_tensors` a list of (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp) with
+    empty tensors for what a view does not use.  Returns [(color, radii), ...]."""
+    K = len(settings)
+    flat = [t for v in per_view_tensors for t in v]
+    out = _RasterizeGaussiansBatch.apply(list(settings), bool(raw_activations), list(range(K)) if slots is None else list(slots), *flat)
+    return [(out[2 * k], out[2 * k + 1]) for k in range(K)]
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """`_C.mark_visible` (rasterize_points.cu:198-217)."""
     dev = _dev_index(means3D)

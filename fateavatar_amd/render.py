@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views_autograd
 
 
 _zero_cache = {}
@@ -87,3 +87,50 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, o
     visible = getattr(radii, "_fr_visible", None)  # written by the preprocess kernel (same values as radii > 0)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
             "visibility_filter": visible if visible is not None else radii > 0, "radii": radii}
+
+
+def render_batch(viewpoint_cameras, pcs, bg_colors, scaling_modifier=1.0, slots=None):
+    """`render()` for K views IN ONE LAUNCH CHAIN (include/fr_rasterizer.h: fr_forward_batch / fr_backward_batch): the
+    reference renders the frames of a batch one after the other (model/fateavatar.py:251-276), and one frame's kernels
+    leave most of an MI355X idle; here every kernel of the frame is launched once for all K views, with no stream or
+    hardware-queue arrangement on the caller's side.  `pcs` / `bg_colors`: one per view, or a single holder / tensor
+    for all of them (shared Gaussians: autograd then sums the views' gradients).  Returns the list of render() dicts."""
+    import torch as _torch
+    K = len(viewpoint_cameras)
+    if not isinstance(pcs, (list, tuple)):
+        pcs = [pcs] * K
+    if isinstance(bg_colors, _torch.Tensor):
+        bg_colors = [bg_colors] * K
+    settings, tensors, points = [], [], []
+    fused = bool(getattr(pcs[0], "fused_activations", False))
+    empty = _torch.Tensor([])
+    for cam, pc, bg in zip(viewpoint_cameras, pcs, bg_colors):
+        if bool(getattr(pc, "fused_activations", False)) != fused:
+            raise RuntimeError("render_batch: the views' holders must agree on fused_activations")
+        means3D = pc.get_xyz
+        sp = _zero_points(means3D)
+        stats = getattr(pc, "fused_densification_stats", None)
+        if stats is not None:
+            sp._fr_densification_stats = stats
+        try:
+            sp.retain_grad()
+        except Exception:
+            pass
+        settings.append(GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=pc.max_sh_degree, campos=cam.camera_center, prefiltered=False,
+            debug=False))
+        if fused:
+            opacity, scales, rotations = pc._opacity, pc._scaling, pc._rotation
+        else:
+            opacity, scales, rotations = pc.get_opacity, pc.get_scaling, pc.get_rotation
+        tensors.append((means3D, sp, pc.get_features, empty, opacity, scales, rotations, empty))
+        points.append(sp)
+    res = rasterize_views_autograd(settings, tensors, raw_activations=fused, slots=slots)
+    out = []
+    for (image, radii), sp in zip(res, points):
+        visible = getattr(radii, "_fr_visible", None)
+        out.append({"render": image, "viewspace_points": sp,
+                    "visibility_filter": visible if visible is not None else radii > 0, "radii": radii})
+    return out

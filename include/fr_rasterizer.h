@@ -192,6 +192,24 @@ int fr_backward(fr_handle* h, const fr_params* prm, const fr_inputs* in, const i
                 const void* image, const void* binning, const float* dL_dpix, const fr_grads* grads,
                 void* hip_stream);
 
+/* ---- several views through ONE launch chain (SURVEY.md §8e / reference model/fateavatar.py:251-276: the frames of a
+ * batch are rendered one after the other with shared Gaussians; one frame's kernels leave most of an MI355X idle).
+ * fr_forward_batch / fr_backward_batch do exactly what n_views calls of fr_forward / fr_backward would — every view has
+ * its own handle, parameter block, inputs (which may or may not share pointers), outputs and scratch buffers, and the
+ * results are the same bit for bit (the forward) resp. to atomic-summation order (the backward) — but every kernel of
+ * the frame is launched once with a (grid, n_views) grid, so that the views fill the chip together without any stream
+ * or hardware-queue arrangement on the caller's side.  1 <= n_views <= FR_MAX_BATCH; batched views need P > 0, distinct
+ * handles and the default forward path (FR_BLEND_FWD unset).  `counts` (may be NULL): n_views entries.  Returns
+ * FR_ERR_BINNING_CAPACITY if ANY view overflowed its binning capacity (counts[k].overflow says which). */
+#define FR_MAX_BATCH 4
+int fr_forward_batch(int32_t n_views, fr_handle* const* handles, const fr_params* const* prm, const fr_inputs* const* in,
+                     float* const* out_color, int32_t* const* radii, void* const* geometry, void* const* image,
+                     void* const* binning, const uint64_t* binning_capacity, fr_counts* counts, void* hip_stream);
+int fr_backward_batch(int32_t n_views, fr_handle* const* handles, const fr_params* const* prm, const fr_inputs* const* in,
+                      const int32_t* const* radii, void* const* geometry, const void* const* image,
+                      const void* const* binning, const float* const* dL_dpix, const fr_grads* const* grads,
+                      void* hip_stream);
+
 /* ---- fused Adam over a flat parameter buffer (replaces torch.optim.Adam.step() over the
  * Gaussian parameter groups of train/optim.py:11-37: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
  * The buffer is cut into up to FR_ADAM_MAX_SEGMENTS consecutive segments, each with its own learning rate (the

@@ -1121,3 +1121,73 @@ def test_backward_accumulates_into_the_arrays_it_is_told_to(gpu_device):
                 assert float(got[k][culled].abs().max()) == 0.0, (added, k)
     with pytest.raises(RuntimeError):
         R.rasterize_gaussians_backward(*args, _accumulate=("dL_dsh",))
+
+
+def test_render_batch_equals_separate_renders(gpu_device):
+    """fr_forward_batch / fr_backward_batch (render_batch): K views through ONE launch chain must give what K separate
+    render() calls give — images, radii and visibility bit for bit, gradients to atomic-summation order — also when the
+    views differ in resolution and Gaussian count (a batched launch's grid is the largest view's), and with ONE holder
+    shared by all views (autograd sums the views' gradients)."""
+    import torch
+    from fateavatar_amd import rasterizer
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render, render_batch
+    specs = [dict(P=20000, res=256, view=0), dict(P=20000, res=256, view=1), dict(P=12000, res=192, view=2)]
+    sc = [scenes.head_scene(P=d["P"], res=d["res"], sh_degree=2, seed=0, view=d["view"], n_views=3, opacity=0.5) for d in specs]
+    cams = [TorchCamera(s.camera, gpu_device) for s in sc]
+    bgs = [torch.from_numpy(s.bg).to(gpu_device) for s in sc]
+    gs = [torch.rand(3, d["res"], d["res"], device=gpu_device, generator=None) / (3 * d["res"] ** 2) for d in specs]
+
+    def holders(fused):
+        return [FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 2, gpu_device, fused_activations=fused) for s in sc]
+
+    for fused in (True, False):
+        a, b = holders(fused), holders(fused)
+        outs_a = []
+        for k in range(3):
+            with rasterizer.handle_slot(k):
+                a[k].begin_step()
+                o = render(cams[k], a[k], bgs[k])
+                torch.autograd.backward(o["render"], grad_tensors=gs[k])
+                outs_a.append(o)
+        for pc in b:
+            pc.begin_step()
+        outs_b = render_batch(cams, b, bgs)
+        torch.autograd.backward([o["render"] for o in outs_b], grad_tensors=gs)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(outs_a[k]["render"], outs_b[k]["render"]), (fused, k)
+            assert torch.equal(outs_a[k]["radii"], outs_b[k]["radii"]) and torch.equal(outs_a[k]["visibility_filter"], outs_b[k]["visibility_filter"])
+            ga, gb = a[k].collect_grads().cpu().numpy(), b[k].collect_grads().cpu().numpy()
+            assert util.rel_l2(gb, ga) < 1e-5, (fused, k, util.rel_l2(gb, ga))
+            va, vb = outs_a[k]["viewspace_points"].grad.cpu().numpy(), outs_b[k]["viewspace_points"].grad.cpu().numpy()
+            assert util.rel_l2(vb, va) < 1e-5 and float(abs(va).max()) > 0
+    # ---- one holder for all views (same Gaussians, two cameras): the views' gradients add up
+    s0 = sc[0]
+    pc1 = FlatGaussians(s0.means3D, s0.shs, s0.opacities, s0.scales, s0.rotations, 2, gpu_device, fused_activations=True)
+    pc2 = FlatGaussians(s0.means3D, s0.shs, s0.opacities, s0.scales, s0.rotations, 2, gpu_device, fused_activations=True)
+    pc1.begin_step()
+    loss = 0
+    for k in range(2):
+        with rasterizer.handle_slot(k):
+            loss = loss + (render(cams[k], pc1, bgs[k])["render"] * gs[k]).sum()
+    loss.backward()
+    pc2.begin_step()
+    o2 = render_batch(cams[:2], pc2, bgs[0])
+    sum((o["render"] * g).sum() for o, g in zip(o2, gs)).backward()
+    torch.cuda.synchronize()
+    g1, g2 = pc1.collect_grads().cpu().numpy(), pc2.collect_grads().cpu().numpy()
+    assert util.rel_l2(g2, g1) < 1e-5 and float(abs(g1).max()) > 0
+
+
+def test_batch_refuses_shared_handles_and_too_many_views(gpu_device):
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render_batch
+    s = scenes.head_scene(P=2000, res=64, sh_degree=0, seed=0)
+    pc = FlatGaussians(s.means3D, s.shs, s.opacities, s.scales, s.rotations, 0, gpu_device, fused_activations=True)
+    cam, bg = TorchCamera(s.camera, gpu_device), torch.from_numpy(s.bg).to(gpu_device)
+    with pytest.raises(RuntimeError, match="handle slot each"):
+        render_batch([cam, cam], pc, bg, slots=[1, 1])
+    with pytest.raises(RuntimeError, match="1 .. 4 views"):
+        render_batch([cam] * 5, pc, bg)
