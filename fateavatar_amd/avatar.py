@@ -157,6 +157,8 @@ class AvatarStep(TrainStep):
         self.pc, self.bg = pc, bg
         self.dev = pc.flat.device
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.exchange = torch.distributed.is_initialized() and (self.world > 1 or dp.group_of_one())
+        self.exchange_in_graph = self.exchange and torch.distributed.get_backend() == "nccl"   # (see TrainStep)
         self.lr = dict(FATE_LRS, **(lrs or {}))
         self.faces = faces.to(self.dev, torch.int32).contiguous()
         self.shell_len, self.resize_scale = float(shell_len), bool(resize_scale)
@@ -448,7 +450,7 @@ class AvatarBatchStep(AvatarStep):
         for L in self.lanes:
             main.wait_event(L.done)
         grads = [L.pc.flat_grad for L in self.lanes]
-        if self.world > 1:                         # sum of the local lanes, then the sum over the ranks; Adam scales
+        if self.exchange:                          # sum of the local lanes, then the sum over the ranks; Adam scales
             for g in grads[1:]:
                 grads[0].add_(g)
             dp.allreduce_sum_(grads[0])

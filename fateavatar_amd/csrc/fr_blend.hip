@@ -220,53 +220,20 @@ __device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, fl
     return make_uint2(m[0], m[1]);
 }
 
-__device__ __forceinline__ void write_record(float4* recs, uint32_t pos, uint32_t id, const GeomView& g, float tile_x0,
-                                             float tile_y0)
-{
-    (void)tile_x0, (void)tile_y0;
-    const float4* t = g.rec_tmpl + (size_t)id * kRecQuads;   // (k_preprocess_fwd built the record: one 48-byte gather)
-    const float4 q0 = t[0], q1 = t[1], q2 = t[2];
-    float4* r = recs + (size_t)pos * kRecQuads;
-    r[0] = q0, r[1] = q1, r[2] = q2;   // (q2.zw: the footprint mask while a unit is staged in LDS)
-}
-
-// Gather and write the records of K sorted keys per lane (slot r of lane l is list position base + r*64 + l).  The
-// gathers of four slots are issued together and unconditionally (an out-of-range slot reads Gaussian 0 and is not
-// written): one memory round trip per four slots instead of one per slot.
+// The sort's output: the Gaussian id of every sorted key (slot r of lane l is list position base + r*64 + l); the blend
+// kernels gather the records themselves (RecSrc).
 template <int K>
-__device__ __forceinline__ void write_records(float4* recs, uint32_t start, uint32_t n, uint32_t base, const u64 (&v)[K],
-                                              int lane, const GeomView& g, float tile_x0, float tile_y0)
+__device__ __forceinline__ void write_ids(uint32_t* ids, uint32_t start, uint32_t n, uint32_t base, const u64 (&v)[K], int lane)
 {
-    constexpr int B = K < 4 ? K : 4;
-    (void)tile_x0, (void)tile_y0;
 #pragma unroll
-    for (int r0 = 0; r0 < K; r0 += B) {
-        float4 q0[B], q1[B], q2[B];
-#pragma unroll
-        for (int u = 0; u < B; u++) {
-            const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
-            const uint32_t id = i < n ? (uint32_t)v[r0 + u] : 0u;
-            // (component-wise on purpose: as plain 16-byte copies the compiler turns load + store into a 48-byte memcpy
-            // through a stack slot — 208 bytes of scratch per lane and a sort kernel 15 us slower)
-            const float* __restrict__ t = reinterpret_cast<const float*>(g.rec_tmpl + (size_t)id * kRecQuads);
-            q0[u] = make_float4(t[0], t[1], t[2], t[3]);
-            q1[u] = make_float4(t[4], t[5], t[6], t[7]);
-            q2[u] = make_float4(t[8], t[9], 0.f, 0.f);   // (.zw of a record in memory are unused; the template's .z is the depth)
-        }
-#pragma unroll
-        for (int u = 0; u < B; u++) {
-            const uint32_t i = base + (uint32_t)((r0 + u) * 64 + lane);
-            if (i < n) {
-                float4* r = recs + (size_t)(start + i) * kRecQuads;
-                r[0] = q0[u], r[1] = q1[u], r[2] = q2[u];
-            }
-        }
+    for (int r = 0; r < K; r++) {
+        const uint32_t i = base + (uint32_t)(r * 64 + lane);
+        if (i < n) ids[start + i] = (uint32_t)v[r];
     }
 }
 
 template <int K>
-__device__ __forceinline__ void sort_tile_regs(const KeySrc& keys, float4* recs, uint32_t start, uint32_t n, int lane,
-                                               const GeomView& g, float tile_x0, float tile_y0)
+__device__ __forceinline__ void sort_tile_regs(const KeySrc& keys, uint32_t* ids, uint32_t start, uint32_t n, int lane)
 {
     u64 v[K];
 #pragma unroll
@@ -275,7 +242,7 @@ __device__ __forceinline__ void sort_tile_regs(const KeySrc& keys, float4* recs,
         v[r] = i < n ? keys.key(i) : ~0ull;
     }
     wave_sort<K>(v, lane);
-    write_records<K>(recs, start, n, 0u, v, lane, g, tile_x0, tile_y0);
+    write_ids<K>(ids, start, n, 0u, v, lane);
 }
 
 // Four waves sort up to 4 * 64 * K keys together (K = 4: 1024, K = 16: 4096): each wave sorts its 64*K keys in
@@ -303,8 +270,7 @@ __device__ __forceinline__ void cross_wave_stage(u64 (&v)[K], SortXchg& sx, int 
 }
 
 template <int K>
-__device__ void sort_tile_group(const KeySrc& keys, float4* recs, uint32_t start, uint32_t n, int wave, int lane,
-                                const GeomView& g, SortXchg& sx, float tile_x0, float tile_y0)
+__device__ void sort_tile_group(const KeySrc& keys, uint32_t* ids, uint32_t start, uint32_t n, int wave, int lane, SortXchg& sx)
 {
     constexpr int KW = 64 * K;  // keys per wave
     u64 v[K];
@@ -323,7 +289,7 @@ __device__ void sort_tile_group(const KeySrc& keys, float4* recs, uint32_t start
     cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
     reg_cleaners_from<K, K / 2>(v);
     lane_cleaners_from_32<K>(v, lane);
-    write_records<K>(recs, start, n, (uint32_t)(wave * KW), v, lane, g, tile_x0, tile_y0);
+    write_ids<K>(ids, start, n, (uint32_t)(wave * KW), v, lane);
 }
 
 #undef SortXchg
@@ -331,8 +297,7 @@ __device__ void sort_tile_group(const KeySrc& keys, float4* recs, uint32_t start
 // in global memory by one 256-thread workgroup (virtual +inf padding: a compare-exchange whose
 // upper index is >= n is a no-op in the flip formulation).  Agent-scope accesses keep the data
 // out of the per-CU L1 so that waves of the workgroup see each other's stores.
-__device__ void sort_tile_global(const KeySrc& src, u64* keys, float4* recs, uint32_t start, uint32_t n, const GeomView& g,
-                                 float tile_x0, float tile_y0)
+__device__ void sort_tile_global(const KeySrc& src, u64* keys, uint32_t* ids, uint32_t start, uint32_t n)
 {
     u64* seg = keys + start;   // contiguous scratch segment of the tile inside the binning buffer
     uint32_t N = 1;
@@ -360,7 +325,7 @@ __device__ void sort_tile_global(const KeySrc& src, u64* keys, float4* recs, uin
     }
     for (uint32_t i = tid; i < n; i += nt) {
         const u64 kv = __hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        write_record(recs, start + i, (uint32_t)kv, g, tile_x0, tile_y0);
+        ids[start + i] = (uint32_t)kv;
     }
 }
 
@@ -382,8 +347,7 @@ struct SortArgs {
     ImageView v;
     uint32_t T, Q;
     u64* keys;
-    float4* recs;
-    GeomView g;
+    uint32_t* ids;
     uint4* unit_tile;
     uint32_t unit_cap;
     float* unit_tseg;
@@ -400,8 +364,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
     const ImageView v = a.v;
     const uint32_t T = a.T, Q = a.Q, unit_cap = a.unit_cap;
     u64* keys = a.keys;
-    float4* recs = a.recs;
-    const GeomView g = a.g;
+    uint32_t* ids = a.ids;
     uint4* unit_tile = a.unit_tile;
     float* unit_tseg = a.unit_tseg;
     const int take_long_lists = a.take_long_lists, W = a.W, H = a.H;
@@ -432,8 +395,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
         const uint32_t nm = v.counts->medium_tiles;
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group<4>(key_src(v, tile), recs, v.tile_offset[tile], v.tile_total[tile], wave, lane, g, sx,
-                               (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+            sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], v.tile_total[tile], wave, lane, sx);
         }
         // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
         // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
@@ -442,8 +404,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
             const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
             for (uint32_t item = blockIdx.x; item < nb + nl; item += kMediumSorters) {
                 const uint32_t tile = item < nb ? v.big_list[item] : v.large_list[item - nb];
-                sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_total[tile], g,
-                                 (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+                sort_tile_global(key_src(v, tile), keys, ids, v.tile_offset[tile], v.tile_total[tile]);
             }
         }
         return;
@@ -479,11 +440,10 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
                 }
             }
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
-                const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
                 const KeySrc ks = key_src(v, tile);
-                if (n <= 64) sort_tile_regs<1>(ks, recs, start, n, lane, g, tx0, ty0);
-                else if (n <= 128) sort_tile_regs<2>(ks, recs, start, n, lane, g, tx0, ty0);
-                else sort_tile_regs<4>(ks, recs, start, n, lane, g, tx0, ty0);
+                if (n <= 64) sort_tile_regs<1>(ks, ids, start, n, lane);
+                else if (n <= 128) sort_tile_regs<2>(ks, ids, start, n, lane);
+                else sort_tile_regs<4>(ks, ids, start, n, lane);
             }
         }
     }
@@ -500,16 +460,14 @@ constexpr uint32_t kBigSorters = 512;
 struct BigSortArgs {
     ImageView v;
     u64* keys;
-    float4* recs;
-    GeomView g;
+    uint32_t* ids;
 };
 
 __device__ __forceinline__ void tile_sort_big_body(const BigSortArgs& a)
 {
     const ImageView v = a.v;
     u64* keys = a.keys;
-    float4* recs = a.recs;
-    const GeomView g = a.g;
+    uint32_t* ids = a.ids;
     __shared__ SortXchgT<16> sx;
     SortXchgT<8>& sx8 = *reinterpret_cast<SortXchgT<8>*>(&sx);   // (lists up to 2048: half the network)
     if (frame_overflow(v.counts, v.bucket_cap)) return;
@@ -519,14 +477,12 @@ __device__ __forceinline__ void tile_sort_big_body(const BigSortArgs& a)
     for (uint32_t item = blockIdx.x; item < nb; item += kBigSorters) {
         const uint32_t tile = v.big_list[item];
         const uint32_t n = v.tile_total[tile];
-        const float tx0 = (float)((tile % (uint32_t)v.tiles_x) * kTile), ty0 = (float)((tile / (uint32_t)v.tiles_x) * kTile);
-        if (n <= 2048u) sort_tile_group<8>(key_src(v, tile), recs, v.tile_offset[tile], n, wave, lane, g, sx8, tx0, ty0);
-        else sort_tile_group<16>(key_src(v, tile), recs, v.tile_offset[tile], n, wave, lane, g, sx, tx0, ty0);
+        if (n <= 2048u) sort_tile_group<8>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx8);
+        else sort_tile_group<16>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
     }
     for (uint32_t item = blockIdx.x; item < nl; item += kBigSorters) {
         const uint32_t tile = v.large_list[item];
-        sort_tile_global(key_src(v, tile), keys, recs, v.tile_offset[tile], v.tile_total[tile], g,
-                         (float)((tile % (uint32_t)v.tiles_x) * kTile), (float)((tile / (uint32_t)v.tiles_x) * kTile));
+        sort_tile_global(key_src(v, tile), keys, ids, v.tile_offset[tile], v.tile_total[tile]);
     }
 }
 
@@ -556,13 +512,14 @@ struct RecRegs {
     float4 q0, q1, q2;
 };
 
-__device__ __forceinline__ RecRegs fetch_record(const float4* __restrict__ src, uint32_t i, uint32_t n)
+__device__ __forceinline__ RecRegs fetch_record(const RecSrc& rs, size_t start, uint32_t i, uint32_t n)
 {
     RecRegs r;
     if (i < n) {
-        r.q0 = src[(size_t)i * kRecQuads + 0];
-        r.q1 = src[(size_t)i * kRecQuads + 1];
-        r.q2 = src[(size_t)i * kRecQuads + 2];
+        const float4* __restrict__ src = rs.at(start + i);
+        r.q0 = src[0];
+        r.q1 = src[1];
+        r.q2 = src[2];
     } else {  // padding: opacity 0 -> alpha 0 -> never blended
         r.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
         r.q1 = r.q0;
@@ -1098,35 +1055,35 @@ __device__ __forceinline__ void pair_alpha_from_memory(const float4* __restrict_
 }
 
 // per-pixel product of (1 - alpha) over unit p's blendable records: what unit p publishes
-__device__ float unit_product_from_memory(const uint4* __restrict__ unit_tile, const float4* __restrict__ recs, uint32_t p, float fx,
+__device__ float unit_product_from_memory(const uint4* __restrict__ unit_tile, const RecSrc& recs, uint32_t p, float fx,
                                           float fy, bool inside)
 {
     const uint4 d = unit_tile[p];
     const uint32_t base = d.y * kUnit, m = min((uint32_t)kUnit, d.w - base);
-    const float4* r = recs + (size_t)(d.z + base) * kRecQuads;
+    const size_t r0 = (size_t)d.z + base;
     float t = 1.0f;
     for (uint32_t j = 0; j < m; j++) {
         float alpha, c0, c1, c2;
         bool ok;
-        pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+        pair_alpha_from_memory(recs.at(r0 + j), fx, fy, inside, alpha, ok, c0, c1, c2);
         t = ok ? t * (1.f - alpha) : t;
     }
     return fmaxf(t, 1e-30f);
 }
 
 // unit q's final row given the transmittance entering it
-__device__ UnitRow unit_row_from_memory(const uint4* __restrict__ unit_tile, const float4* __restrict__ recs, uint32_t q, float Tin,
+__device__ UnitRow unit_row_from_memory(const uint4* __restrict__ unit_tile, const RecSrc& recs, uint32_t q, float Tin,
                                         float fx, float fy, bool inside)
 {
     const uint4 d = unit_tile[q];
     const uint32_t base = d.y * kUnit, m = min((uint32_t)kUnit, d.w - base);
-    const float4* r = recs + (size_t)(d.z + base) * kRecQuads;
+    const size_t r0 = (size_t)d.z + base;
     float t = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f;
     uint32_t last = 0u;
     for (uint32_t j = 0; j < m; j++) {   // the local blend (walk_unit_fwd<false> from T = 1)
         float alpha, c0, c1, c2;
         bool ok;
-        pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+        pair_alpha_from_memory(recs.at(r0 + j), fx, fy, inside, alpha, ok, c0, c1, c2);
         const float w = ok ? alpha * t : 0.f;
         cr += c0 * w, cg += c1 * w, cb += c2 * w;
         t = ok ? t * (1.f - alpha) : t;
@@ -1145,7 +1102,7 @@ __device__ UnitRow unit_row_from_memory(const uint4* __restrict__ unit_tile, con
         for (uint32_t j = 0; j < m; j++) {
             float alpha, c0, c1, c2;
             bool ok;
-            pair_alpha_from_memory(r + j * kRecQuads, fx, fy, inside, alpha, ok, c0, c1, c2);
+            pair_alpha_from_memory(recs.at(r0 + j), fx, fy, inside, alpha, ok, c0, c1, c2);
             bool c = ok && crosses;
             const float test_T = T * (1.f - alpha);
             const bool fin = c && !term && (test_T < 0.0001f);
@@ -1163,7 +1120,7 @@ __device__ UnitRow unit_row_from_memory(const uint4* __restrict__ unit_tile, con
 }
 
 // the product unit p published — or, if it has not appeared after `spins` polls, computed here
-__device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __restrict__ unit_tile, const float4* __restrict__ recs,
+__device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __restrict__ unit_tile, const RecSrc& recs,
                                                uint32_t p, float first, uint32_t spins, int lane, float fx, float fy, bool inside)
 {
     float v = first;
@@ -1179,7 +1136,7 @@ __device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __res
 struct ChainArgs {
     DeviceCounts* counts;
     const uint4* unit_tile;
-    const float4* recs;
+    RecSrc recs;
     uint2* masks;
     int W, H, tiles_x;
     float* g_tseg;
@@ -1198,7 +1155,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
 {
     DeviceCounts* __restrict__ counts = a.counts;
     const uint4* __restrict__ unit_tile = a.unit_tile;
-    const float4* __restrict__ recs = a.recs;
+    const RecSrc recs = a.recs;
     uint2* __restrict__ masks = a.masks;
     const int W = a.W, H = a.H, tiles_x = a.tiles_x, pair_hist = a.pair_hist;
     float* g_tseg = a.g_tseg;
@@ -1217,7 +1174,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     if (u >= counts->num_units) return;
     const TransposeConsts tc = transpose_consts(lane);
     const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
-    RecRegs rr = fetch_record(recs + (size_t)ui.start * kRecQuads, ui.base + (uint32_t)lane, ui.n);
+    RecRegs rr = fetch_record(recs, (size_t)ui.start, ui.base + (uint32_t)lane, ui.n);
     // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in `masks` for the backward
     uint2 fm = make_uint2(0u, 0u);
     if (ui.base + (uint32_t)lane < ui.n) {
@@ -1365,6 +1322,7 @@ extern "C" int fr_debug_read_bwd_trace(void* dst, size_t bytes)
 struct BlendBwdArgs {
     const DeviceCounts* counts;
     ImageView v;
+    const float4* rec_tmpl;   // GeomView::rec_tmpl: the records are gathered through the sorted ids
     void* binning;
     int W, H;
     const float* bg;
@@ -1423,7 +1381,8 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         const bool inside = px < W && py < H;
         const size_t pix = inside ? (size_t)py * W + px : 0;
         const uint32_t ridx = min(base + (uint32_t)lane, n - 1u);
-        const float4* rsrc = b.recs + ((size_t)start + ridx) * kRecQuads;
+        const RecSrc recsrc = {b.ids, a.rec_tmpl};
+        const float4* rsrc = recsrc.at((size_t)start + ridx);
         const uint32_t last_raw = v.n_contrib[pix];
         const float4 rq0 = rsrc[0], rq1 = rsrc[1];
         const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
@@ -1682,15 +1641,16 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         unit_wgs = max(unit_wgs, (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG));
         gather_blocks = max(gather_blocks, (T + kWavesPerWG - 1) / kWavesPerWG);
         SortArgs& a = sa[k];
-        a.v = v, a.T = T, a.Q = small_blocks, a.keys = (u64*)b.keys, a.recs = b.recs, a.g = f[k].g, a.unit_tile = b.unit_tile;
+        a.v = v, a.T = T, a.Q = small_blocks, a.keys = (u64*)b.keys, a.ids = b.ids, a.unit_tile = b.unit_tile;
         a.unit_cap = (uint32_t)b.unit_cap, a.unit_tseg = b.unit_tseg, a.take_long_lists = launch_big ? 0 : 1;
         a.host_counts = h->host_counts_dev;
         a.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
         a.empty_color = h->gather_in_chain ? f[k].out_color : nullptr;
         a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H;
-        ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].recs = b.recs, ba[k].g = f[k].g;
+        ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].ids = b.ids;
         ChainArgs& c = ca[k];
-        c.counts = v.counts, c.unit_tile = b.unit_tile, c.recs = (const float4*)b.recs, c.masks = b.masks;
+        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks;
+        c.recs = RecSrc{b.ids, f[k].g.rec_tmpl};
         c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
         c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;
         c.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
@@ -1735,6 +1695,7 @@ int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, c
     BlendBwdArgs a[kMaxBatch];
     for (int k = 0; k < n; k++) {
         a[k].counts = v[k].counts, a[k].v = v[k], a[k].binning = const_cast<void*>(calls[k].binning);
+        a[k].rec_tmpl = g[k].rec_tmpl;
         a[k].W = calls[k].prm->W, a[k].H = calls[k].prm->H, a[k].bg = calls[k].in->background;
         a[k].dL_dpix = calls[k].dL_dpix, a[k].accum = g[k].accum, a[k].dense_pairs = calls[k].h->dense_pairs_bwd;
     }

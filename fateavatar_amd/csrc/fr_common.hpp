@@ -57,10 +57,10 @@ __host__ __device__ static inline T* carve(char*& p, size_t count)
 
 // Per-Gaussian state written by the forward preprocess and read by every later stage.
 struct GeomView {
-    float4* rec_tmpl;       // [P*3] the 48-byte splat RECORD of the blend kernels as k_tile_sort copies it into every
-                            // (tile, Gaussian) instance's slot: (x, y, a', b'), (c', opacity, r, g), (b, id, depth, 0) with
-                            // the pixel-space centre, the conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour
-                            // fed to the blend (SH result or colors_precomp) — ONE gather per instance, not three
+    float4* rec_tmpl;       // [P*3] the 48-byte splat RECORD the blend kernels gather for every (tile, Gaussian) instance:
+                            // (x, y, a', b'), (c', opacity, r, g), (b, id, depth, 0) with the pixel-space centre, the
+                            // conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour fed to the blend (SH result or
+                            // colors_precomp) — ONE 48-byte gather per instance, not three
     float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
     float* cov3D;           // [P*6]
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
@@ -179,7 +179,8 @@ struct BatchOf {
 struct BinningView {
     size_t cap, unit_cap;
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
-    float4* recs;         // [cap*3] 48-byte splat records per tile, in blend order (depth, then id)
+    uint32_t* ids;        // [cap]   the Gaussian id of every (tile, Gaussian) instance, per tile in blend order (depth, then
+                          //         id): the blend kernels gather the 48-byte record from GeomView::rec_tmpl through it
     uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_chained writes it, the backward reads it)
     uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile y << 16 | tile x, segment, list start, list length)
     uint32_t* unit_done;  // [unit_cap] k_unit_blend_chained: the unit's final contribution is in memory (zeroed by k_tile_sort)
@@ -196,9 +197,9 @@ struct BinningView {
         // (the descriptors come FIRST: their address does not depend on the capacity, so the blend backward, which
         // learns the capacity from the device counts, can request a unit's descriptor together with the counts)
         b.unit_tile = carve<uint4>(p, b.unit_cap);
-        b.recs = carve<float4>(p, cap * 3);
         b.keys = carve<uint64_t>(p, cap);
         b.masks = carve<uint2>(p, cap);
+        b.ids = carve<uint32_t>(p, cap);
         b.unit_done = carve<uint32_t>(p, b.unit_cap);
         b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
         b.unit_out = carve<float>(p, b.unit_cap * 5 * kUnit);
@@ -210,6 +211,16 @@ struct BinningView {
         BinningView b = make(nullptr, cap, T);
         return reinterpret_cast<size_t>(b.unit_state + b.unit_cap * kUnit) + 256;
     }
+};
+
+// Where the blend kernels read the record at position `pos` of the sorted lists: the Gaussian's template record
+// (GeomView::rec_tmpl, 4.8 MB at 100 k Gaussians: L2 / MALL resident), found through the sorted id.  (Round 2 had
+// k_tile_sort gather the template and write a 48-byte copy per instance: 3.4 us more in the sort, 1.5 us less in each
+// blend kernel, but 10 MB more written and read per frame — with frames in flight together the copies lost by 3-5 %.)
+struct RecSrc {
+    const uint32_t* ids;
+    const float4* tmpl;
+    __device__ __forceinline__ const float4* at(size_t pos) const { return tmpl + (size_t)ids[pos] * 3; }
 };
 
 enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };

@@ -41,6 +41,11 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
+def group_of_one() -> bool:
+    """True for the diagnostic one-rank process group (FR_DP_GROUP_OF_ONE=1): the N > 1 code paths on one GPU."""
+    return dist.is_initialized() and dist.get_world_size() == 1
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -106,8 +111,9 @@ def allreduce_mean_async(flat_grad: torch.Tensor) -> PendingReduce:
 
 
 def allreduce_sum_(stats: torch.Tensor) -> torch.Tensor:
-    """In-place sum of per-view statistics (densification accumulators) across ranks."""
-    if world_size() > 1:
+    """In-place sum of a buffer across ranks (flat gradients, densification accumulators).  On the one-rank diagnostic
+    group the collective is still issued: that is what the group is for."""
+    if world_size() > 1 or group_of_one():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     return stats
 

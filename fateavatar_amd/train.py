@@ -38,6 +38,11 @@ class TrainStep:
         self.pc, self.bg = pc, bg
         self.dev = pc.flat.device
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        # RCCL ("nccl") collectives can be captured into a HIP graph: the whole step — render, backward, all-reduce of
+        # the flat gradient buffer, Adam — is then ONE replay, with no host work between the backward and the update.
+        # (gloo cannot be captured: the CPU tests keep the eager exchange.)
+        self.exchange = torch.distributed.is_initialized() and (self.world > 1 or dp.group_of_one())
+        self.exchange_in_graph = self.exchange and torch.distributed.get_backend() == "nccl"
         lr = dict(DEFAULT_LRS, **(lrs or {}))
         P, M = pc.P, pc.M
         self.adam = FusedAdam(pc.flat, pc.flat_grad, [
@@ -72,10 +77,16 @@ class TrainStep:
         # AccumulateGrad nodes (and the stream they were created on) alive, which breaks a later stream capture
         self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
 
+    def _exchange_and_update(self):
+        dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
+        self.adam.step()
+
     def _body(self):
         self._forward_backward()
-        if self.world == 1:
+        if not self.exchange:
             self.adam.step()
+        elif self.exchange_in_graph:
+            self._exchange_and_update()
 
     def _capture(self):
         from . import rasterizer
@@ -111,9 +122,8 @@ class TrainStep:
         else:
             self._body()              # eager: first steps size the binning capacity (high-water mark)
             self._eager_steps += 1
-        if self.world > 1:
-            dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
-            self.adam.step()
+        if self.exchange and not self.exchange_in_graph:
+            self._exchange_and_update()
         return self.loss
 
     def _load_inputs(self, camera: TorchCamera, gt_image: torch.Tensor, extra=()) -> None:

@@ -260,6 +260,47 @@ def test_rccl_exchange_path_runs_on_this_gpu(gpu_device):
     assert "rccl-ok nccl" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_train_step_captures_the_rccl_exchange_in_its_graph(gpu_device):
+    """On the RCCL backend the optimisation step captures its gradient all-reduce and the Adam update into the step's HIP
+    graph (TrainStep.exchange_in_graph): one replay per step, no host work between the backward and the update.  A
+    one-rank "nccl" group on this GPU: the captured step must follow the eager one (its all-reduce is an identity, what is
+    checked is that capture, replay and ordering work on this stack), for the generic and the FateAvatar step."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', FR_DP_GROUP_OF_ONE='1')\n"
+        "from fateavatar_amd import dp, scenes\n"
+        "rank, world, local = dp.init_from_env()\n"
+        "assert dist.get_backend() == 'nccl' and world == 1\n"
+        "from fateavatar_amd.model import FlatGaussians, TorchCamera\n"
+        "from fateavatar_amd.render import render\n"
+        "from fateavatar_amd.train import TrainStep\n"
+        "dev = torch.device('cuda', 0)\n"
+        "t = scenes.head_scene(P=3000, res=96, sh_degree=1, seed=4, opacity=0.5)\n"
+        "cam = TorchCamera(t.camera, dev); bg = torch.from_numpy(t.bg).to(dev)\n"
+        "mk = lambda: FlatGaussians(t.means3D, t.shs * 0.5, t.opacities, t.scales, t.rotations, 1, dev, fused_activations=True)\n"
+        "with torch.no_grad():\n"
+        "    gt = render(cam, FlatGaussians(t.means3D, t.shs, t.opacities, t.scales, t.rotations, 1, dev, fused_activations=True), bg)['render'].clone()\n"
+        "res = {}\n"
+        "for use_graph in (False, True):\n"
+        "    ts = TrainStep(mk(), TorchCamera(t.camera, dev), bg, use_graph=use_graph)\n"
+        "    assert ts.exchange and ts.exchange_in_graph\n"
+        "    losses = [float(ts.step(cam, gt)) for _ in range(10)]\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert (ts._graph is not None) == use_graph and losses[-1] < losses[0]\n"
+        "    res[use_graph] = ts.pc.flat.clone()\n"
+        "d = float((res[True] - res[False]).abs().max())\n"
+        "assert d < 2e-3, d\n"
+        "print('captured-exchange-ok', d)\n"
+        "dist.destroy_process_group()\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert "captured-exchange-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_bench_exchange_machinery_on_one_gpu_accumulates_rounds_in_place(gpu_device):
     """`bench.py --exchange-at-1`: the N > 1 step (two gradient-buffer sets, rounds that ADD to the set in the backward
     kernel, one fold and one RCCL all-reduce per step) on a one-rank group.  Every round renders the same views, so
