@@ -357,6 +357,7 @@ struct SortArgs {
     float* empty_color;
     const float* bg;
     int W, H;
+    uint32_t* stripe_cursor;
 };
 
 __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
@@ -374,6 +375,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
     const float* __restrict__ bg = a.bg;
     __shared__ SortXchgT<4> sx;
     const bool overflow = frame_overflow(v.counts, v.bucket_cap);
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kStripes) a.stripe_cursor[threadIdx.x * kStripeWords] = 0u;   // (BwdUnit list cursors)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // the frame's verdict for the later kernels, and the counts for the host (pinned memory; made visible by the
         // end-of-kernel release; word 4 of the 64-byte slot = largest bucket need)
@@ -384,6 +386,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
         host_counts->max_tile_list = c->max_tile_list;
         host_counts->overflow = overflow ? 1u : 0u;
         reinterpret_cast<uint32_t*>(host_counts)[4] = c->max_bucket;
+        reinterpret_cast<uint32_t*>(host_counts)[5] = overflow ? 0u : c->num_units;   // (sizes the blend backward's grid)
         if (overflow) c->num_units = 0u;   // nothing to blend
     }
     // longest jobs first in dispatch order: medium lists, then the short ones
@@ -813,6 +816,7 @@ struct WalkOut {
     float Cr, Cg, Cb, T;
     uint32_t last;
     bool term;
+    uint32_t iters;   // loop iterations taken (wave-uniform): the unit's cost class for the backward
 };
 
 // Front-to-back blend of the records in `Bg` (bit j = record j of the staged unit) for this lane's pixel, starting at
@@ -826,7 +830,9 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
     o.T = T0;
     o.last = 0u;
     o.term = false;
+    o.iters = 0u;
     while (__any(Bg != 0ull)) {
+        o.iters++;
         int j[2];
         bool act[2];
 #pragma unroll
@@ -882,6 +888,7 @@ __device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restri
     o.T = 1.f;
     o.last = 0u;
     o.term = false;
+    o.iters = 64u;   // (a dense unit is a heavy unit)
     for (uint32_t j = 0; j < m; j += kGroup) {
         float alpha[kGroup], cr[kGroup], cg[kGroup], cb[kGroup];
         bool ok[kGroup];
@@ -1138,6 +1145,10 @@ struct ChainArgs {
     const uint4* unit_tile;
     RecSrc recs;
     uint2* masks;
+    uint2* walks;
+    BwdUnit* bwd_units;
+    uint32_t* stripe_cursor;
+    uint32_t heavy_iters;
     int W, H, tiles_x;
     float* g_tseg;
     float* g_out;
@@ -1171,7 +1182,8 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rec = s_rec_all[wave_in_wg];
     const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
-    if (u >= counts->num_units) return;
+    const uint32_t nu_all = counts->num_units;
+    if (u >= nu_all) return;
     const TransposeConsts tc = transpose_consts(lane);
     const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
     RecRegs rr = fetch_record(recs, (size_t)ui.start, ui.base + (uint32_t)lane, ui.n);
@@ -1187,6 +1199,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     rec[lane * kRecQuads + 1] = rr.q1;
     rec[lane * kRecQuads + 2] = rr.q2;
     const uint2 bt = transpose_bits64(fm, lane, tc);
+    a.walks[(size_t)u * kUnit + lane] = bt;   // (BinningView::walks: the backward does not repeat the transpose)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u64 Bp = ui.inside ? (((u64)bt.y << 32) | bt.x) : 0ull;
@@ -1199,6 +1212,15 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
                                            : walk_unit_fwd<false>(rec, Bp, 1.0f, fx, fy, ui.base);
     if (ui.base + kUnit < ui.n)   // (nobody reads the last unit's product)
         __hip_atomic_store(g_tseg + (size_t)u * kUnit + lane, fmaxf(o.T, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the unit's place in the backward's work list (BwdUnit): long walks from the front of its stripe, the others from the back
+    if (lane == 0) {
+        const bool heavy = o.iters >= a.heavy_iters;
+        const uint32_t j = u % kStripes, n_j = (nu_all - j + kStripes - 1u) / kStripes;   // the stripe and its slot count
+        const uint32_t k = atomicAdd(a.stripe_cursor + (j * 2u + (heavy ? 0u : 1u)) * kStripeWords, 1u);
+        BwdUnit* w = a.bwd_units + (j + kStripes * (heavy ? k : n_j - 1u - k));
+        w->d = make_uint4(ui.ty << 16 | ui.tx, ui.seg, ui.start, ui.n);
+        w->u = u;
+    }
 
     // ---- transmittance entering the unit: the products of the units in front, in list order
     float Tin = 1.0f;
@@ -1342,23 +1364,32 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     float* __restrict__ accum = a.accum;
     const uint32_t dense_pairs = a.dense_pairs;
     __shared__ SparseLds s_all[kWavesPerWG];
+#ifdef FR_BWD_TRACE
+    unsigned long long t_raw;   // the wave's very first instruction (nothing outstanding yet: the wait is for this read alone)
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_raw)::"memory");
+#endif
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef FR_BWD_SLEEP   // (timing experiment: do the early waves' loads slow the launch of the later waves?)
+    for (int k = 0; k < FR_BWD_SLEEP; k++) __builtin_amdgcn_s_sleep(16);
+#endif
     FR_STAMP(0);
     FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
+    FR_STAMPV(13, t_raw);
     // The first unit's descriptor is requested BEFORE the counts are known (one round trip less in front of every
     // wave's first loads): the descriptors sit at the head of the binning buffer whatever its capacity, and there are at
     // least T + 1 of them (BinningView::units_for), so index min(u, T) is always inside the buffer.
     const uint32_t n_tiles = (uint32_t)v.tiles_x * (uint32_t)v.tiles_y;
-    const uint32_t u_first = blockIdx.x * kWavesPerWG + wave_in_wg;
+    const uint32_t w_first = blockIdx.x * kWavesPerWG + wave_in_wg;   // slot of the work list (BwdUnit)
     const uint32_t nu = counts->num_units, capacity = counts->capacity;
-    const uint4 d_first = BinningView::make(binning, 0, (size_t)n_tiles).unit_tile[min(u_first, n_tiles)];
+    const BwdUnit* __restrict__ work = BinningView::make(binning, 0, (size_t)n_tiles).bwd_units;
+    const uint4 d_first = work[min(w_first, n_tiles)].d;
+    const uint32_t u_of_first = work[min(w_first, n_tiles)].u;
     // (pinned together: the descriptor load is issued before anything waits for the counts — without this the compiler
     // parks it behind the loop's entry test, i.e. behind the counts' round trip)
-    asm volatile("" ::"v"(d_first.x), "s"(nu), "s"(capacity));
+    asm volatile("" ::"v"(d_first.x), "v"(u_of_first), "s"(nu), "s"(capacity));
     const BinningView b = BinningView::make(binning, (size_t)capacity, (size_t)n_tiles);
     SparseLds& S = s_all[wave_in_wg];
-    const TransposeConsts tc = transpose_consts(lane);
     const uint32_t wave_stride = gridDim.x * kWavesPerWG;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     // flush: lanes 0..62 = 7 records x 9 components; lane l of a septet starting at record r0 reads word r0 * 9 + l of
@@ -1369,11 +1400,12 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     const int vv = bitrev6(lane);
     const int own_u = vv / 9, own_c = vv - own_u * 9;
     const size_t HW = (size_t)H * W;
-    for (uint32_t u = u_first; u < nu; u += wave_stride) {
+    for (uint32_t w = w_first; w < nu; w += wave_stride) {
         // ---- every load below depends on the descriptor only: all of them are in flight together (clamped indices keep
         // them unconditional; the compiler serialises loads that sit behind exec-masked branches)
         uint4 d = d_first;
-        if (u != u_first || u > n_tiles) d = b.unit_tile[u];
+        uint32_t u = u_of_first;
+        if (w != w_first || w > n_tiles) d = work[w].d, u = work[w].u;
         const uint32_t base = d.y * kUnit, start = d.z, n = d.w;
         const uint32_t m = min((uint32_t)kUnit, n - base);
         const int tx0 = (int)(d.x & 0xFFFFu) * kTile, ty0 = (int)(d.x >> 16) * kTile;
@@ -1387,11 +1419,12 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         const float4 rq0 = rsrc[0], rq1 = rsrc[1];
         const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
         const uint2 mraw = b.masks[(size_t)start + ridx];
+        const uint2 bt = b.walks[(size_t)u * kUnit + lane];   // the unit's footprint masks, pixel-major
         const float4 st = b.unit_state[(size_t)u * kUnit + lane];
         const float Tf_raw = v.final_T[pix];
         const float d0 = dL_dpix[pix], d1 = dL_dpix[HW + pix], d2 = dL_dpix[2 * HW + pix];
         // (pinned: otherwise everything but n_contrib is sunk below the early exit, a second round trip)
-        asm volatile("" ::"v"(last_raw), "v"(rq0.x), "v"(rq1.x), "v"(rq2.x), "v"(mraw.x), "v"(st.x), "v"(Tf_raw), "v"(d0), "v"(d1), "v"(d2));
+        asm volatile("" ::"v"(last_raw), "v"(rq0.x), "v"(rq1.x), "v"(rq2.x), "v"(mraw.x), "v"(bt.x), "v"(st.x), "v"(Tf_raw), "v"(d0), "v"(d1), "v"(d2));
         FR_STAMP(1);
         const uint32_t last = inside ? last_raw : 0u;
         // nothing at or behind the deepest contributor of any pixel of the tile can matter
@@ -1414,13 +1447,14 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         S.rec[lane * kRecQuads + 1] = make_float4(valid_rec ? rq1.x : 0.f, valid_rec ? rq1.y : 0.f, valid_rec ? rq1.z : 0.f, valid_rec ? rq1.w : 0.f);
         // the walks read (colour b, first pair slot, mask) from the third quad, the all-pairs form (colour b, id)
         S.rec[lane * kRecQuads + 2] = make_float4(rq2.x, dense ? rq2.y : __uint_as_float(cum - cnt), __uint_as_float(mj.x), __uint_as_float(mj.y));
-        // record-major masks -> pixel-major walk sets, limited to the records in front of the pixel's last contributor
-        const uint2 bt = transpose_bits64(mj, lane, tc);
+        // the pixel's walk set, limited to the records in front of its last contributor
         const int lim = (int)last - (int)base;      // records [0, lim) of this unit can contribute to this pixel
         u64 Bp = ((u64)bt.y << 32) | bt.x;
         Bp = lim <= 0 ? 0ull : (lim >= 64 ? Bp : (Bp & ((1ull << lim) - 1ull)));
         FR_STAMP(3);
         FR_STAMPV(9, npairs);
+        FR_STAMPV(10, n);
+        FR_STAMPV(11, base);
 #ifdef FR_BWD_TRACE   // (tools/diag/bwd_lens.py: the walk lengths of every unit, for scheduling simulations)
         if (u < 8192u) g_bwd_lens[u * 128u + lane] = (unsigned char)__popcll(Bp), g_bwd_lens[u * 128u + 64u + lane] = (unsigned char)cnt;
 #endif
@@ -1646,10 +1680,10 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         a.host_counts = h->host_counts_dev;
         a.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
         a.empty_color = h->gather_in_chain ? f[k].out_color : nullptr;
-        a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H;
+        a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H, a.stripe_cursor = b.stripe_cursor;
         ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].ids = b.ids;
         ChainArgs& c = ca[k];
-        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks;
+        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_iters = h->heavy_iters;
         c.recs = RecSrc{b.ids, f[k].g.rec_tmpl};
         c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
         c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;
@@ -1690,8 +1724,16 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
 
 int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, const ImageView* v, hipStream_t s, bool debug)
 {
-    // the unit count lives on the device: fixed grid, grid-stride loop over the units
-    const uint32_t unit_grid = kUnitGrid;
+    // The unit count lives on the device: grid-stride loop over the units, whatever the grid.  The grid follows the unit
+    // count of the handle's most recent frame whose counts have reached the host (+ 1/8), between 256 and kUnitGrid
+    // workgroups: waves that find no unit still cost a dispatch slot and a round trip for the counts.
+    uint32_t unit_grid = 256;
+    for (int k = 0; k < n; k++) {
+        const fr_handle_impl* h = calls[k].h;
+        const uint32_t seen = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[5] : ~0u;
+        const uint32_t want = seen > 4u * kUnitGrid ? kUnitGrid : (seen + seen / 8 + kWavesPerWG - 1) / kWavesPerWG;
+        unit_grid = min(kUnitGrid, max(unit_grid, want));
+    }
     BlendBwdArgs a[kMaxBatch];
     for (int k = 0; k < n; k++) {
         a[k].counts = v[k].counts, a[k].v = v[k], a[k].binning = const_cast<void*>(calls[k].binning);

@@ -176,12 +176,30 @@ struct BatchOf {
 
 // A blend UNIT is one 64-record segment of one tile's sorted list: the independent work item of the
 // blend kernels.  Per unit and pixel (lane) the forward leaves what the other passes need.
+// The blend BACKWARD's work list: slot w = the unit wave w takes.  The forward blend fills it, heavy units (long walks)
+// from the front and light ones from the back: the waves of a dispatch start over several microseconds, in slot order,
+// and the kernel ends with its slowest unit — the long ones go first.
+struct BwdUnit {
+    uint4 d;       // the unit's descriptor (BinningView::unit_tile)
+    uint32_t u;    // the unit
+    uint32_t pad[3];
+};
+// The list is filled without a global cursor (four thousand returning atomics on one address take 100 us): unit u
+// belongs to stripe u % kStripes, which owns the slots j, j + kStripes, j + 2 kStripes ... and has a heavy cursor (from
+// its front) and a light cursor (from its back), each on a cache line of its own.
+constexpr uint32_t kStripes = 64;
+constexpr uint32_t kStripeWords = 16;   // words between two cursors
+
 struct BinningView {
     size_t cap, unit_cap;
+    BwdUnit* bwd_units;   // [unit_cap]
+    uint32_t* stripe_cursor;   // [kStripes * 2 * kStripeWords] (zeroed by k_tile_sort)
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
     uint32_t* ids;        // [cap]   the Gaussian id of every (tile, Gaussian) instance, per tile in blend order (depth, then
                           //         id): the blend kernels gather the 48-byte record from GeomView::rec_tmpl through it
     uint2* masks;         // [cap]   footprint mask of every record (k_unit_blend_chained writes it, the backward reads it)
+    uint2* walks;         // [unit_cap*64] the same bits pixel-major: bit j of word u*64 + p = record j of unit u names pixel p
+                          //         (the forward has the 64 x 64 transpose in registers; the backward walks by pixel)
     uint4* unit_tile;     // [unit_cap] descriptor of each unit: (tile y << 16 | tile x, segment, list start, list length)
     uint32_t* unit_done;  // [unit_cap] k_unit_blend_chained: the unit's final contribution is in memory (zeroed by k_tile_sort)
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
@@ -194,11 +212,14 @@ struct BinningView {
         BinningView b;
         b.cap = cap;
         b.unit_cap = units_for(cap, T);
-        // (the descriptors come FIRST: their address does not depend on the capacity, so the blend backward, which
+        // (the backward's work list comes FIRST: its address does not depend on the capacity, so the blend backward, which
         // learns the capacity from the device counts, can request a unit's descriptor together with the counts)
+        b.bwd_units = carve<BwdUnit>(p, b.unit_cap);
         b.unit_tile = carve<uint4>(p, b.unit_cap);
+        b.stripe_cursor = carve<uint32_t>(p, kStripes * 2 * kStripeWords);
         b.keys = carve<uint64_t>(p, cap);
         b.masks = carve<uint2>(p, cap);
+        b.walks = carve<uint2>(p, b.unit_cap * kUnit);
         b.ids = carve<uint32_t>(p, cap);
         b.unit_done = carve<uint32_t>(p, b.unit_cap);
         b.unit_tseg = carve<float>(p, b.unit_cap * kUnit);
@@ -274,6 +295,7 @@ struct fr_handle_impl {
     std::vector<void*> retired;
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
+    uint32_t heavy_iters = 11;   // a unit whose forward walk takes at least this many iterations (two records each) is classed heavy (FR_HEAVY_ITERS)
     uint32_t chain_spins = 1u << 16;   // polls before a blend unit stops waiting for another one and computes its product / row itself (FR_CHAIN_SPINS)
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events

@@ -22,6 +22,11 @@ g = (np.random.default_rng(0).uniform(-1, 1, (3, a.res, a.res)) / (a.res * a.res
 for _ in range(3):
     f.backward(g)
 torch.cuda.synchronize()
+if os.environ.get("FR_TRACE_IDLE"):   # the traced launch on an idle GPU, nothing queued in front of it
+    import time
+    time.sleep(0.05)
+    f.backward(g)
+    torch.cuda.synchronize()
 L = _lib.lib()
 buf = np.zeros(8192 * 16, np.uint64)
 L.fr_debug_read_bwd_trace.argtypes = [C.c_void_p, C.c_size_t]
@@ -50,3 +55,48 @@ for i in idx:
     print("slow unit: total", tot[i], "segments", d[i].tolist(), "pairs", w[i, 9])
 # correlation of unit duration with pairs
 print("corr(total, pairs) =", np.corrcoef(tot, w[:, 9])[0, 1])
+# who finishes last: entry / exit (us from the first entry), duration in cycles, and the unit index
+ent = (w[:, 8] - rt0) / 100.0
+ext = (w[:, 12] - rt0) / 100.0
+uidx = np.nonzero(work)[0]
+print("exit time percentiles (us): p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(ext, [50, 90, 99, 100])))
+print("entry time percentiles (us): p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(ent, [50, 90, 99, 100])))
+for i in np.argsort(-ext)[:10]:
+    print(f"late wave {uidx[i]:5d}: entry {ent[i]:6.2f} exit {ext[i]:6.2f} us, cycles {tot[i]}, segments {d[i].tolist()}, pairs {w[i, 9]}")
+print("cycles per us over the slowest waves: %.0f" % np.median(tot[np.argsort(-tot)[:50]] / (ext - ent)[np.argsort(-tot)[:50]]))
+# dispatch-order simulation: the waves enter along the measured ramp whatever they carry; kernel end = max(entry + duration)
+dur = ext - ent
+ramp = np.sort(ent)
+n_list, base = w[:, 10], w[:, 11]
+def sim(order, label):
+    end = (ramp + dur[order]).max()
+    print(f"  order {label:34s}: kernel end {end:6.2f} us")
+print("dispatch-order simulation (measured ramp, measured durations):")
+sim(np.arange(len(dur)), "as dispatched (unit index)")
+sim(np.argsort(-dur), "longest first (oracle)")
+sim(np.argsort(-w[:, 9]), "most pairs first")
+sim(np.argsort(-(n_list.astype(np.int64) * 64 - base), kind="stable"), "longest list first, front units first")
+sim(np.argsort(-n_list, kind="stable"), "longest list first")
+sim(np.argsort(-np.minimum(n_list - base, 64) * 1000 - n_list, kind="stable"), "full units first, then by list")
+print("corr(duration, n) %.3f corr(duration, pairs) %.3f corr(duration, min(n-base,64)) %.3f" % (
+    np.corrcoef(dur, n_list)[0, 1], np.corrcoef(dur, w[:, 9])[0, 1], np.corrcoef(dur, np.minimum(n_list - base, 64))[0, 1]))
+
+print("entry time by unit index (us):", " ".join(f"{uidx[i]}:{ent[i]:.2f}" for i in range(0, len(ent), max(1, len(ent) // 24))))
+print("entry -> first stamp (loads landed), us: p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(d[:, 0] / 2230.0, [50, 90, 100])))
+
+raw = (w[:, 13] - w[:, 13].min()) / 100.0
+print("RAW entry (first instruction) percentiles (us): p50 %.2f p90 %.2f p99 %.2f max %.2f; kernargs+first code -> 'entry' stamp: mean %.2f max %.2f us"
+      % (*np.percentile(raw, [50, 90, 99, 100]), ((w[:, 8] - w[:, 13]) / 100.0).mean(), ((w[:, 8] - w[:, 13]) / 100.0).max()))
+print("raw entry by unit index (us):", " ".join(f"{uidx[i]}:{raw[i]:.2f}" for i in range(0, len(ent), max(1, len(ent) // 24))))
+# two-class dispatch (heavy units first, arrival order inside a class): what a forward-side classification could give
+rng = np.random.default_rng(0)
+def two_class(score, frac, label):
+    thr = np.quantile(score, 1.0 - frac)
+    heavy = score >= thr
+    order = np.concatenate([rng.permutation(np.nonzero(heavy)[0]), rng.permutation(np.nonzero(~heavy)[0])])
+    sim(order, f"2 classes, top {int(frac * 100)}% by {label}")
+for fr in (0.1, 0.25, 0.5):
+    two_class(w[:, 9].astype(float), fr, "pairs")
+    two_class(d[:, 3].astype(float), fr, "phase-A cycles")
+    two_class(dur, fr, "duration (oracle)")
+sim(rng.permutation(len(dur)), "random order")
