@@ -100,3 +100,15 @@ for fr in (0.1, 0.25, 0.5):
     two_class(d[:, 3].astype(float), fr, "phase-A cycles")
     two_class(dur, fr, "duration (oracle)")
 sim(rng.permutation(len(dur)), "random order")
+
+it = w[:, 14]
+print("forward walk iterations of the units: p10 %d p50 %d p75 %d p90 %d p99 %d max %d; corr(duration, iters) %.3f, corr(phase A cycles, iters) %.3f"
+      % (*np.percentile(it, [10, 50, 75, 90, 99, 100]), np.corrcoef(dur, it)[0, 1], np.corrcoef(d[:, 3], it)[0, 1]))
+for thr in (8, 10, 11, 12, 14, 16):
+    print(f"  iters >= {thr}: {100.0 * (it >= thr).mean():.0f} % of the units")
+two_class(it.astype(float), 0.1, "forward iterations")
+two_class(it.astype(float), 0.25, "forward iterations")
+sim(np.argsort(-it, kind="stable"), "most forward iterations first")
+slot = np.nonzero(work)[0]
+print("mean duration (us) by slot decile:", " ".join(f"{dur[(slot >= a) & (slot < b)].mean():.1f}" for a, b in zip(np.linspace(0, slot.max() + 1, 11)[:-1], np.linspace(0, slot.max() + 1, 11)[1:])))
+print("mean entry (us) by slot decile:   ", " ".join(f"{ent[(slot >= a) & (slot < b)].mean():.1f}" for a, b in zip(np.linspace(0, slot.max() + 1, 11)[:-1], np.linspace(0, slot.max() + 1, 11)[1:])))
