@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         BwdUnit* w = a.bwd_units + (j + kStripes * (heavy ? k : n_j - 1u - k));
         w->d = make_uint4(ui.ty << 16 | ui.tx, ui.seg, ui.start, ui.n);
         w->u = u;
-        w->pad[0] = o.iters;   // (development: tools/diag/bwd_trace.py)
+        w->pad[0] = npairs, w->pad[1] = o.iters;   // (development: tools/diag/bwd_trace.py, bwd_order.py)
     }
 
     // ---- transmittance entering the unit: the products of the units in front, in list order
@@ -1328,10 +1328,15 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
 __device__ unsigned long long g_bwd_trace[8192 * 16];
 #define FR_STAMP(K) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
 #define FR_STAMPV(K, V) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = (unsigned long long)(V); } while (0)
+__device__ unsigned int g_bwd_work[8192 * 4];   // per UNIT: phase A iterations, phase B iterations, record ranges, pairs
 __device__ unsigned char g_bwd_lens[8192 * 128];   // per unit: 64 phase-A chain lengths, 64 phase-B walk lengths
 extern "C" int fr_debug_read_bwd_lens(void* dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_lens), bytes < sizeof(g_bwd_lens) ? bytes : sizeof(g_bwd_lens));
+}
+extern "C" int fr_debug_read_bwd_work(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bwd_work), bytes < sizeof(g_bwd_work) ? bytes : sizeof(g_bwd_work));
 }
 extern "C" int fr_debug_read_bwd_trace(void* dst, size_t bytes)
 {
@@ -1377,6 +1382,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     FR_STAMP(0);
     FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     FR_STAMPV(13, t_raw);
+    FR_STAMPV(15, ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4));   // XCC_ID, HW_ID
     // The first unit's descriptor is requested BEFORE the counts are known (one round trip less in front of every
     // wave's first loads): the descriptors sit at the head of the binning buffer whatever its capacity, and there are at
     // least T + 1 of them (BinningView::units_for), so index min(u, T) is always inside the buffer.
@@ -1459,7 +1465,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         FR_STAMPV(9, npairs);
         FR_STAMPV(10, n);
         FR_STAMPV(11, base);
-        FR_STAMPV(14, work[w].pad[0]);
+        FR_STAMPV(14, u);
 #ifdef FR_BWD_TRACE   // (tools/diag/bwd_lens.py: the walk lengths of every unit, for scheduling simulations)
         if (u < 8192u) g_bwd_lens[u * 128u + lane] = (unsigned char)__popcll(Bp), g_bwd_lens[u * 128u + 64u + lane] = (unsigned char)cnt;
 #endif
@@ -1509,6 +1515,16 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
             // iteration: their alpha evaluations and slot computations are independent instruction streams; only the
             // T / accum_rec recurrence is serial
             u64 Bg = Bp & range;
+#ifdef FR_BWD_TRACE
+            {
+                const uint32_t ia = (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1;
+                const uint32_t ib = (wave_max_u32((uint32_t)__popcll((lane >= lo && lane < hi) ? Mj : 0ull)) + 1u) >> 1;
+                if (lane == 0 && u < 8192u) {
+                    if (hi == (int)m) g_bwd_work[u * 4 + 0] = 0u, g_bwd_work[u * 4 + 1] = 0u, g_bwd_work[u * 4 + 2] = 0u, g_bwd_work[u * 4 + 3] = npairs;
+                    g_bwd_work[u * 4 + 0] += ia, g_bwd_work[u * 4 + 1] += ib, g_bwd_work[u * 4 + 2] += 1u;
+                }
+            }
+#endif
 #ifdef FR_BWD_STATS   // development build (tools/diag/bwd_stats.sh): where do the kernel's iterations go?
             if (lane == 0) {
                 DeviceCounts* dc = const_cast<DeviceCounts*>(counts);

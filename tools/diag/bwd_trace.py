@@ -101,7 +101,7 @@ for fr in (0.1, 0.25, 0.5):
     two_class(dur, fr, "duration (oracle)")
 sim(rng.permutation(len(dur)), "random order")
 
-it = w[:, 14]
+it = w[:, 9] * 0 + 1   # (slot 14 of the trace is the unit index now)
 print("forward walk iterations of the units: p10 %d p50 %d p75 %d p90 %d p99 %d max %d; corr(duration, iters) %.3f, corr(phase A cycles, iters) %.3f"
       % (*np.percentile(it, [10, 50, 75, 90, 99, 100]), np.corrcoef(dur, it)[0, 1], np.corrcoef(d[:, 3], it)[0, 1]))
 for thr in (8, 10, 11, 12, 14, 16):
@@ -112,3 +112,45 @@ sim(np.argsort(-it, kind="stable"), "most forward iterations first")
 slot = np.nonzero(work)[0]
 print("mean duration (us) by slot decile:", " ".join(f"{dur[(slot >= a) & (slot < b)].mean():.1f}" for a, b in zip(np.linspace(0, slot.max() + 1, 11)[:-1], np.linspace(0, slot.max() + 1, 11)[1:])))
 print("mean entry (us) by slot decile:   ", " ".join(f"{ent[(slot >= a) & (slot < b)].mean():.1f}" for a, b in zip(np.linspace(0, slot.max() + 1, 11)[:-1], np.linspace(0, slot.max() + 1, 11)[1:])))
+
+# where the waves ran: HW_ID (wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13) + XCC_ID
+hw = w[:, 15]
+xcc, hwid = hw >> 32, hw & 0xFFFFFFFF
+simd, cu, sh, se = (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 12) & 1, (hwid >> 13) & 7
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+simd_key = cu_key * 4 + simd
+print(f"distinct XCCs {len(np.unique(xcc))}, CUs {len(np.unique(cu_key))}, SIMDs {len(np.unique(simd_key))}")
+cyc = tot.astype(float)
+busy = cyc - d[:, 0]   # cycles after the loads landed
+def per(key, val):
+    ks, inv = np.unique(key, return_inverse=True)
+    return np.bincount(inv, weights=val), np.bincount(inv)
+for name, key in (("SIMD", simd_key), ("CU", cu_key), ("XCC", xcc)):
+    ssum, cnt = per(key, busy)
+    last, _ = per(key, np.zeros(len(key)))
+    ends = np.array([ext[key == k].max() for k in np.unique(key)])
+    print(f"per {name}: waves min {cnt.min()} max {cnt.max()}; sum of post-load cycles mean {ssum.mean():.0f} max {ssum.max():.0f} (max/mean {ssum.max() / ssum.mean():.2f}); "
+          f"last exit mean {ends.mean():.2f} p90 {np.percentile(ends, 90):.2f} max {ends.max():.2f} us; corr(sum, last exit) {np.corrcoef(ssum, ends)[0, 1]:.2f}")
+print("slot -> (xcc, se, sh, cu, simd) of the first 24 slots:", [(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i])) for i in range(24)])
+# slots sharing a SIMD
+ks = np.unique(simd_key)
+ex = [sorted(slot[simd_key == k].tolist()) for k in ks[:6]]
+print("slots on the first SIMDs:", ex)
+
+# per-unit work counters (indexed by unit) for tools/diag/bwd_order.py
+wk = np.zeros(8192 * 4, np.uint32)
+L.fr_debug_read_bwd_work.argtypes = [C.c_void_p, C.c_size_t]
+assert L.fr_debug_read_bwd_work(wk.ctypes.data, wk.nbytes) == 0
+wk = wk.reshape(8192, 4)
+os.makedirs("gpurun_out", exist_ok=True)
+np.save("gpurun_out/bwd_work.npy", wk)
+uw = w[:, 14]  # (class or pairs; not the unit) -- the unit index of a slot is not in the trace: use the counters by unit
+n_units = int((wk[:, 2] > 0).sum())
+print(f"work counters of {n_units} units: phase A iterations mean {wk[:n_units, 0].mean():.1f} max {wk[:n_units, 0].max()}, phase B {wk[:n_units, 1].mean():.1f} max {wk[:n_units, 1].max()}, ranges mean {wk[:n_units, 2].mean():.2f}")
+
+du = np.zeros(8192)
+du[w[:, 14]] = dur
+np.save("gpurun_out/bwd_dur.npy", du)
+pa = np.zeros(8192)
+pa[w[:, 14]] = d[:, 3]
+np.save("gpurun_out/bwd_phase_a.npy", pa)
