@@ -129,7 +129,6 @@ int fr_create(fr_handle** out)
     h->dense_pairs_fwd = pf ? (uint32_t)strtoul(pf, nullptr, 10) : kDensePairsFwd;
     h->dense_pairs_bwd = pb ? (uint32_t)strtoul(pb, nullptr, 10) : kDensePairsBwd;
     if (const char* hp = getenv("FR_HEAVY_PAIRS")) h->heavy_pairs = (uint32_t)strtoul(hp, nullptr, 10);
-    if (const char* hi = getenv("FR_HEAVY_ITERS")) h->heavy_iters = (uint32_t)strtoul(hi, nullptr, 10);
     if (const char* cs = getenv("FR_CHAIN_SPINS")) h->chain_spins = (uint32_t)strtoul(cs, nullptr, 10);
     const char* ph = getenv("FR_DEBUG_PAIR_HIST");
     h->debug_pair_hist = ph && ph[0] == '1';

@@ -1148,7 +1148,7 @@ struct ChainArgs {
     uint2* walks;
     BwdUnit* bwd_units;
     uint32_t* stripe_cursor;
-    uint32_t heavy_iters, heavy_pairs;
+    uint32_t heavy_pairs;
     int W, H, tiles_x;
     float* g_tseg;
     float* g_out;
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         __hip_atomic_store(g_tseg + (size_t)u * kUnit + lane, fmaxf(o.T, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the unit's place in the backward's work list (BwdUnit): long walks from the front of its stripe, the others from the back
     if (lane == 0) {
-        const bool heavy = npairs >= a.heavy_pairs || o.iters >= a.heavy_iters;
+        const bool heavy = npairs >= a.heavy_pairs;
         const uint32_t j = u % kStripes, n_j = (nu_all - j + kStripes - 1u) / kStripes;   // the stripe and its slot count
         const uint32_t k = atomicAdd(a.stripe_cursor + (j * 2u + (heavy ? 0u : 1u)) * kStripeWords, 1u);
         BwdUnit* w = a.bwd_units + (j + kStripes * (heavy ? k : n_j - 1u - k));
@@ -1376,9 +1376,6 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
 #endif
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef FR_BWD_SLEEP   // (timing experiment: do the early waves' loads slow the launch of the later waves?)
-    for (int k = 0; k < FR_BWD_SLEEP; k++) __builtin_amdgcn_s_sleep(16);
-#endif
     FR_STAMP(0);
     FR_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     FR_STAMPV(13, t_raw);
@@ -1448,9 +1445,6 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
         // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
         const bool dense = npairs > dense_pairs;
-#ifdef FR_BWD_PRIO   // (timing experiment: the units that need more than one record range ahead of their SIMD's other waves)
-        if (npairs > (uint32_t)kPairCap) __builtin_amdgcn_s_setprio(FR_BWD_PRIO);
-#endif
         const uint32_t my_id = __float_as_uint(rq2.y);
         // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch)
         S.rec[lane * kRecQuads + 0] = make_float4(valid_rec ? rq0.x : 0.f, valid_rec ? rq0.y : 0.f, valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
@@ -1636,9 +1630,6 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
             if (hi == (int)m) FR_STAMP(6);
             hi = lo;
         }
-#ifdef FR_BWD_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         FR_STAMP(7);
         FR_STAMPV(12, __builtin_amdgcn_s_memrealtime());
     }
@@ -1707,7 +1698,7 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H, a.stripe_cursor = b.stripe_cursor;
         ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].ids = b.ids;
         ChainArgs& c = ca[k];
-        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_iters = h->heavy_iters, c.heavy_pairs = h->heavy_pairs;
+        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_pairs = h->heavy_pairs;
         c.recs = RecSrc{b.ids, f[k].g.rec_tmpl};
         c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
         c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;

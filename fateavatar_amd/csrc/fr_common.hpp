@@ -295,8 +295,7 @@ struct fr_handle_impl {
     std::vector<void*> retired;
     uint32_t dense_pairs_fwd = 0, dense_pairs_bwd = 0;  // per-unit pair counts above which the all-pairs loops take a unit (FR_DENSE_PAIRS_FWD / _BWD)
     bool debug_pair_hist = false;
-    uint32_t heavy_pairs = 641;  // a unit that names at least this many pairs (FR_HEAVY_PAIRS: more than the backward's pair slots hold at once) ...
-    uint32_t heavy_iters = 999;   // a unit whose forward walk takes at least this many iterations (two records each) is classed heavy (FR_HEAVY_ITERS)
+    uint32_t heavy_pairs = 641;  // a unit that names at least this many pairs goes to the FRONT of the backward work list (FR_HEAVY_PAIRS; default = more than the pair slots of k_unit_blend_bwd_sparse hold at once, FR_PAIR_CAP + 1)
     uint32_t chain_spins = 1u << 16;   // polls before a blend unit stops waiting for another one and computes its product / row itself (FR_CHAIN_SPINS)
     bool gather_in_chain = true;    // FR_BLEND_FWD=gather: a separate k_tile_gather launch instead of the tile's last unit gathering
     bool profiling = false;      // fr_profile_enable: bracket every stage launch with HIP events

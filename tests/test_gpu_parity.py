@@ -884,14 +884,16 @@ def test_two_frames_in_flight_like_the_reference_batch_loop(gpu_device, fused, m
 
 @pytest.mark.parametrize("mode", ["FR_BLEND_FWD=gather",
                                   "FR_DENSE_PAIRS_FWD=0,FR_DENSE_PAIRS_BWD=0", "FR_DENSE_PAIRS_FWD=9999,FR_DENSE_PAIRS_BWD=9999",
-                                  "FR_CHAIN_SPINS=0", "FR_CHAIN_SPINS=3"])
+                                  "FR_CHAIN_SPINS=0", "FR_CHAIN_SPINS=3", "FR_HEAVY_PAIRS=0", "FR_HEAVY_PAIRS=99999", "FR_HEAVY_PAIRS=60"])
 def test_selectable_blend_paths_stay_correct(gpu_device, mode):
     """The blend paths the environment can select (the gather as its own launch, and the per-unit
     all-pairs / sparse choice forced either way — 0: every unit takes the in-kernel all-pairs loops, 9999: none does, units
     with more pairs than slots are walked in record ranges) must keep matching the oracle for as long as they stay in
     the tree.  FR_CHAIN_SPINS=0 / 3: the units of the one-launch forward give up waiting for each other at
     once (after three polls) and compute the missing products and rows themselves — the path that makes the launch
-    independent of dispatch order.  Run in a subprocess: the switches are read at handle creation."""
+    independent of dispatch order.  FR_HEAVY_PAIRS: the order of the backward's work list (every unit from the front,
+    every unit from the back, most units in front) must not matter for the result.  Run in a subprocess: the switches
+    are read at handle creation."""
     import os
     import subprocess
     import sys
@@ -917,6 +919,38 @@ def test_selectable_blend_paths_stay_correct(gpu_device, mode):
         env[k] = v
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "mode-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_backward_work_list_is_a_permutation_of_the_units(gpu_device):
+    """k_unit_blend_chained leaves the blend backward a work list (BinningView::bwd_units, the first array of the binning
+    buffer: 32 bytes per slot = descriptor, unit): every unit exactly once, whatever the stripes' cursors did — long
+    lists (several units per tile, units in both classes) and a scene of short ones."""
+    import torch
+    for s, want_heavy in ((scenes.random_scene(4000, 64, 64, sh_degree=0, seed=5, opacity_lo=0.6, opacity_hi=0.99, scale_lo=0.02, scale_hi=0.08), True),
+                          (scenes.head_scene(P=20000, res=256, sh_degree=0, seed=1), False)):
+        h = util.HipFrame(s, gpu_device)
+        torch.cuda.synchronize()
+        n_tiles8 = ((s.camera.image_width + 7) // 8) * ((s.camera.image_height + 7) // 8)
+        off = (-h.binning.data_ptr()) & 255
+        # the number of units: every tile list of n entries has ceil(n / 64) of them; the descriptors carry (list start,
+        # list length), so count the distinct lists
+        raw = h.binning[off:off + 32 * (h.counts.num_instances // 64 + n_tiles8 + 1)].view(torch.int32).view(-1, 8).cpu().numpy()
+        # slots are filled densely from 0: find nu as the point where the units stop being a permutation prefix
+        starts = {}
+        nu = 0
+        for (xy, seg, start, n, u, *_pad) in raw.tolist():
+            if n <= 0 or seg * 64 >= n:
+                break
+            nu += 1
+        units = raw[:nu, 4]
+        lists = {(int(r[2]), int(r[3])) for r in raw[:nu]}
+        assert nu == sum((n + 63) // 64 for _, n in lists), (nu, len(lists))
+        assert sorted(units.tolist()) == list(range(nu))
+        # every slot's descriptor is its unit's: segment index in range, and the (start, n) pair names a list with that many units
+        for xy, seg, start, n, u, *_pad in raw[:nu].tolist():
+            assert 0 <= seg < (n + 63) // 64
+        if want_heavy:
+            assert h.counts.max_tile_list > 64
 
 
 def test_forward_chain_makes_progress_while_other_work_holds_the_cus(gpu_device):
