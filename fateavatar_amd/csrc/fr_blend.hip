@@ -1181,8 +1181,11 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rec = s_rec_all[wave_in_wg];
-    const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
     const uint32_t nu_all = counts->num_units;
+    // (Giving XCD x a contiguous run of the units, as the backward's work list does, takes 4 MB off this kernel's L2
+    // fills and 1 us off the isolated launch, but costs 2-3 % with frames in flight and at config 5: the heavy part of the
+    // image then sits on one XCD.  Measured, not kept.)
+    const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
     if (u >= nu_all) return;
     const TransposeConsts tc = transpose_consts(lane);
     const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
@@ -1215,7 +1218,23 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     // the unit's place in the backward's work list (BwdUnit): long walks from the front of its stripe, the others from the back
     if (lane == 0) {
         const bool heavy = npairs >= a.heavy_pairs;
-        const uint32_t j = u % kStripes, n_j = (nu_all - j + kStripes - 1u) / kStripes;   // the stripe and its slot count
+        // Which stripe?  Stripe j holds slots j, j + 64, ...: n_j = ceil((nu - j) / 64) of them, and the hardware runs
+        // the waves of slot w on XCD (w / 4) % 8, i.e. XCD x owns the eight stripes 4x .. 4x+3 and 32+4x .. 32+4x+3.
+        // The units are dealt out so that XCD x gets a CONTIGUOUS run of them (neighbouring tiles: each L2 then
+        // gathers its own eighth of the record table instead of all of it): the first N_0 units go to XCD 0, the next
+        // N_1 to XCD 1 ... (N_x = the capacity of x's stripes), and inside a run round-robin over the eight stripes,
+        // which fills every stripe exactly (the stripes of an XCD that have one slot more are the first ones).
+        const uint32_t q = nu_all / kStripes, rem = nu_all % kStripes;
+        uint32_t x = 0, first = 0;
+        for (; x < 7u; x++) {
+            const uint32_t lo4 = 4u * x, hi4 = 32u + 4u * x;
+            const uint32_t n_x = 8u * q + (rem > lo4 ? min(rem - lo4, 4u) : 0u) + (rem > hi4 ? min(rem - hi4, 4u) : 0u);
+            if (u < first + n_x) break;
+            first += n_x;
+        }
+        const uint32_t t = (u - first) & 7u;
+        const uint32_t j = t < 4u ? 4u * x + t : 32u + 4u * x + (t - 4u);
+        const uint32_t n_j = (nu_all - j + kStripes - 1u) / kStripes;   // the stripe's slot count
         const uint32_t k = atomicAdd(a.stripe_cursor + (j * 2u + (heavy ? 0u : 1u)) * kStripeWords, 1u);
         BwdUnit* w = a.bwd_units + (j + kStripes * (heavy ? k : n_j - 1u - k));
         w->d = make_uint4(ui.ty << 16 | ui.tx, ui.seg, ui.start, ui.n);
