@@ -407,10 +407,25 @@ class GradExchange:
         self.works = [None, None]
         self.k = 0
         self.rounds = max(1, int(rounds))   # every view's buffer holds the sum over the step's rounds
+        self.last = self.bufs[0]
 
-    def submit(self, eng):
-        """After the step's last round: mean of the views' accumulated gradients into an exchange buffer, all-reduce."""
+    def submit(self, eng, serial=False):
+        """After the step's last round: mean of the views' accumulated gradients into an exchange buffer, all-reduce.
+        `serial` (the literal step: one view, one round, nothing overlapped): the view's gradient buffer is reduced in
+        place, on the view's own stream, and that stream waits for the collective before its next frame — frame,
+        all-reduce, frame, all-reduce ..., two stream hand-overs per step (to RCCL's stream and back) and no copy."""
         from fateavatar_amd import dp
+        grads = eng.flat_grads()
+        if serial and len(grads) == 1 and self.rounds == 1:
+            st = getattr(eng.views[0], "stream", None) if hasattr(eng, "views") else None
+            if st is not None:
+                with torch.cuda.stream(st):
+                    dp.allreduce_mean_async(grads[0]).wait()
+            else:                                    # (the CPU stub of tests/test_bench_dp.py)
+                dp.allreduce_mean_async(grads[0]).wait()
+            self.last = grads[0]
+            self.k += 1
+            return
         i = self.k & 1
         if self.works[i] is not None:
             self.works[i].wait()
@@ -430,6 +445,7 @@ class GradExchange:
             torch.mul(acc, scale, out=buf)
         eng.mark_grads_read()                        # the step after next may overwrite these gradient buffers
         self.works[i] = dp.allreduce_mean_async(buf)
+        self.last = buf
         self.k += 1
 
     def drain(self):
@@ -439,7 +455,7 @@ class GradExchange:
                 self.works[i] = None
 
     def latest(self) -> torch.Tensor:
-        return self.bufs[(self.k - 1) & 1]
+        return self.last
 
 
 def _flush_c_stdio():
@@ -520,7 +536,7 @@ def main():
             for _ in range(rounds):
                 eng.enqueue_frame()
             if xchg is not None:
-                xchg.submit(eng)
+                xchg.submit(eng, serial=not overlap)
                 if not overlap:
                     xchg.drain()
 
@@ -534,6 +550,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        if os.environ.get("FR_BENCH_HOST_TIME") and rank == 0:
+            print(f"[host] K={K} rounds={rounds}: the {args.steps} steps were enqueued in {(time.perf_counter() - t0) * 1e6 / args.steps:.1f} us each", file=sys.stderr)
         if xchg is not None:
             xchg.drain()          # the last collectives are inside the clock
         eng.sync()
