@@ -10,11 +10,18 @@ With N > 1 and no torchrun environment the script re-executes itself through
 A FRAME is `render(camera, gaussians, bg)` through the reference's Python API (activations inside the HIP preprocess
 kernels by default, `--torch-activations` for the reference's stock PyTorch ops) followed by the backward pass down to the
 raw Gaussian parameters, replayed as one HIP graph.
-  N = 1: a step is `--rounds` (4) rounds of the views in flight (3, calibrated): the metric's configuration, configs[1].
+  N = 1: a step is `--rounds` (4) rounds of the frames in flight: the metric's configuration, configs[1].  HOW the
+         frames are in flight is calibrated (40 steps each; `config.in_flight_calibration_frames_per_s`): 1, 2 or 3 views
+         with a stream, a handle and a graph each, or 2 / 3 batched LAUNCH CHAINS of 4 views each (fr_forward_batch /
+         fr_backward_batch: every kernel of the frame launched once for the chain's views; a stream and a graph per
+         chain) — `--chains off` keeps the per-view streams, `--chains 4x3` forces a shape.  Every view has its own
+         camera, handle, scratch buffers and gradient buffers either way; `one_frame_at_a_time`, `views_on_streams` and
+         `batched_views` in the line are the other modes' rates on the same box.
   N > 1: TWO modes are timed in the same run, each with its own K steps, and both are in the line (`dp.modes`):
     literal    BASELINE configs[3] as written — every rank renders ONE view of the replicated Gaussians, then ONE RCCL
-               all-reduce(AVG) of the flat gradient buffer, and only then the next step starts (a synchronous
-               data-parallel optimisation step: the next frame needs the averaged gradient's update).  THIS is `value`.
+               all-reduce(AVG) of the flat gradient buffer (in place, on the view's stream), and only then the next step
+               starts (a synchronous data-parallel optimisation step: the next frame needs the averaged gradient's
+               update).  THIS is `value`.
     amortised  `--rounds` x (views in flight) frames per rank and exchange, their mean folded into one of two exchange
                buffers and all-reduced while the next step's frames render (local gradient accumulation; step k+2 waits
                for the collective of step k; the timed region ends when the last one has finished).
@@ -166,6 +173,8 @@ class HipEngine:
         self._render = render
         self.graph = None
         self.grads_read = [None, None]   # events: the exchange has read the gradient buffers of set 0 / 1
+        self._chains, self._extra_views = {}, []
+        self.chains = None               # (K, streams, views, graphs) when the timed steps run batched launch chains
 
     def set_mode(self, K, rounds):
         """Which views take part in a step and how many rounds a step has (bench modes: literal = 1 view, 1 round)."""
@@ -225,42 +234,73 @@ class HipEngine:
         outs = render_batch([v.cam for v in views], [v.pc for v in views], [v.bg for v in views], slots=[v.k for v in views])
         torch.autograd.backward([o["render"] for o in outs], grad_tensors=[v.dL_dpix for v in views])
 
-    def measure_batched(self, K, reps):
-        """K views per launch chain, one stream, one captured graph: frames/s (None if it cannot be set up here)."""
+    def setup_chains(self, K, streams):
+        """`streams` launch chains of K views each (fr_forward_batch / fr_backward_batch: every kernel of the frame launched
+        once for the K views), every chain captured as one graph on a stream of its own.  Returns (views, [(graph, stream)])."""
         from fateavatar_amd import scenes
-        views = list(self.all_views[:K])
-        while len(views) < K:   # (more views than the stream mode uses: a further camera around the head)
-            k = len(views)
-            views.append(_View(self, k, scenes.head_scene(P=self.args.P, res=self.args.res, sh_degree=self.args.sh_degree, seed=0,
-                                                          view=self.rank * K + k, n_views=max(K, 1), scale=self.args.scale,
-                                                          opacity=self.args.opacity)))
-        for _ in range(3):
-            self.batch_frame(views)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream(device=self.dev)
-        with self.rasterizer.no_wait():
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.batch_frame(views)
+        from fateavatar_amd.streams import concurrent_streams
+        key = (K, streams)
+        if key in self._chains:
+            return self._chains[key]
+        n = K * streams
+        views = list(self.all_views[:n])
+        views += self._extra_views[:n - len(views)]
+        while len(views) < n:   # (more views than the stream mode uses: further cameras around the head)
+            k = len(self.all_views) + len(self._extra_views)
+            v = _View(self, k, scenes.head_scene(P=self.args.P, res=self.args.res, sh_degree=self.args.sh_degree, seed=0,
+                                                 view=self.rank * n + k, n_views=max(n, 1), scale=self.args.scale, opacity=self.args.opacity))
+            self._extra_views.append(v)
+            views.append(v)
+        groups = [views[i * K:(i + 1) * K] for i in range(streams)]
+        sts = concurrent_streams(streams, self.dev, also_with=[torch.cuda.current_stream(self.dev)]) if streams > 1 \
+            else [torch.cuda.Stream(device=self.dev)]
+        graphs = []
+        for grp, side in zip(groups, sts):
+            for _ in range(3):
+                self.batch_frame(grp)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                self.batch_frame(views)
+            with self.rasterizer.no_wait():
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self.batch_frame(grp)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    self.batch_frame(grp)
+            graphs.append((g, side))
         torch.cuda.synchronize()
-        for _ in range(10):
-            g.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            g.replay()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        self._chains[key] = (views, graphs)
+        return self._chains[key]
+
+    @staticmethod
+    def replay_chains(graphs):
+        for g, side in graphs:
+            with torch.cuda.stream(side):
+                g.replay()
+
+    def chains_overflowed(self, views):
         for v in views:
             with self.rasterizer.handle_slot(v.k):
                 if self.rasterizer.check_async_overflow(self.local):
-                    return None
-        return {"value": round(K * reps / dt, 2), "unit": "frames/s", "views_per_launch_chain": K, "streams": 1,
+                    return True
+        return False
+
+    def measure_batched(self, K, reps, streams=1):
+        """K views per launch chain and captured graph, `streams` such chains in flight on streams of their own:
+        frames/s (None if it cannot be set up here)."""
+        views, graphs = self.setup_chains(K, streams)
+        for _ in range(10):
+            self.replay_chains(graphs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.replay_chains(graphs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if self.chains_overflowed(views):
+            return None
+        return {"value": round(K * streams * reps / dt, 2), "unit": "frames/s", "views_per_launch_chain": K, "streams": streams,
                 "launches_per_frame": round(6.0 / K, 2), "us_per_launch_chain": round(dt / reps * 1e6, 1)}
 
     def calibrate(self, world):
@@ -287,10 +327,29 @@ class HipEngine:
         self.views = self.views[:self.K]
         self.all_views = self.views
         self.calibration = {str(k + 1): round(float(x) / world, 1) for k, x in enumerate(r.tolist())}
+        # ... or batched launch chains in flight together: K views per chain through the same six launches
+        # (fr_forward_batch / fr_backward_batch), `streams` chains on streams of their own.  One process only: the
+        # exchange modes keep a graph per view (their gradient sets alternate per step).
+        if world == 1 and not self.exchanging and self.args.graph and self.args.chains != "off":
+            best = float(r.max().item())
+            cands = [(4, 2), (4, 3)] if self.args.chains == "auto" else [tuple(int(x) for x in self.args.chains.split("x"))]
+            for K, S in cands:
+                m = self.measure_batched(K, 30, S)
+                if m is None:
+                    continue
+                self.calibration[f"{S} chains x {K} views"] = m["value"]
+                if m["value"] > best * 1.02 or self.args.chains != "auto":
+                    best = m["value"]
+                    views, graphs = self.setup_chains(K, S)
+                    self.chains = (K, S, views, graphs)
 
     def enqueue_frame(self, views=None, count=True):
         """One ROUND: every view's render + backward, each on its own stream.  N > 1: a step is `rounds` rounds on one
         set of gradient buffers (the first overwrites them, the others add), and steps alternate between the two sets."""
+        if self.chains is not None and views is None and count:
+            self.replay_chains(self.chains[3])   # one ROUND = every chain's K views once
+            self.round_no += 1
+            return
         which, add, last = 0, False, False
         if self.exchanging and count:
             step, r = divmod(self.round_no, self.rounds)
@@ -333,6 +392,8 @@ class HipEngine:
     def finish(self):
         """After the timed region: overflow check of the captured frames, per-kernel durations, counts."""
         from fateavatar_amd import _lib
+        if self.chains is not None and self.chains_overflowed(self.chains[2]):
+            raise SystemExit("binning capacity overflowed inside a captured launch chain; rerun (capacity hint was raised)")
         for v in self.views:
             with self.rasterizer.handle_slot(v.k):
                 if v.graph is not None and self.rasterizer.check_async_overflow(self.local):
@@ -486,6 +547,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="views of a step that run concurrently on one GPU: 1 = one frame at a time (as in round 1), 0 = "
                          "calibrate (1, 2 or 3, whichever renders most frames per second here)")
+    ap.add_argument("--chains", default="auto",
+                    help="N = 1: batched launch chains in flight ('KxS' = S chains of K views each, 'auto' = try 4x2 and 4x3 "
+                         "next to the per-view streams and keep the fastest, 'off' = per-view streams only)")
     ap.add_argument("--rounds", type=int, default=4,
                     help="rounds of views per step: a step renders rounds x (views in flight) frames per GPU and, on N > 1 "
                          "GPUs, exchanges their mean gradient ONCE (local gradient accumulation in the backward kernel, "
@@ -579,6 +643,8 @@ def main():
     else:
         elapsed, xchg = run_mode(K_best, rounds, False)
         frames_per_step = K_best * rounds
+        if getattr(eng, "chains", None) is not None:
+            frames_per_step = eng.chains[0] * eng.chains[1] * rounds
 
     # the same engine with ONE view in flight (what `value` measured until views overlapped): a reference point
     single = None
@@ -593,7 +659,10 @@ def main():
     # K views through ONE launch chain (render_batch): the in-flight gain without any stream / hardware-queue arrangement
     batched = None
     if not STUB and not exchanging and args.graph:
-        batched = [b for b in (eng.measure_batched(K, max(20, args.steps * rounds // 2)) for K in (2, 3, 4)) if b is not None]
+        combos = [(2, 1), (3, 1), (4, 1)]
+        if os.environ.get("FR_BENCH_BATCH_X_STREAMS"):   # (experiment: batched chains in flight together)
+            combos += [(4, 2), (3, 3), (4, 3), (4, 4), (2, 3)]
+        batched = [b for b in (eng.measure_batched(K, max(20, args.steps * rounds // 2), S) for K, S in combos) if b is not None]
 
     prof, counts = eng.finish()
 
@@ -684,6 +753,7 @@ def main():
         cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) and stock else
                     "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024) and stock
                     else f"custom scene (scale {args.scale}, opacity {args.opacity}; not the metric's configuration)")
+        chains = getattr(eng, "chains", None)
         line = {
             "metric": "render+backward frames/sec at 512^2, 100k Gaussians", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -694,17 +764,25 @@ def main():
                                    "forward+backward through render() with a fixed dL/dpixel",
                        "frames_per_step_per_gpu": frames_per_step,
                        "rounds_per_step": 1 if exchanging else rounds,
-                       "frames_in_flight_per_gpu": 1 if exchanging else K_best,
+                       "frames_in_flight_per_gpu": 1 if exchanging else (chains[0] * chains[1] if chains else K_best),
+                       "launch_chains_in_flight": None if not chains else {"chains": chains[1], "views_per_chain": chains[0]},
                        "in_flight_calibration_frames_per_s": eng.calibration,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
                        "parallelism": (f"dp{world}: one view per GPU and step, then ONE flat-grad RCCL all-reduce(AVG), then the next "
                                        "step (BASELINE configs[3]); the amortised mode is in dp.modes" if exchanging else
-                                       f"dp1 ({rounds} round(s) of {K_best} view(s) in flight per step, each view on its own stream)"),
+                                       (f"dp1 ({rounds} round(s) per step of {chains[1]} launch chains in flight, {chains[0]} views per chain "
+                                        "(fr_forward_batch / fr_backward_batch), a stream and a graph per chain)" if chains else
+                                        f"dp1 ({rounds} round(s) of {K_best} view(s) in flight per step, each view on its own stream)")),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            # (when `value` is the launch-chain mode) the best per-view-stream count of the calibration: a stream, a handle
+            # and a graph per view, as `value` was measured until round 3
+            "views_on_streams": (None if not chains or not eng.calibration else
+                                 {"value": max(v for k, v in eng.calibration.items() if k.isdigit()), "unit": "frames/s",
+                                  "views_in_flight": K_best, "measured": "40-step calibration run"}),
             # the same frames with K views per launch chain on ONE stream (fr_forward_batch / fr_backward_batch); `value`
             # above is the stream mode (a stream, a handle and a graph per view)
             "batched_views": batched,
