@@ -64,6 +64,9 @@ struct GeomView {
     float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
     float* cov3D;           // [P*6]
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
+    float* dcolor_ddir;     // [P*9] d(SH colour)/d(view direction): (dR,dG,dB)/dx, /dy, /dz — computed by the forward, which has
+                            // the 48 coefficients in LDS anyway, so that the backward reads 36 bytes per Gaussian instead
+                            // of its 192-byte SH row (the largest array of the frame) a second time
     float* accum;           // [P*kAccumStride] gradient accumulators of the blend backward.  NOT part of the geometry
                             // buffer: they belong to the handle (fr_handle_impl::accum), are all zero between
                             // backward passes (k_preprocess_bwd zeroes each row after reading it) and so cost the
@@ -77,6 +80,7 @@ struct GeomView {
         g.conic_opacity = carve<float4>(p, P);
         g.cov3D = carve<float>(p, P * 6);
         g.clamped = carve<uint8_t>(p, P);
+        g.dcolor_ddir = carve<float>(p, P * 9);
         g.accum = nullptr;
         g.block_ref_tiles = carve<uint32_t>(p, (P + kPreWG - 1) / kPreWG + 1);
         return g;

@@ -66,6 +66,38 @@ __device__ __forceinline__ float sh_channel(const float* sh, int c, int deg, flo
     return result + 0.5f;
 }
 
+// d(colour of channel c) / d(direction): the expressions of the reference's SH backward (backward.cu:44-133), evaluated
+// HERE, in the forward, where the coefficients are staged in LDS anyway (GeomView::dcolor_ddir).
+__device__ __forceinline__ void sh_dchannel_ddir(const float* sh, int c, int deg, float x, float y, float z, float& ddx, float& ddy,
+                                                 float& ddz)
+{
+#define SH(k) sh[(k) * 3 + c]
+    ddx = ddy = ddz = 0.f;
+    if (deg > 0) {
+        ddx = -kSH_C1 * SH(3);
+        ddy = -kSH_C1 * SH(1);
+        ddz = kSH_C1 * SH(2);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            ddx += kSH_C2[0] * y * SH(4) + kSH_C2[2] * 2.f * -x * SH(6) + kSH_C2[3] * z * SH(7) + kSH_C2[4] * 2.f * x * SH(8);
+            ddy += kSH_C2[0] * x * SH(4) + kSH_C2[1] * z * SH(5) + kSH_C2[2] * 2.f * -y * SH(6) + kSH_C2[4] * 2.f * -y * SH(8);
+            ddz += kSH_C2[1] * y * SH(5) + kSH_C2[2] * 2.f * 2.f * z * SH(6) + kSH_C2[3] * x * SH(7);
+            if (deg > 2) {
+                ddx += (kSH_C3[0] * SH(9) * 3.f * 2.f * xy + kSH_C3[1] * SH(10) * yz + kSH_C3[2] * SH(11) * -2.f * xy +
+                        kSH_C3[3] * SH(12) * -3.f * 2.f * xz + kSH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                        kSH_C3[5] * SH(14) * 2.f * xz + kSH_C3[6] * SH(15) * 3.f * (xx - yy));
+                ddy += (kSH_C3[0] * SH(9) * 3.f * (xx - yy) + kSH_C3[1] * SH(10) * xz + kSH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                        kSH_C3[3] * SH(12) * -3.f * 2.f * yz + kSH_C3[4] * SH(13) * -2.f * xy + kSH_C3[5] * SH(14) * -2.f * yz +
+                        kSH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                ddz += (kSH_C3[1] * SH(10) * xy + kSH_C3[2] * SH(11) * 4.f * 2.f * yz + kSH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                        kSH_C3[4] * SH(13) * 4.f * 2.f * xz + kSH_C3[5] * SH(14) * (xx - yy));
+            }
+        }
+    }
+#undef SH
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // One thread per Gaussian.  reference: preprocessCUDA, forward.cu:155-256.
@@ -284,12 +316,16 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
                 const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                 dx = dx / len, dy = dy / len, dz = dz / len;
                 const float* sh = my_sh;
+                float dd[9];
                 for (int c = 0; c < 3; c++) {
                     const float v = sh_channel(sh, c, a.D, dx, dy, dz);
                     if (v < 0) clamp_bits |= (uint8_t)(1u << c);
                     col[c] = fmaxf(v, 0.0f);
                     raw_sum += v;
+                    sh_dchannel_ddir(sh, c, a.D, dx, dy, dz, dd[c], dd[3 + c], dd[6 + c]);
                 }
+                float* o = a.g.dcolor_ddir + (size_t)idx * 9;
+                for (int k = 0; k < 9; k++) o[k] = dd[k];
             }
 
             const float opacity = a.raw ? act_sigmoid(in_opacity) : in_opacity;

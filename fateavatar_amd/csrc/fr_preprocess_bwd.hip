@@ -51,8 +51,8 @@ __device__ __forceinline__ void store3(float* p, size_t i, float a, float b, flo
     p[3 * i] = a, p[3 * i + 1] = b, p[3 * i + 2] = c;
 }
 
-// Everything for ONE Gaussian.  `row` (LDS, may be null) holds this Gaussian's SH coefficients on entry and
-// receives its dL_dsh row in place (the kernel stages both through LDS for coalesced HBM access).
+// Everything for ONE Gaussian.  `row` (LDS, may be null) receives this Gaussian's dL_dsh row (the kernel writes the rows
+// of a wave through LDS for coalesced HBM access).
 __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const CameraRegs& cam, const int radius,
                                                    const int idx, float* row)
 {
@@ -207,34 +207,27 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         const float dox = mean.x - cam.campos[0], doy = mean.y - cam.campos[1], doz = mean.z - cam.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        // `row` is read (SH) and overwritten (dL_dsh) in place: each channel pass loads its coefficients into
-        // registers before it writes anything
-        const float* sh_src = row ? row : a.shs + i * Mc * 3;
+        // (the derivative of the colour with respect to the direction comes from the forward, GeomView::dcolor_ddir: this
+        // kernel does not read the SH coefficients at all; `row`, if staged, only collects the dL_dsh row)
         float* dsh = row ? row : (a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr);
         const bool dsh_adds = !row && adds(G_SH);   // (a staged row is added to the array by unstage_rows)
         const uint8_t cl = a.g.clamped[idx];
         float dRGB[3];
         for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1) ? 0 : 1);
-        float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+        const float* dd = a.g.dcolor_ddir + i * 9;
+        const float dRGBdx[3] = {dd[0], dd[1], dd[2]}, dRGBdy[3] = {dd[3], dd[4], dd[5]}, dRGBdz[3] = {dd[6], dd[7], dd[8]};
         const int deg = a.D;
         const int used = (deg + 1) * (deg + 1);
-#define SH(k, c) shc[(k)]
 #define DSH(k, c, v_)                    \
     do {                                 \
         if (dsh) put(dsh + (k) * 3 + (c), (v_), dsh_adds); \
     } while (0)
         for (int c = 0; c < 3; c++) {
-            float shc[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) shc[k] = (k < used) ? sh_src[k * 3 + c] : 0.f;
             DSH(0, c, bSH_C0 * dRGB[c]);
             if (deg > 0) {
                 DSH(1, c, (-bSH_C1 * y) * dRGB[c]);
                 DSH(2, c, (bSH_C1 * z) * dRGB[c]);
                 DSH(3, c, (-bSH_C1 * x) * dRGB[c]);
-                dRGBdx[c] = -bSH_C1 * SH(3, c);
-                dRGBdy[c] = -bSH_C1 * SH(1, c);
-                dRGBdz[c] = bSH_C1 * SH(2, c);
                 if (deg > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z;
                     const float xy = x * y, yz = y * z, xz = x * z;
@@ -243,9 +236,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
                     DSH(6, c, (bSH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c]);
                     DSH(7, c, (bSH_C2[3] * xz) * dRGB[c]);
                     DSH(8, c, (bSH_C2[4] * (xx - yy)) * dRGB[c]);
-                    dRGBdx[c] += bSH_C2[0] * y * SH(4, c) + bSH_C2[2] * 2.f * -x * SH(6, c) + bSH_C2[3] * z * SH(7, c) + bSH_C2[4] * 2.f * x * SH(8, c);
-                    dRGBdy[c] += bSH_C2[0] * x * SH(4, c) + bSH_C2[1] * z * SH(5, c) + bSH_C2[2] * 2.f * -y * SH(6, c) + bSH_C2[4] * 2.f * -y * SH(8, c);
-                    dRGBdz[c] += bSH_C2[1] * y * SH(5, c) + bSH_C2[2] * 2.f * 2.f * z * SH(6, c) + bSH_C2[3] * x * SH(7, c);
                     if (deg > 2) {
                         DSH(9, c, (bSH_C3[0] * y * (3.f * xx - yy)) * dRGB[c]);
                         DSH(10, c, (bSH_C3[1] * xy * z) * dRGB[c]);
@@ -254,17 +244,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
                         DSH(13, c, (bSH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c]);
                         DSH(14, c, (bSH_C3[5] * z * (xx - yy)) * dRGB[c]);
                         DSH(15, c, (bSH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c]);
-                        dRGBdx[c] += (bSH_C3[0] * SH(9, c) * 3.f * 2.f * xy + bSH_C3[1] * SH(10, c) * yz +
-                                      bSH_C3[2] * SH(11, c) * -2.f * xy + bSH_C3[3] * SH(12, c) * -3.f * 2.f * xz +
-                                      bSH_C3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy) +
-                                      bSH_C3[5] * SH(14, c) * 2.f * xz + bSH_C3[6] * SH(15, c) * 3.f * (xx - yy));
-                        dRGBdy[c] += (bSH_C3[0] * SH(9, c) * 3.f * (xx - yy) + bSH_C3[1] * SH(10, c) * xz +
-                                      bSH_C3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) +
-                                      bSH_C3[3] * SH(12, c) * -3.f * 2.f * yz + bSH_C3[4] * SH(13, c) * -2.f * xy +
-                                      bSH_C3[5] * SH(14, c) * -2.f * yz + bSH_C3[6] * SH(15, c) * -3.f * 2.f * xy);
-                        dRGBdz[c] += (bSH_C3[1] * SH(10, c) * xy + bSH_C3[2] * SH(11, c) * 4.f * 2.f * yz +
-                                      bSH_C3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) +
-                                      bSH_C3[4] * SH(13, c) * 4.f * 2.f * xz + bSH_C3[5] * SH(14, c) * (xx - yy));
                     }
                 }
             }
@@ -273,7 +252,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         // zero-initialised rows untouched)
         if (dsh && !dsh_adds)
             for (int k = used; k < Mc; k++) dsh[k * 3] = 0.f, dsh[k * 3 + 1] = 0.f, dsh[k * 3 + 2] = 0.f;
-#undef SH
 #undef DSH
         const float ddx = dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2];
         const float ddy = dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2];
@@ -455,8 +433,6 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a)
     // camera and radius are requested before the SH block is staged: one round trip for all of them
     const CameraRegs cam = load_camera(a.view, a.proj, a.campos, lane);
     const int radius = idx < a.P ? a.radii[idx] : 0;
-    if (staged && rows > 0) stage_rows(w_rows, stride, a.shs + (size_t)wave_first * M3, rows, M3, lane);
-    __syncthreads();
     if (idx < a.P) preprocess_bwd_one(a, cam, radius, idx, staged ? w_rows + lane * stride : nullptr);
     __syncthreads();
     if (staged && rows > 0) unstage_rows(a.out.dL_dsh + (size_t)wave_first * M3, w_rows, stride, rows, M3, lane, ((a.acc >> G_SH) & 1u) != 0u);
