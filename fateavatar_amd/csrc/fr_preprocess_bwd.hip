@@ -328,43 +328,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
     }
 }
 
-// Coalesced LDS staging of a wave's [64][row_len] block (see fr_preprocess.hip) and its inverse.
-__device__ __forceinline__ void stage_rows(float* dst, int stride, const float* __restrict__ src, int rows, int row_len, int lane)
-{
-    const int total = rows * row_len;
-    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)row_len - 1u) / (unsigned)row_len);
-    // kStageBatch 16-byte loads per lane are issued before the first one is consumed: the copy costs one or two
-    // memory round trips per wave, not one per 1 KiB
-    constexpr int kStageBatch = 6;
-    for (int base = lane * 4; base < total; base += 64 * 4 * kStageBatch) {
-        float4 q[kStageBatch];
-#pragma unroll
-        for (int u = 0; u < kStageBatch; u++) {
-            const int c = base + u * 64 * 4;
-            if (c + 3 < total) {
-                q[u] = *reinterpret_cast<const float4*>(src + c);
-            } else {
-                q[u].x = (c < total) ? src[c] : 0.f;
-                q[u].y = (c + 1 < total) ? src[c + 1] : 0.f;
-                q[u].z = (c + 2 < total) ? src[c + 2] : 0.f;
-                q[u].w = 0.f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kStageBatch; u++) {
-            const int c = base + u * 64 * 4;
-            const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int e = c + k;
-                if (e < total) {
-                    const int r = (int)__umulhi((unsigned)e, magic);  // e / row_len (exact: e < 2^16)
-                    dst[r * stride + (e - r * row_len)] = v[k];
-                }
-            }
-        }
-    }
-}
+// A wave's [64][row_len] block of dL_dsh rows goes from LDS to HBM in coalesced 16-byte stores (the inverse of the
+// forward's staging, fr_preprocess.hip).
 template <bool ADD>
 __device__ __forceinline__ void unstage_rows_t(float* __restrict__ dst, const float* src, int stride, int rows, int row_len, int lane)
 {
