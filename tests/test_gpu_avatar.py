@@ -308,9 +308,10 @@ def test_batch_step_is_the_mean_gradient_step_of_its_frames(gpu_device):
     torch.cuda.synchronize()
     stats_ref = (ref.xyz_gradient_accum.clone(), ref.denom.clone())
 
-    for use_graph in (False, True):
+    for use_graph, chain in ((False, False), (True, False), (False, True), (True, True)):
+        # chain: the K frames through ONE launch chain on one stream (render_batch) instead of K lanes on K streams
         pc = S["make"]()
-        st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=use_graph)
+        st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=use_graph, chain=chain)
         losses = []
         for it in range(steps):
             fs = [(it * K + k) % n_frames for k in range(K)]
@@ -318,11 +319,11 @@ def test_batch_step_is_the_mean_gradient_step_of_its_frames(gpu_device):
             losses.append([float(x) for x in out])
         torch.cuda.synchronize()
         st.check()
-        assert (st.lanes[0].graph is not None) == use_graph and st.overflows == 0
+        assert ((st._chain_graph if chain else st.lanes[0].graph) is not None) == use_graph and st.overflows == 0
         assert st.adam.step_count == steps
-        assert np.allclose(losses, losses_ref, rtol=2e-3), (use_graph, losses[-1], losses_ref[-1])
-        assert float((pc.flat - pc_r.flat).abs().max()) < 5e-3, use_graph
-        assert util_rel_l2(pc.flat, pc_r.flat) < 1e-3, use_graph
+        assert np.allclose(losses, losses_ref, rtol=2e-3), (use_graph, chain, losses[-1], losses_ref[-1])
+        assert float((pc.flat - pc_r.flat).abs().max()) < 5e-3, (use_graph, chain)
+        assert util_rel_l2(pc.flat, pc_r.flat) < 1e-3, (use_graph, chain)
         acc, den = st.reduce_densification_stats()
         assert torch.equal(den, stats_ref[1]) and float(den.max()) == steps * K
         assert util_rel_l2(acc, stats_ref[0]) < 1e-3
@@ -333,7 +334,8 @@ def util_rel_l2(a, b):
     return float(torch.linalg.norm((a - b).double()) / torch.linalg.norm(b.double()))
 
 
-def test_batch_step_survives_the_maintenance_schedule(gpu_device):
+@pytest.mark.parametrize("chain", [True, False])
+def test_batch_step_survives_the_maintenance_schedule(gpu_device, chain):
     """AvatarBatchStep under densify / prune / opacity reset / checkpoint: the lanes' densification statistics are folded
     together before anything reads them (every frame of every lane counts), the lanes are rebuilt over the re-bound
     point set (fresh graphs, same shared parameter storage), the opacity reset keeps the captured lanes, and a step
@@ -346,7 +348,10 @@ def test_batch_step_survives_the_maintenance_schedule(gpu_device):
     bg = torch.ones(3, device=dev)
     gts = _targets(S, dev, bg)
     pc = S["make"]()
-    st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K)
+    st = AvatarBatchStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, chain=chain)
+
+    def graphs():   # the captured step: one graph for the launch chain, or one per lane
+        return [st._chain_graph] if chain else [L.graph for L in st.lanes]
 
     def run(n, start=0):
         out = None
@@ -357,17 +362,17 @@ def test_batch_step_survives_the_maintenance_schedule(gpu_device):
         return [float(x) for x in out]
 
     run(6)
-    assert st.lanes[0].graph is not None and st.lanes[1].graph is not None
+    assert all(g is not None for g in graphs())
     assert st.lanes[1].pc.flat.data_ptr() == pc.flat.data_ptr() and st.lanes[1].pc.flat_grad.data_ptr() != pc.flat_grad.data_ptr()
     acc, den = st.reduce_densification_stats()              # folds the lanes
     assert float(den.max()) == 6 * K and float(st.lanes[1].denom.abs().max()) == 0.0
     rows0 = pc.P
     did = st.maintain(3000, dict(increase_num=200, prune_interval=10 ** 9))
     assert did == {"densified": 200} and pc.P == rows0 + 200
-    assert all(L.graph is None and L.pc.P == pc.P and L.denom.shape == (pc.P, 1) for L in st.lanes)
+    assert all(g is None for g in graphs()) and all(L.pc.P == pc.P and L.denom.shape == (pc.P, 1) for L in st.lanes)
     assert st.lanes[1].pc.flat.data_ptr() == pc.flat.data_ptr()
     l = run(6, 6)
-    assert all(np.isfinite(l)) and st.lanes[1].graph is not None
+    assert all(np.isfinite(l)) and all(g is not None for g in graphs())
     with torch.no_grad():
         pc._opacity[::5] = -8.0
     keep = ~(torch.sigmoid(pc._opacity) < 0.005).reshape(-1)
@@ -376,9 +381,9 @@ def test_batch_step_survives_the_maintenance_schedule(gpu_device):
     assert did["pruned"] == int((~keep).sum()) > 0 and pc.P == int(keep.sum())
     assert torch.equal(st.denom, den_before[keep]) and float(st.denom.max()) == 6 * K
     run(4, 12)
-    graphs = [L.graph for L in st.lanes]
+    before = graphs()
     did = st.maintain(60000, dict(densify_interval=10 ** 9, prune_interval=10 ** 9))
-    assert did == {"opacity_reset": True} and [L.graph for L in st.lanes] == graphs
+    assert did == {"opacity_reset": True} and graphs() == before
     assert float(torch.sigmoid(st.lanes[1].pc._opacity.detach()).max()) <= 0.01 + 1e-6      # the lanes share the storage
     l = run(3, 16)
     st.check()
@@ -386,7 +391,7 @@ def test_batch_step_survives_the_maintenance_schedule(gpu_device):
     # checkpoint round trip: a fresh step loaded from the state continues with the same losses
     sd = st.state_dict()
     pc2 = S["make"]()
-    st2 = AvatarBatchStep(pc2, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=False)
+    st2 = AvatarBatchStep(pc2, S["faces"], S["canon"], S["cams"][0].clone(), bg, views_per_step=K, use_graph=False, chain=chain)
     st2.load_state_dict(sd)
     assert pc2.P == pc.P and st2.lanes[1].pc.flat.data_ptr() == pc2.flat.data_ptr()
     fs = [0, 1]

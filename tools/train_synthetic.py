@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", dest="chain", action="store_false",
+                    help="--views-per-step K: K lanes on K streams (a graph per frame) instead of ONE launch chain on one "
+                         "stream (render_batch: the default)")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="--fateavatar: frames per optimisation step, rendered in flight together (the reference's batch)")
     ap.add_argument("--fateavatar", action="store_true",
@@ -120,7 +123,7 @@ def main_fateavatar(a, rank, world, dev):
         st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=not a.no_graph)
     else:   # the reference's batch of K frames per step (model/fateavatar.py:251-276), in flight together
         from fateavatar_amd.avatar import AvatarBatchStep
-        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=not a.no_graph)
+        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=not a.no_graph, chain=a.chain)
 
     def one_step(it, keep=True):
         if K == 1:
@@ -154,7 +157,7 @@ def main_fateavatar(a, rank, world, dev):
         print(json.dumps({"host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4),
                           "metric": "FateAvatar optimisation steps/s (bind + render + L1 + backward + stats + Adam)",
                           "value": round(a.steps / dt, 1), "frames_per_s": round(world * K * a.steps / dt, 1), "n_gpus": world,
-                          "views_per_step": K,
+                          "views_per_step": K, "launch_chain": bool(a.chain) if K > 1 else None,
                           "ms_per_step": round(dt / a.steps * 1e3, 4), "P": a.P, "res": a.res, "frames": n_frames, "sh_degree": 0,
                           "graph": not a.no_graph, "overflows": st.overflows,
                           "loss_first": round(float(np.mean(l[:4])), 6), "loss_last": round(float(np.mean(l[-4:])), 6)}))
