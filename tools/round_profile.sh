@@ -11,6 +11,7 @@ python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --cpu-seconds 0 > $O/$
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 > $O/${tag}_train_step_fateavatar_batch4.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 --lanes > $O/${tag}_train_step_fateavatar_batch4_lanes.json 2>> $O/${tag}_bench.err
 FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${tag}_bench_2ranks_gloo_1gpu.json 2>> $O/${tag}_bench.err
 # the N > 1 step on a one-rank RCCL group: what the exchange machinery costs apart from the wire
 python $R/bench.py --exchange-at-1 --cpu-seconds 0 2>> $O/${tag}_bench.err | grep '^{' > $O/${tag}_bench_exchange_at_1.json
