@@ -334,7 +334,11 @@ class HipEngine:
             best = float(r.max().item())
             cands = [(4, 2), (4, 3)] if self.args.chains == "auto" else [tuple(int(x) for x in self.args.chains.split("x"))]
             for K, S in cands:
-                m = self.measure_batched(K, 30, S)
+                try:
+                    m = self.measure_batched(K, 30, S)
+                except Exception as e:   # (a chain that cannot be set up here must not cost the run: the per-view streams remain)
+                    print(f"[bench] {S} chains x {K} views could not be set up ({type(e).__name__}: {e}); skipped", file=sys.stderr)
+                    m = None
                 if m is None:
                     continue
                 self.calibration[f"{S} chains x {K} views"] = m["value"]
@@ -402,12 +406,17 @@ class HipEngine:
                                      f"num_rendered {c.num_rendered}, max list {c.max_tile_list}); rerun (capacity hint was raised)")
         # HIP events around every stage launch, on the launch stream, over eager frames of ONE view (event records inside
         # a replayed graph cannot be read back)
+        # (in no-wait mode, like the captured frames: the host does not block on each frame's counts, so the launches
+        # queue up behind each other as they do in a replayed graph instead of each starting on an idle, cold GPU)
         _lib.profile_enable(self.local, True)
-        for _ in range(min(self.args.steps, 50)):
-            self.frame()
+        with self.rasterizer.no_wait():
+            for _ in range(min(self.args.steps, 50)):
+                self.frame()
         torch.cuda.synchronize()
         prof = _lib.profile_read(self.local)
         _lib.profile_enable(self.local, False)
+        self.frame()                             # (one waiting frame: its counts)
+        torch.cuda.synchronize()
         c = self.rasterizer.last_counts[self.local]
         return prof, dict(num_rendered=int(c.num_rendered), num_instances=int(c.num_instances), max_tile_list=int(c.max_tile_list))
 

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 bad = 0
+kinds = {}
 for it in range(n):
     big = len(sys.argv) > 3
     P = int(rng.integers(1, 60000 if big else 6000))
@@ -29,10 +30,14 @@ for it in range(n):
         h = util.HipFrame(s, dev)
         _check_forward(o, h, name)
         dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
-        _check_backward(o, h, dpix, name)
+        # (the share of rows a threshold flip may exempt from the tight test: as tests/test_gpu_configs.py bounds it —
+        # one flipped pixel under image-sized splats shares its list with a large part of the scene)
+        _check_backward(o, h, dpix, name, max_skip_frac=0.6 if shi >= 0.05 else 0.08)   # (asserted after the gradient checks)
         print("ok  ", name, "inst", h.counts.num_instances, "maxlist", h.counts.max_tile_list, flush=True)
     except Exception as e:
         bad += 1
-        print("FAIL", name, repr(e)[:300], flush=True)
+        kind = "skipped-row bound" if "exempt too many rows" in repr(e) else "PARITY"
+        kinds[kind] = kinds.get(kind, 0) + 1
+        print("FAIL", kind, name, repr(e)[:300], flush=True)
         traceback.print_exc(limit=2)
-print("failures:", bad)
+print("failures:", bad, kinds)
