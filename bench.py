@@ -44,6 +44,8 @@ The JSON line carries
   dp           — N > 1: ranks seen, backend, RCCL version, per-rank num_rendered, both modes' frame rates, and the
                  un-overlapped all-reduce duration per payload.
 
+Diagnostics: FR_BENCH_HOST_TIME=1 prints how long the host took to enqueue a step; FR_BENCH_BATCH_X_STREAMS=1 adds more
+(views per chain, chains) shapes to `batched_views`.
 FR_BENCH_STUB=1 replaces the rasterizer by a deterministic CPU gradient generator so that the N > 1 control flow can
 be exercised without GPUs (tests/test_bench_dp.py); such a line says "data": "stub" and is not a measurement.
 """
@@ -753,8 +755,8 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
                         "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": n,
-                        "measured": "dispatch-tied HIP events around ISOLATED launches (eager frames of one view, nothing else "
-                                    "on the GPU); rocprofv3 of `bench.py --in-flight 1` agrees (profiles/)"}
+                        "measured": "dispatch-tied HIP events around ISOLATED launches (eager no-wait frames of one view, queued "
+                                    "behind each other, nothing else on the GPU); rocprofv3 of `bench.py --in-flight 1` agrees (profiles/)"}
         cpu = None
         if args.cpu_seconds > 0 and world == 1 and eng.scene is not None:
             cpu = cpu_baseline(eng.scene, args.cpu_seconds)
