@@ -183,3 +183,34 @@ def test_handle_slot_is_scoped():
     except KeyError:
         pass
     assert rasterizer._slot == 0
+
+
+def test_backward_work_list_stripe_assignment_is_exact():
+    """The blend backward's work list (fateavatar_amd/csrc/fr_blend.hip, k_unit_blend_chained: "Which stripe?") deals the
+    units out to 64 stripes so that the eight stripes whose slots run on XCD x hold a CONTIGUOUS run of units, and fills
+    every stripe exactly: stripe j owns slots j, j + 64, ... < nu, and the two-ended cursors only work if exactly that
+    many units are sent to it.  The arithmetic, restated here, must be a perfect deal for every unit count."""
+    def stripe_of(u, nu):
+        q, rem = divmod(nu, 64)
+        x, first = 0, 0
+        while x < 7:
+            lo4, hi4 = 4 * x, 32 + 4 * x
+            n_x = 8 * q + (min(rem - lo4, 4) if rem > lo4 else 0) + (min(rem - hi4, 4) if rem > hi4 else 0)
+            if u < first + n_x:
+                break
+            first += n_x
+            x += 1
+        t = (u - first) & 7
+        return (4 * x + t) if t < 4 else (32 + 4 * x + (t - 4)), x
+
+    for nu in list(range(1, 700)) + [1023, 1024, 1025, 3914, 3916, 4096, 4097, 16383, 50001]:
+        counts = [0] * 64
+        last_x = 0
+        for u in range(nu):
+            j, x = stripe_of(u, nu)
+            assert 0 <= j < 64 and (j // 4) % 8 == x          # the stripe's slots run on XCD x (slot w: XCD (w / 4) % 8)
+            assert x >= last_x                                 # contiguous runs: the XCD never goes back
+            last_x = x
+            counts[j] += 1
+        want = [(nu - j + 63) // 64 for j in range(64)]        # slots j, j + 64, ... below nu
+        assert counts == want, (nu, [(j, counts[j], want[j]) for j in range(64) if counts[j] != want[j]][:4])
