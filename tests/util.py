@@ -147,3 +147,16 @@ def unexplained_outliers(o, got_color, got_T, rtol=1e-4, atol=1e-5, limit=2000):
         if not (m <= 1.0):
             out.append((x, y, m))
     return int(bad.sum()), out
+
+
+def assert_same_trajectory(a, b, what="", tight=5e-3, lr_max=0.05):
+    """Two optimisation runs that differ only in the summation order of float atomics (eager against graph replay, lanes
+    against a launch chain ...).  Adam turns a gradient that is pure rounding noise into a full step of either sign
+    (m / sqrt(v) is +-1 whatever the size), so a handful of parameters whose true gradient is zero may end up a learning
+    rate apart; everything else must agree closely.  Held to: rel-L2 <= 1e-3 of the whole parameter vector, 99.99 % of
+    the entries within `tight`, and no entry further apart than two steps of the largest learning rate."""
+    import torch
+    d = (a - b).abs()
+    rl = float(torch.linalg.norm((a - b).double()) / torch.linalg.norm(b.double()))
+    frac = float((d < tight).double().mean())
+    assert rl <= 1e-3 and frac >= 0.9999 and float(d.max()) <= 2 * lr_max, (what, rl, frac, float(d.max()))
