@@ -194,27 +194,25 @@ __device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, fl
     const bool ellipse = a2 < 0.f;
     const float inv2a = __builtin_amdgcn_rcpf(2.f * a2);
     uint32_t m[2] = {0u, 0u};
+    // (branch-free, and v_sqrt_f32 as it comes — one ulp, against a slack of 1e-3 pixels: the correctly rounded square
+    // root the compiler emits for sqrtf() is eighteen instructions, and eight divergent regions per record cost more
+    // than the arithmetic they skip)
 #pragma unroll
     for (int r = 0; r < kTile; r++) {
         const float dy = y0 - (tile_y0 + (float)r);
         const float bb = b2 * dy;
         const float cc = c2 * dy * dy - thr;
         const float disc = bb * bb - 4.f * a2 * cc;
+        const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
+        // a' < 0: inv2a < 0, so (-bb + sq) * inv2a is the SMALLER root of dx = x0 - px
+        const float dx_lo = (-bb + sq) * inv2a, dx_hi = (-bb - sq) * inv2a;
+        const float lo = ceilf((x0 - dx_hi) - tile_x0 - 1e-3f), hi = floorf((x0 - dx_lo) - tile_x0 + 1e-3f);
+        const int il = (int)fminf(fmaxf(lo, 0.f), 8.f), ih = (int)fminf(fmaxf(hi, -1.f), 7.f);
+        const uint32_t span = il <= ih ? ((2u << ih) - 1u) & ~((1u << il) - 1u) : 0u;
+        // the whole row unless this plainly is an ellipse with a real (or no) intersection: NaNs anywhere select it
         uint32_t row = 0xFFu;
-        if (ellipse) {
-            if (disc >= 0.f) {
-                const float sq = __builtin_sqrtf(disc);
-                // a' < 0: inv2a < 0, so (-bb + sq) * inv2a is the SMALLER root of dx = x0 - px
-                const float dx_lo = (-bb + sq) * inv2a, dx_hi = (-bb - sq) * inv2a;
-                const float lo = ceilf((x0 - dx_hi) - tile_x0 - 1e-3f), hi = floorf((x0 - dx_lo) - tile_x0 + 1e-3f);
-                if (lo == lo && hi == hi) {   // not NaN
-                    const int il = (int)fminf(fmaxf(lo, 0.f), 8.f), ih = (int)fminf(fmaxf(hi, -1.f), 7.f);
-                    row = il <= ih ? ((2u << ih) - 1u) & ~((1u << il) - 1u) : 0u;
-                }
-            } else if (disc < 0.f) {
-                row = 0u;
-            }
-        }
+        row = (ellipse && disc >= 0.f && lo == lo && hi == hi) ? span : row;
+        row = (ellipse && disc < 0.f) ? 0u : row;
         m[r >> 2] |= row << (8 * (r & 3));
     }
     return make_uint2(m[0], m[1]);
@@ -1140,6 +1138,19 @@ __device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __res
     return v;
 }
 
+#ifdef FR_FWD_TRACE   // development build (tools/diag/fwd_trace.py): per-unit time stamps of the forward blend's phases
+__device__ unsigned long long g_fwd_trace[16384 * 16];
+extern "C" int fr_debug_read_fwd_trace(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_trace), bytes < sizeof(g_fwd_trace) ? bytes : sizeof(g_fwd_trace));
+}
+#define FW_STAMP(K) do { if (lane == 0 && u < 16384u) g_fwd_trace[(size_t)u * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#define FW_STAMPV(K, V) do { if (lane == 0 && u < 16384u) g_fwd_trace[(size_t)u * 16 + (K)] = (unsigned long long)(V); } while (0)
+#else
+#define FW_STAMP(K) do { } while (0)
+#define FW_STAMPV(K, V) do { } while (0)
+#endif
+
 struct ChainArgs {
     DeviceCounts* counts;
     const uint4* unit_tile;
@@ -1188,9 +1199,15 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     // flight.  Measured, not kept.)
     const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
     if (u >= nu_all) return;
+    FW_STAMP(0);
+    FW_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     const TransposeConsts tc = transpose_consts(lane);
     const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
     RecRegs rr = fetch_record(recs, (size_t)ui.start, ui.base + (uint32_t)lane, ui.n);
+    asm volatile("" ::"v"(rr.q0.x), "v"(rr.q1.x), "v"(rr.q2.x));
+    FW_STAMP(1);   // records in registers
+    FW_STAMPV(10, ui.n);
+    FW_STAMPV(11, ui.seg);
     // lane = record here: the footprint mask of this (tile, Gaussian) instance, kept in `masks` for the backward
     uint2 fm = make_uint2(0u, 0u);
     if (ui.base + (uint32_t)lane < ui.n) {
@@ -1211,6 +1228,8 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     if (pair_hist && lane == 0)
         atomicAdd(&counts->pair_hist[npairs <= 500 ? 0 : npairs <= 1000 ? 1 : npairs <= 1500 ? 2 : npairs <= 2500 ? 3 : 4], 1u);
     const float fx = (float)ui.px, fy = (float)ui.py;
+    FW_STAMP(2);   // staged, masks, transpose
+    FW_STAMPV(9, npairs);
     // ---- local blend from T = 1, no termination test
     const WalkOut o = npairs > dense_pairs ? blend_unit_dense_local<false>(rec, ui.m, ui.inside, fx, fy, ui.base)
                                            : walk_unit_fwd<false>(rec, Bp, 1.0f, fx, fy, ui.base);
@@ -1243,6 +1262,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         w->pad[0] = npairs, w->pad[1] = o.iters;   // (development: tools/diag/bwd_trace.py, bwd_order.py)
     }
 
+    FW_STAMP(3);   // local walk done, product published
     // ---- transmittance entering the unit: the products of the units in front, in list order
     float Tin = 1.0f;
     for (uint32_t p = u - ui.seg; p < u; p += 4) {
@@ -1256,6 +1276,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
                 Tin *= chain_product(g_tseg, unit_tile, recs, p + (uint32_t)k, pv[k], chain_spins, lane, fx, fy, ui.inside);
     }
 
+    FW_STAMP(4);   // entering transmittance known
     // ---- the unit's final contribution
     const bool dead = !ui.inside || (Tin < 0.0001f);
     const bool crosses = !dead && (Tin * o.T < 0.0001f);
@@ -1286,6 +1307,8 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     __hip_atomic_store(out + 3 * kUnit, To, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(out + 4 * kUnit, __uint_as_float(lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FW_STAMP(5);   // row written
+    FW_STAMPV(12, __builtin_amdgcn_s_memrealtime());
     if (ui.base + kUnit < ui.n) {
         if (lane == 0) __hip_atomic_store(unit_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1320,7 +1343,10 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("" ::: "memory");
+    FW_STAMP(6);   // (a tile's last unit) the other units' rows are there
     gather_tile<true>(v, ui.ty * (uint32_t)v.tiles_x + ui.tx, u0, ui.seg + 1u, g_out, unit_state, W, H, bg[0], bg[1], bg[2], out_color, lane);
+    FW_STAMP(7);   // gathered
+    FW_STAMPV(12, __builtin_amdgcn_s_memrealtime());
 }
 
 __global__ void __launch_bounds__(256) k_unit_blend_chained(ChainArgs a) { unit_blend_chained_body(a); }

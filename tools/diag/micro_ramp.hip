@@ -70,6 +70,12 @@ int main()
     hipMemset(big, 0, (size_t)8192 * 8 * 1024);
     run<4, 38912, 120>(N, d_rt, d_out);
     run<4, 38912, 120, 6>(N, d_rt, d_out, big);
+    run<4, 12288, 80, 6>(N, d_rt, d_out, big);      // the forward blend's footprint: the chip two thirds full
+    run<4, 12288, 120, 6>(N, d_rt, d_out, big);
+    run<4, 38912, 80, 6>(N, d_rt, d_out, big);
+    run<4, 30000, 120, 6>(N, d_rt, d_out, big);     // 5 workgroups per CU would fit the LDS; registers allow 4
+    run<4, 38912, 120, 6>(3072, d_rt, d_out, big);  // three quarters of the slots
+    run<4, 38912, 120, 6>(2048, d_rt, d_out, big);
     run<4, 38912, 120, 6, 50>(N, d_rt, d_out, big);
     run<4, 38912, 120, 6, 100>(N, d_rt, d_out, big);
     run<4, 38912, 120, 6, 150>(N, d_rt, d_out, big);
