@@ -368,7 +368,9 @@ class AvatarBatchStep(AvatarStep):
         from .streams import concurrent_streams
         # (streams that land on one hardware queue are serialised: pick lanes' streams that overlap with each other and
         # with the caller's — fateavatar_amd/streams.py)
-        streams = concurrent_streams(self.K, self.dev, also_with=[torch.cuda.current_stream(self.dev)])
+        # (the launch chain runs on the caller's stream: no lane streams, no probing)
+        streams = ([None] * self.K if self.chain else
+                   concurrent_streams(self.K, self.dev, also_with=[torch.cuda.current_stream(self.dev)]))
         self.lanes = []
         for k in range(self.K):
             L = _Lane()
