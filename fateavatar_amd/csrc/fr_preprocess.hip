@@ -402,8 +402,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
         float2* s_ctr = reinterpret_cast<float2*>(cl + 1536);                             // [64]    512 B
         uint32_t* s_excl = reinterpret_cast<uint32_t*>(cl + 2048);                        // [64]    256 B
         uint2* s_gk = reinterpret_cast<uint2*>(cl + 2304);                                // [64]    512 B  (id, depth bits)
-        volatile uint32_t* s_gkey = reinterpret_cast<volatile uint32_t*>(cl + 2816);      // [4][64] 1024 B (lanes talk through it)
-        volatile uint32_t* s_gbase = reinterpret_cast<volatile uint32_t*>(cl + 3840);     // [4][64] 1024 B
+        // (the lanes of the wave talk through these two: plain LDS accesses, ordered by wave-level fences between the
+        // phases below — as `volatile` pointers they lost their address space and became FLAT loads and stores, whose
+        // s_waitcnt vmcnt(0) also waited for every global atomic in flight)
+        uint32_t* s_gkey = reinterpret_cast<uint32_t*>(cl + 2816);      // [4][64] 1024 B
+        uint32_t* s_gbase = reinterpret_cast<uint32_t*>(cl + 3840);     // [4][64] 1024 B
         uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 4864);                        // [4][64] 1024 B  -> kCountLdsBytes
         s_cull[lane] = cull;
         s_ctr[lane] = ctr;
@@ -462,11 +465,15 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the slots' winners are in LDS
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
                 grouped[u] = valid[u] && s_gkey[u * 64 + slot[u]] == key[u];
                 if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[u * 64 + slot[u]], 1u);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' sizes
+            __builtin_amdgcn_wave_barrier();
             uint32_t got[kCountUnroll];
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
@@ -479,6 +486,8 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++)
                 if (grouped[u] && rank[u] == 0) s_gbase[u * 64 + slot[u]] = got[u];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' bases
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < kCountUnroll; u++) {
                 if (!valid[u]) continue;
