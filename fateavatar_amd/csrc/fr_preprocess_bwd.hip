@@ -209,8 +209,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         const float x = dox / len, y = doy / len, z = doz / len;
         // (the derivative of the colour with respect to the direction comes from the forward, GeomView::dcolor_ddir: this
         // kernel does not read the SH coefficients at all; `row`, if staged, only collects the dL_dsh row)
-        float* dsh = row ? row : (a.out.dL_dsh ? a.out.dL_dsh + i * Mc * 3 : nullptr);
-        const bool dsh_adds = !row && adds(G_SH);   // (a staged row is added to the array by unstage_rows)
         const uint8_t cl = a.g.clamped[idx];
         float dRGB[3];
         for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1) ? 0 : 1);
@@ -218,41 +216,44 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         const float dRGBdx[3] = {dd[0], dd[1], dd[2]}, dRGBdy[3] = {dd[3], dd[4], dd[5]}, dRGBdz[3] = {dd[6], dd[7], dd[8]};
         const int deg = a.D;
         const int used = (deg + 1) * (deg + 1);
-#define DSH(k, c, v_)                    \
-    do {                                 \
-        if (dsh) put(dsh + (k) * 3 + (c), (v_), dsh_adds); \
-    } while (0)
-        for (int c = 0; c < 3; c++) {
-            DSH(0, c, bSH_C0 * dRGB[c]);
-            if (deg > 0) {
-                DSH(1, c, (-bSH_C1 * y) * dRGB[c]);
-                DSH(2, c, (bSH_C1 * z) * dRGB[c]);
-                DSH(3, c, (-bSH_C1 * x) * dRGB[c]);
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z;
-                    const float xy = x * y, yz = y * z, xz = x * z;
-                    DSH(4, c, (bSH_C2[0] * xy) * dRGB[c]);
-                    DSH(5, c, (bSH_C2[1] * yz) * dRGB[c]);
-                    DSH(6, c, (bSH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c]);
-                    DSH(7, c, (bSH_C2[3] * xz) * dRGB[c]);
-                    DSH(8, c, (bSH_C2[4] * (xx - yy)) * dRGB[c]);
-                    if (deg > 2) {
-                        DSH(9, c, (bSH_C3[0] * y * (3.f * xx - yy)) * dRGB[c]);
-                        DSH(10, c, (bSH_C3[1] * xy * z) * dRGB[c]);
-                        DSH(11, c, (bSH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c]);
-                        DSH(12, c, (bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c]);
-                        DSH(13, c, (bSH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c]);
-                        DSH(14, c, (bSH_C3[5] * z * (xx - yy)) * dRGB[c]);
-                        DSH(15, c, (bSH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c]);
+        // the dL_dsh row: into the wave's LDS block (coalesced to HBM afterwards) or straight into the array.  One body,
+        // called once per destination: a pointer that may be either made every access a FLAT one.
+        auto write_row = [&](float* dsh, const bool dsh_adds) {
+#define DSH(k, c, v_) put(dsh + (k) * 3 + (c), (v_), dsh_adds)
+            for (int c = 0; c < 3; c++) {
+                DSH(0, c, bSH_C0 * dRGB[c]);
+                if (deg > 0) {
+                    DSH(1, c, (-bSH_C1 * y) * dRGB[c]);
+                    DSH(2, c, (bSH_C1 * z) * dRGB[c]);
+                    DSH(3, c, (-bSH_C1 * x) * dRGB[c]);
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z;
+                        const float xy = x * y, yz = y * z, xz = x * z;
+                        DSH(4, c, (bSH_C2[0] * xy) * dRGB[c]);
+                        DSH(5, c, (bSH_C2[1] * yz) * dRGB[c]);
+                        DSH(6, c, (bSH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c]);
+                        DSH(7, c, (bSH_C2[3] * xz) * dRGB[c]);
+                        DSH(8, c, (bSH_C2[4] * (xx - yy)) * dRGB[c]);
+                        if (deg > 2) {
+                            DSH(9, c, (bSH_C3[0] * y * (3.f * xx - yy)) * dRGB[c]);
+                            DSH(10, c, (bSH_C3[1] * xy * z) * dRGB[c]);
+                            DSH(11, c, (bSH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c]);
+                            DSH(12, c, (bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c]);
+                            DSH(13, c, (bSH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c]);
+                            DSH(14, c, (bSH_C3[5] * z * (xx - yy)) * dRGB[c]);
+                            DSH(15, c, (bSH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c]);
+                        }
                     }
                 }
             }
-        }
-        // coefficients above the active degree receive no gradient (the reference leaves its
-        // zero-initialised rows untouched)
-        if (dsh && !dsh_adds)
-            for (int k = used; k < Mc; k++) dsh[k * 3] = 0.f, dsh[k * 3 + 1] = 0.f, dsh[k * 3 + 2] = 0.f;
+            // coefficients above the active degree receive no gradient (the reference leaves its
+            // zero-initialised rows untouched)
+            if (!dsh_adds)
+                for (int k = used; k < Mc; k++) dsh[k * 3] = 0.f, dsh[k * 3 + 1] = 0.f, dsh[k * 3 + 2] = 0.f;
 #undef DSH
+        };
+        if (row) write_row(row, false);                                   // (added to the array by unstage_rows)
+        else if (a.out.dL_dsh) write_row(a.out.dL_dsh + i * Mc * 3, adds(G_SH));
         const float ddx = dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2];
         const float ddy = dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2];
         const float ddz = dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2];

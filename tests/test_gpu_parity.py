@@ -53,7 +53,10 @@ def _check_forward(o, h, name):
     fT = h.final_T.cpu().numpy()
     fc = util.frac_close(col, o.color, 1e-4, 1e-5)
     ft = util.frac_close(fT, o.final_T, 1e-4, 1e-5)
-    assert fc >= 0.9999 and ft >= 0.9999, (name, fc, ft)
+    # (99.99 % of the values — but a single threshold flip must not fail an image of a few hundred pixels: one value
+    # per colour plane may always be out; that it IS a flip is checked next)
+    n_px = fT.size
+    assert (fc >= 0.9999 or round((1.0 - fc) * col.size) <= 3) and (ft >= 0.9999 or round((1.0 - ft) * n_px) <= 1), (name, fc, ft)
     assert np.isfinite(col).all()
     # every pixel outside the tolerance must be EXPLAINED: some splat of its list sits on one of the reference's
     # three thresholds (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) within fp32 rounding (util.explain_pixel)
