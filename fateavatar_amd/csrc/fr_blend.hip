@@ -497,7 +497,8 @@ __global__ void __launch_bounds__(256) k_tile_sort_big_batch(BatchOf<BigSortArgs
 // wave-uniform addresses (LDS broadcast), four at a time so that the four exp/alpha evaluations
 // are independent instruction streams and only the short T / colour recurrence is serial.
 constexpr int kBatch = 64;
-constexpr uint32_t kUnitGrid = 2048;  // workgroups (of 4 waves) of the unit kernels: grid-stride over the unit count
+constexpr uint32_t kUnitGrid = 8192;  // most workgroups (of 4 waves) of the blend backward, which strides over the work list beyond that
+                                      // (config 5, ~30 k units: 8192 workgroups 70.6 us, 2048: 73.4, 1024: 75.4 — the dispatcher balances better than the stride)
 constexpr int kGroup = 4;
 
 // log2 of the Gaussian falloff of one (pixel, record) pair from the record's pre-scaled conic (write_record):
@@ -976,7 +977,9 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
             for (int k = R - 1; k >= 0; k--) {
                 if ((uint32_t)k < nu) {
                     const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // (dead on entry: T may have underflowed)
-                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    // (the tile's LAST unit has nothing behind it and leaves with final_T: the backward builds that state itself)
+                    if ((uint32_t)k + 1u < nu)
+                        unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
                     Sr += cr[k], Sg += cg[k], Sb += cb[k];
                 }
             }
@@ -1000,7 +1003,8 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
             for (int k = R - 1; k >= 0; k--) {
                 if (base + (uint32_t)k < k_end) {
                     const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
-                    unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                    if (base + (uint32_t)k + 1u < nu)
+                        unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
                     Sr += cr[k], Sg += cg[k], Sb += cb[k];
                 }
             }
@@ -1287,6 +1291,19 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         const WalkOut x = walk_unit_fwd<true>(rec, crosses ? Bp : 0ull, Tin, fx, fy, ui.base);
         if (crosses) Cr = x.Cr, Cg = x.Cg, Cb = x.Cb, To = x.T, last = x.last;
     }
+    if (unit_done && ui.seg == 0u && ui.base + kUnit >= ui.n) {
+        // the tile's ONLY unit (most tiles of BASELINE config 2): nothing to hand over, nothing to gather — the pixels are
+        // final (gather_tile with one row: 0 + C, T, last), and the backward needs no entry state for a last unit
+        if (ui.inside) {
+            const size_t pix = (size_t)ui.py * W + ui.px, HW = (size_t)H * W;
+            v.final_T[pix] = To;
+            v.n_contrib[pix] = last;
+            out_color[pix] = Cr + To * bg[0];
+            out_color[HW + pix] = Cg + To * bg[1];
+            out_color[2 * HW + pix] = Cb + To * bg[2];
+        }
+        return;
+    }
     float* out = g_out + (size_t)u * 5 * kUnit + lane;
     const uint32_t lw = last | (dead ? kDeadBit : 0u);
     if (!unit_done) {   // the gather is a launch of its own
@@ -1372,8 +1389,8 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
 
 #ifdef FR_BWD_TRACE   // development build (tools/diag/bwd_trace.sh): per-wave time stamps of the backward's phases
 __device__ unsigned long long g_bwd_trace[8192 * 16];
-#define FR_STAMP(K) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
-#define FR_STAMPV(K, V) do { if (lane == 0) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = (unsigned long long)(V); } while (0)
+#define FR_STAMP(K) do { if (lane == 0 && blockIdx.x < 2048u) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#define FR_STAMPV(K, V) do { if (lane == 0 && blockIdx.x < 2048u) g_bwd_trace[(size_t)(blockIdx.x * kWavesPerWG + wave_in_wg) * 16 + (K)] = (unsigned long long)(V); } while (0)
 __device__ unsigned int g_bwd_work[8192 * 4];   // per UNIT: phase A iterations, phase B iterations, record ranges, pairs
 __device__ unsigned char g_bwd_lens[8192 * 128];   // per unit: 64 phase-A chain lengths, 64 phase-B walk lengths
 extern "C" int fr_debug_read_bwd_lens(void* dst, size_t bytes)
@@ -1470,8 +1487,12 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         const float2 rq2 = *reinterpret_cast<const float2*>(rsrc + 2);         // (colour b, id)
         const uint2 mraw = b.masks[(size_t)start + ridx];
         const uint2 bt = b.walks[(size_t)u * kUnit + lane];   // the unit's footprint masks, pixel-major
-        const float4 st = b.unit_state[(size_t)u * kUnit + lane];
         const float Tf_raw = v.final_T[pix];
+        // entry state (colour behind the unit / T_out, T_out).  A tile's last unit has nothing behind it and leaves with
+        // final_T: the forward does not store that row (gather_tile)
+        float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool last_unit = base + (uint32_t)kUnit >= n;
+        if (!last_unit) st = b.unit_state[(size_t)u * kUnit + lane];
         const float d0 = dL_dpix[pix], d1 = dL_dpix[HW + pix], d2 = dL_dpix[2 * HW + pix];
         // (pinned: otherwise everything but n_contrib is sunk below the early exit, a second round trip)
         asm volatile("" ::"v"(last_raw), "v"(rq0.x), "v"(rq1.x), "v"(rq2.x), "v"(mraw.x), "v"(bt.x), "v"(st.x), "v"(Tf_raw), "v"(d0), "v"(d1), "v"(d2));
@@ -1515,7 +1536,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         const float fx = (float)px, fy = (float)py;
         const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
         const float tfb = -T_final * bgd;                                      // -T_final * (bg . dL_dpixel)
-        float T = lim > 0 ? st.w : 0.f;
+        float T = lim > 0 ? (last_unit ? Tf_raw : st.w) : 0.f;
         float A = lim > 0 ? (st.x * dpr + st.y * dpg) + st.z * dpb : 0.f;     // accum_rec . dL_dpixel: the recurrence is linear, one scalar is carried
         if (dense) {
 #ifdef FR_BWD_STATS
@@ -1795,6 +1816,7 @@ int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, c
         const uint32_t want = seen > 4u * kUnitGrid ? kUnitGrid : (seen + seen / 8 + kWavesPerWG - 1) / kWavesPerWG;
         unit_grid = min(kUnitGrid, max(unit_grid, want));
     }
+    if (const char* e = getenv("FR_BWD_GRID")) unit_grid = (uint32_t)strtoul(e, nullptr, 10);   // (experiments)
     BlendBwdArgs a[kMaxBatch];
     for (int k = 0; k < n; k++) {
         a[k].counts = v[k].counts, a[k].v = v[k], a[k].binning = const_cast<void*>(calls[k].binning);
