@@ -1816,7 +1816,6 @@ int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, c
         const uint32_t want = seen > 4u * kUnitGrid ? kUnitGrid : (seen + seen / 8 + kWavesPerWG - 1) / kWavesPerWG;
         unit_grid = min(kUnitGrid, max(unit_grid, want));
     }
-    if (const char* e = getenv("FR_BWD_GRID")) unit_grid = (uint32_t)strtoul(e, nullptr, 10);   // (experiments)
     BlendBwdArgs a[kMaxBatch];
     for (int k = 0; k < n; k++) {
         a[k].counts = v[k].counts, a[k].v = v[k], a[k].binning = const_cast<void*>(calls[k].binning);
