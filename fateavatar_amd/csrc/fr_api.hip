@@ -306,7 +306,7 @@ const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t fie
         case 1: return nullptr;   // (view-space depth: column 10 of field 8)
         case 2: return g.conic_opacity;
         case 3: return nullptr;   // (colours: columns 6-8 of field 8)
-        case 4: return g.cov3D;
+        case 4: return nullptr;   // (Sigma3D is not stored any more: both per-Gaussian kernels compute it)
         case 5: return nullptr;   // (the 8x8-tile rectangle is no longer stored)
         case 6: return g.clamped;
         case 7: return nullptr;   // (the gradient accumulators moved into the handle)

@@ -62,7 +62,6 @@ struct GeomView {
                             // conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour fed to the blend (SH result or
                             // colors_precomp) — ONE 48-byte gather per instance, not three
     float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
-    float* cov3D;           // [P*6]
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* dcolor_ddir;     // [P*9] d(SH colour)/d(view direction): (dR,dG,dB)/dx, /dy, /dz — computed by the forward, which has
                             // the 48 coefficients in LDS anyway, so that the backward reads 36 bytes per Gaussian instead
@@ -78,7 +77,6 @@ struct GeomView {
         GeomView g;
         g.rec_tmpl = carve<float4>(p, P * 3);
         g.conic_opacity = carve<float4>(p, P);
-        g.cov3D = carve<float>(p, P * 6);
         g.clamped = carve<uint8_t>(p, P);
         g.dcolor_ddir = carve<float>(p, P * 9);
         g.accum = nullptr;
@@ -432,6 +430,25 @@ __device__ __forceinline__ float act_exp(float x) { return expf(x); }
 __device__ __forceinline__ float act_rot_inv_norm(float r, float x, float y, float z)
 {
     return 1.0f / fmaxf(sqrtf(r * r + x * x + y * y + z * z), 1e-12f);  // torch.nn.functional.normalize, eps 1e-12
+}
+
+// Sigma3D = R S^2 R^T as its 6 upper-triangular floats (forward.cu:118-152) from the ACTIVATED scale and unit quaternion.
+// Both per-Gaussian kernels call this: the forward does not store the matrix (24 bytes per Gaussian written and read
+// back), the backward computes the same bits again from the scales and rotations it reads anyway.
+__device__ __forceinline__ void cov3d_from_scale_rot(float sc0, float sc1, float sc2, float r, float x, float y, float z,
+                                                     float scale_modifier, float (&c3)[6])
+{
+    const float s0 = scale_modifier * sc0, s1 = scale_modifier * sc1, s2 = scale_modifier * sc2;
+    // rows of the rotation matrix, each entry scaled by the scale of its COLUMN index
+    const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)), m02 = s2 * (2.f * (x * z + r * y));
+    const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)), m12 = s2 * (2.f * (y * z - r * x));
+    const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)), m22 = s2 * (1.f - 2.f * (x * x + y * y));
+    c3[0] = m00 * m00 + m01 * m01 + m02 * m02;
+    c3[1] = m10 * m00 + m11 * m01 + m12 * m02;
+    c3[2] = m20 * m00 + m21 * m01 + m22 * m02;
+    c3[3] = m10 * m10 + m11 * m11 + m12 * m12;
+    c3[4] = m20 * m10 + m21 * m11 + m22 * m12;
+    c3[5] = m20 * m20 + m21 * m21 + m22 * m22;
 }
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -203,21 +203,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
                     const float inv = act_rot_inv_norm(r, x, y, z);
                     r *= inv, x *= inv, y *= inv, z *= inv;
                 }
-                const float s0 = a.scale_modifier * sc0, s1 = a.scale_modifier * sc1, s2 = a.scale_modifier * sc2;
-                // rows of the rotation matrix, each entry scaled by the scale of its COLUMN index
-                const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)),
-                            m02 = s2 * (2.f * (x * z + r * y));
-                const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)),
-                            m12 = s2 * (2.f * (y * z - r * x));
-                const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)),
-                            m22 = s2 * (1.f - 2.f * (x * x + y * y));
-                c3[0] = m00 * m00 + m01 * m01 + m02 * m02;
-                c3[1] = m10 * m00 + m11 * m01 + m12 * m02;
-                c3[2] = m20 * m00 + m21 * m01 + m22 * m02;
-                c3[3] = m10 * m10 + m11 * m11 + m12 * m12;
-                c3[4] = m20 * m10 + m21 * m11 + m22 * m12;
-                c3[5] = m20 * m20 + m21 * m21 + m22 * m22;
-                for (int k = 0; k < 6; k++) a.g.cov3D[6 * (size_t)idx + k] = c3[k];
+                cov3d_from_scale_rot(sc0, sc1, sc2, r, x, y, z, a.scale_modifier, c3);   // (not stored: k_preprocess_bwd computes it again)
             }
 
             // ---- EWA projection to a 2D covariance (forward.cu:74-113)

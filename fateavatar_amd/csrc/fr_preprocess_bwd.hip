@@ -119,7 +119,24 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
 
     const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     const float* vm = cam.view;
-    const float* c3 = a.cov3D_precomp ? a.cov3D_precomp + 6 * i : a.g.cov3D + 6 * i;
+    // Sigma3D: the caller's, or computed again from the scales and rotations (the same function and bits as the forward)
+    float q_r = 0.f, q_x = 0.f, q_y = 0.f, q_z = 0.f, rot_inv = 1.0f;
+    float sc[3] = {0.f, 0.f, 0.f};
+    float c3[6];
+    if (a.scales) {
+        q_r = a.rotations[4 * idx], q_x = a.rotations[4 * idx + 1], q_y = a.rotations[4 * idx + 2], q_z = a.rotations[4 * idx + 3];
+        sc[0] = a.scales[3 * idx], sc[1] = a.scales[3 * idx + 1], sc[2] = a.scales[3 * idx + 2];
+        if (a.raw) {
+            sc[0] = act_exp(sc[0]), sc[1] = act_exp(sc[1]), sc[2] = act_exp(sc[2]);
+            rot_inv = act_rot_inv_norm(q_r, q_x, q_y, q_z);
+            q_r *= rot_inv, q_x *= rot_inv, q_y *= rot_inv, q_z *= rot_inv;
+        }
+    }
+    if (a.cov3D_precomp) {
+        for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * i + k];
+    } else {
+        cov3d_from_scale_rot(sc[0], sc[1], sc[2], q_r, q_x, q_y, q_z, a.scale_modifier, c3);
+    }
 
     // ---------------- conic -> Sigma2D -> Sigma3D and mean (backward.cu:144-274)
     float3 t = xform4x3(mean, vm);
@@ -270,15 +287,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
 
     // ---------------- Sigma3D -> scale, quaternion (backward.cu:278-341)
     if (a.scales) {
-        float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-              z = a.rotations[4 * idx + 3];
-        float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-        float rot_inv = 1.0f;
-        if (a.raw) {
-            sc[0] = act_exp(sc[0]), sc[1] = act_exp(sc[1]), sc[2] = act_exp(sc[2]);
-            rot_inv = act_rot_inv_norm(r, x, y, z);
-            r *= rot_inv, x *= rot_inv, y *= rot_inv, z *= rot_inv;
-        }
+        const float r = q_r, x = q_x, y = q_y, z = q_z;   // (read and activated above, for Sigma3D)
         const float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
         // Rc[c][w]: the reference's column-major R (its column c is row c of the usual rotation matrix)
         const float Rc[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},

@@ -47,8 +47,8 @@ def _check_forward(o, h, name):
     np.testing.assert_array_equal(h.geometry(2, 4)[vis], o.conic_opacity[vis])
     np.testing.assert_array_equal(h.geometry(3, 4)[vis, :3], o.rgb[vis] if o._inputs["colors_precomp"] is None
                                   else o._inputs["colors_precomp"][vis])
-    if o._inputs["cov3D_precomp"] is None:
-        np.testing.assert_array_equal(h.geometry(4, 6)[vis], o.cov3D[vis])
+    # (Sigma3D itself is no longer stored: both per-Gaussian kernels compute it with one function, and the conic above,
+    # bit-equal to the oracle's, is a function of it; the backward's copy is covered by the gradient comparisons)
     col = h.color.cpu().numpy()
     fT = h.final_T.cpu().numpy()
     fc = util.frac_close(col, o.color, 1e-4, 1e-5)
