@@ -43,6 +43,10 @@ The JSON line carries
                  bounded sample of the same frames: best thread count of a quick sweep, and one thread.
   dp           — N > 1: ranks seen, backend, RCCL version, per-rank num_rendered, both modes' frame rates, and the
                  un-overlapped all-reduce duration per payload.
+  dp_reference_at_1 — N = 1: the two N > 1 steps measured on a one-rank RCCL group (this script again, as a child
+                 process with --exchange-at-1, after the timed region): `value` at N = 1 is frames in flight with no
+                 exchange at all, `value` at N > 1 the literal configs[3] step — a scaling curve over `value` compares the
+                 two; the like-for-like first point of the N > 1 series is `dp_reference_at_1.literal.value`.
 
 Diagnostics: FR_BENCH_HOST_TIME=1 prints how long the host took to enqueue a step; FR_BENCH_BATCH_X_STREAMS=1 adds more
 (views per chain, chains) shapes to `batched_views`.
@@ -545,6 +549,26 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _dp_reference_at_1(args):
+    """`bench.py --exchange-at-1` as a child process (its own HIP context and one-rank RCCL group), after this process's timed
+    region: the literal and the amortised N > 1 steps at one rank.  None if it cannot be run."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-at-1", "--cpu-seconds", "0", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--P", str(args.P), "--res", str(args.res), "--sh-degree", str(args.sh_degree),
+           "--opacity", str(args.opacity), "--rounds", str(args.rounds)]
+    if args.scale is not None:
+        cmd += ["--scale", str(args.scale)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        m = rec["dp"]["modes"]
+        return {"what": "the N > 1 steps on a one-rank RCCL group (`bench.py --exchange-at-1`, a second process after the timed region)",
+                "literal": {k: m["literal"][k] for k in ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")},
+                "amortised": {k: m["amortised"][k] for k in ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")},
+                "allreduce_table": rec["dp"]["allreduce_table"], "rccl_version": rec["dp"]["rccl_version"]}
+    except Exception as e:   # (no RCCL, no free port, ...: the record goes without it)
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -569,6 +593,9 @@ def main():
                     help="diagnostic: run N = 1 with the N > 1 machinery (second gradient-buffer sets, per-round fold, "
                          "all-reduce on a one-rank RCCL group): what the exchange costs the rendering apart from the wire")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-dp-reference", dest="dp_reference", action="store_false", default=True,
+                    help="N = 1: do not add `dp_reference_at_1` (the N > 1 step — one view, one all-reduce on a one-rank RCCL "
+                         "group — measured by a second run of this script after the timed region)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
@@ -760,6 +787,11 @@ def main():
         cpu = None
         if args.cpu_seconds > 0 and world == 1 and eng.scene is not None:
             cpu = cpu_baseline(eng.scene, args.cpu_seconds)
+        # What `value` is on N > 1 GPUs (the literal configs[3] step) measured at ONE rank, so that a scaling curve has a
+        # like-for-like first point: `value` at N = 1 is frames in flight without any exchange, a different mode.
+        dp_ref = None
+        if not STUB and world == 1 and not exchanging and args.dp_reference and args.graph:
+            dp_ref = _dp_reference_at_1(args)
         stock = args.scale is None and args.opacity == 0.1
         cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) and stock else
                     "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024) and stock
@@ -789,6 +821,7 @@ def main():
                        "max_tile_list": counts["max_tile_list"]},
             "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            "dp_reference_at_1": dp_ref,
             # (when `value` is the launch-chain mode) the best per-view-stream count of the calibration: a stream, a handle
             # and a graph per view, as `value` was measured until round 3
             "views_on_streams": (None if not chains or not eng.calibration else

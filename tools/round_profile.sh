@@ -5,9 +5,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-python $R/bench.py --P 500000 --res 1024 --steps 100 --cpu-seconds 6 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
-python $R/bench.py --opacity 0.9 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_opaque.json 2>> $O/${tag}_bench.err
-python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --cpu-seconds 0 > $O/${tag}_bench_dense.json 2>> $O/${tag}_bench.err
+python $R/bench.py --P 500000 --res 1024 --steps 100 --no-dp-reference --cpu-seconds 6 > $O/${tag}_bench_config5.json 2>> $O/${tag}_bench.err
+python $R/bench.py --opacity 0.9 --steps 100 --no-dp-reference --cpu-seconds 0 > $O/${tag}_bench_opaque.json 2>> $O/${tag}_bench.err
+python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --no-dp-reference --cpu-seconds 0 > $O/${tag}_bench_dense.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 > $O/${tag}_train_step_fateavatar_batch4.json 2>> $O/${tag}_bench.err
@@ -16,10 +16,10 @@ FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${ta
 # the N > 1 step on a one-rank RCCL group: what the exchange machinery costs apart from the wire
 python $R/bench.py --exchange-at-1 --cpu-seconds 0 2>> $O/${tag}_bench.err | grep '^{' > $O/${tag}_bench_exchange_at_1.json
 # per-kernel durations: one frame at a time (the roofline figures are per ISOLATED launch), then the default command
-$R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --no-graph --in-flight 1 > /dev/null 2>&1
-$R/tools/profile.sh ${tag}_graph python $R/bench.py --steps 100 --warmup 10 --cpu-seconds 0 --in-flight 1 > /dev/null 2>&1
-$R/tools/profile.sh ${tag}_graph3 python $R/bench.py --steps 100 --warmup 10 --cpu-seconds 0 > /dev/null 2>&1
-python $R/bench.py --in-flight 1 --cpu-seconds 0 > $O/${tag}_bench_one_at_a_time.json 2>> $O/${tag}_bench.err
+$R/tools/profile.sh ${tag}_eager python $R/bench.py --steps 50 --warmup 10 --no-dp-reference --cpu-seconds 0 --no-graph --in-flight 1 > /dev/null 2>&1
+$R/tools/profile.sh ${tag}_graph python $R/bench.py --steps 100 --warmup 10 --no-dp-reference --cpu-seconds 0 --in-flight 1 > /dev/null 2>&1
+$R/tools/profile.sh ${tag}_graph3 python $R/bench.py --steps 100 --warmup 10 --no-dp-reference --cpu-seconds 0 > /dev/null 2>&1
+python $R/bench.py --in-flight 1 --no-dp-reference --cpu-seconds 0 > $O/${tag}_bench_one_at_a_time.json 2>> $O/${tag}_bench.err
 $R/tools/pmc.sh ${tag}_fetch "FETCH_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_write "WRITE_SIZE" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 $R/tools/pmc.sh ${tag}_sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
