@@ -61,7 +61,8 @@ struct GeomView {
                             // (x, y, a', b'), (c', opacity, r, g), (b, id, depth, 0) with the pixel-space centre, the
                             // conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour fed to the blend (SH result or
                             // colors_precomp) — ONE 48-byte gather per instance, not three
-    float4* conic_opacity;  // [P] inverse 2D covariance (a,b,c) + opacity
+    float* opacity_act;     // [P] the activated opacity (the backward's API does not take the opacities; the conic is NOT stored:
+                            // k_preprocess_bwd computes the 2D covariance again anyway and inverts it with the forward's expressions)
     uint8_t* clamped;       // [P] bit c set if SH colour channel c was clamped at 0
     float* dcolor_ddir;     // [P*9] d(SH colour)/d(view direction): (dR,dG,dB)/dx, /dy, /dz — computed by the forward, which has
                             // the 48 coefficients in LDS anyway, so that the backward reads 36 bytes per Gaussian instead
@@ -76,7 +77,7 @@ struct GeomView {
         char* p = static_cast<char*>(buf);
         GeomView g;
         g.rec_tmpl = carve<float4>(p, P * 3);
-        g.conic_opacity = carve<float4>(p, P);
+        g.opacity_act = carve<float>(p, P);
         g.clamped = carve<uint8_t>(p, P);
         g.dcolor_ddir = carve<float>(p, P * 9);
         g.accum = nullptr;

@@ -304,7 +304,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
             }
             radius_out = mr;
             key_depth = p_view.z;
-            a.g.conic_opacity[idx] = make_float4(conic_a, conic_b, conic_c, opacity);
+            a.g.opacity_act[idx] = opacity;
             {
                 // the blend record (GeomView::rec_tmpl): the conic pre-scaled so that the blend loops get
                 // log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into v_exp_f32: a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise

@@ -97,26 +97,6 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         acc[0] = r0.x, acc[1] = r0.y, acc[2] = r0.z, acc[3] = r0.w, acc[4] = r1.x, acc[5] = r1.y, acc[6] = r1.z,
         acc[7] = r1.w, acc[8] = r2.x, acc[9] = r2.y, acc[10] = r2.z, acc[11] = r2.w;
     }
-    // moments of q = dL/dG * G accumulated by the blend backward -> the reference's per-Gaussian sums
-    // (backward.cu:538-554): dG/ddelx = -G*(dx*A + dy*B), dG/ddely = -G*(dy*C + dx*B)
-    const float4 co = a.g.conic_opacity[idx];
-    const float sx = acc[ACC_MX], sy = acc[ACC_MY];
-    const float g2x = -(co.x * sx + co.y * sy) * (0.5f * a.W);
-    const float g2y = -(co.z * sy + co.y * sx) * (0.5f * a.H);
-    const float dcx = -0.5f * acc[ACC_CA], dcy = -0.5f * acc[ACC_CB], dcz = -0.5f * acc[ACC_CC];
-    const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
-    float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
-    store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f, adds(G_MEANS2D));
-    // fused _add_densification_stats (model/fateavatar.py:734-737); this branch is radii > 0
-    // (a replayed frame that overflowed its captured binning capacity back-propagates zeros: it must not count as a view)
-    if (!a.counts->overflow) {
-        if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
-        if (a.denom) a.denom[i] += 1.0f;
-    }
-    store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2], adds(G_COLORS));
-    // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
-    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = old_op + (a.raw ? dop * co.w * (1.0f - co.w) : dop);
-
     const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     const float* vm = cam.view;
     // Sigma3D: the caller's, or computed again from the scales and rotations (the same function and bits as the forward)
@@ -167,6 +147,29 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
     ca += 0.3f;
     cc += 0.3f;
     const float denom = ca * cc - cb * cb;
+    // moments of q = dL/dG * G accumulated by the blend backward -> the reference's per-Gaussian sums
+    // (backward.cu:538-554): dG/ddelx = -G*(dx*A + dy*B), dG/ddely = -G*(dy*C + dx*B)
+    // The conic is not read back: it is the inverse of the 2D covariance this kernel has just computed again, with the
+    // forward's expressions (forward.cu:74-113, 207-219) — the same bits; only the activated opacity comes from the state.
+    const float det_inv = 1.f / denom;
+    const float4 co = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, a.g.opacity_act[idx]);
+    const float sx = acc[ACC_MX], sy = acc[ACC_MY];
+    const float g2x = -(co.x * sx + co.y * sy) * (0.5f * a.W);
+    const float g2y = -(co.z * sy + co.y * sx) * (0.5f * a.H);
+    const float dcx = -0.5f * acc[ACC_CA], dcy = -0.5f * acc[ACC_CB], dcz = -0.5f * acc[ACC_CC];
+    const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
+    float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};
+    store3(a.out.dL_dmeans2D, i, g2x, g2y, 0.f, adds(G_MEANS2D));
+    // fused _add_densification_stats (model/fateavatar.py:734-737); this branch is radii > 0
+    // (a replayed frame that overflowed its captured binning capacity back-propagates zeros: it must not count as a view)
+    if (!a.counts->overflow) {
+        if (a.grad_accum) a.grad_accum[i] += sqrtf(g2x * g2x + g2y * g2y);
+        if (a.denom) a.denom[i] += 1.0f;
+    }
+    store3(a.out.dL_dcolors, i, dcol[0], dcol[1], dcol[2], adds(G_COLORS));
+    // raw-parameter mode: d sigmoid = o (1 - o); co.w is the activated opacity the forward stored
+    if (a.out.dL_dopacity) a.out.dL_dopacity[i] = old_op + (a.raw ? dop * co.w * (1.0f - co.w) : dop);
+
     float dL_da = 0, dL_db = 0, dL_dc = 0;
     const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
     float dcov[6] = {0, 0, 0, 0, 0, 0};
