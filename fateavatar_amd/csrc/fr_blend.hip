@@ -715,18 +715,15 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
 // record-major one, done in registers: v_permlane32_swap for the 32 x 32 blocks, rotate + v_bfi for the rest.
 // LDS per wave decides how many units are in flight per CU (the kernel is latency-bound: a unit is a chain of
 // dependent LDS round trips): 9.25 KB -> 16 waves per CU, enough for every unit of BASELINE config 2 to be resident.
-constexpr int kPairCap = 568;      // pairs a wave holds at once; denser units are processed in several record ranges
-constexpr int kMaxChunks = (kPairCap + 127) / 128;   // phase A takes 128 pairs at a time, two per lane
+constexpr int kPairCap = 640;      // (q, w) slots per wave; denser units are processed in several record ranges
+constexpr int kARecs = 2;         // records per phase-A iteration (3 and 4 measured: no faster, the T / accum_rec chain is the iteration)
 
 struct SparseLds {
-    float4 rec[kBatch * kRecQuads];   // the unit's records: (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, hi)  3 KB
-    float4 pix[64 * 2];               // per pixel: (dL_dpixel r, g, b, -T_final bg . dL_dpixel), (T, accum_rec . dL_dpixel,        2 KB
-                                      // lanes-below-this-pixel mask lo, hi)
-    float2 pair[kPairCap];            // (q, w) of every pair, RECORD-major: a record's pairs are consecutive                    4.4 KB
-    uint8_t pidx[kPairCap];           // ... and the pair's pixel                                                                 0.6 KB
-};                                    // 10 KB per wave: 16 waves per CU.  The pair slots first hold the pairs' descriptors
-                                      // (4 bytes each, pixel-major), until phase A has them in registers.
-static_assert(sizeof(SparseLds) <= 10240, "k_unit_blend_bwd_sparse: 16 waves per CU need <= 10 KB of LDS per wave");
+    float4 rec[kBatch * kRecQuads];   // the unit's records: (x, y, a', b') (c', opacity, r, g) (b, first pair slot, mask lo, hi)   3 KB
+    float4 pix[64];                   // per pixel: dL_dpixel (r, g, b, -)                                     1 KB
+    float2 pair[kPairCap + 64];       // (q, w) of every pair, RECORD-major: a record's pairs are consecutive  5.5 KB
+                                      // (+ 64: one scratch slot per lane, where a lane without a pair reads and writes)
+};
 
 // maximum over the 64 lanes, in every lane's SGPR-able form (result is wave-uniform)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
@@ -1140,18 +1137,6 @@ __device__ __forceinline__ float chain_product(float* g_tseg, const uint4* __res
     return v;
 }
 
-#ifdef FR_FWD_TRACE   // development build (tools/diag/fwd_trace.py): per-unit time stamps of the forward blend's phases
-__device__ unsigned long long g_fwd_trace[16384 * 16];
-extern "C" int fr_debug_read_fwd_trace(void* dst, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_trace), bytes < sizeof(g_fwd_trace) ? bytes : sizeof(g_fwd_trace));
-}
-#define FW_STAMP(K) do { if (lane == 0 && u < 16384u) g_fwd_trace[(size_t)u * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
-#define FW_STAMPV(K, V) do { if (lane == 0 && u < 16384u) g_fwd_trace[(size_t)u * 16 + (K)] = (unsigned long long)(V); } while (0)
-#else
-#define FW_STAMP(K) do { } while (0)
-#define FW_STAMPV(K, V) do { } while (0)
-#endif
 
 struct ChainArgs {
     DeviceCounts* counts;
@@ -1385,14 +1370,6 @@ __global__ void __launch_bounds__(256) k_tile_gather(const DeviceCounts* __restr
     gather_tile<false>(v, tile, u0, (n + kUnit - 1) / kUnit, g_out, unit_state, W, H, bg0, bg1, bg2, out_color, lane);
 }
 
-constexpr uint32_t kNoPair = 1u << 29;   // descriptor of a lane without a pair: reads pixel 0 / record 0, neither first nor last
-// one (pixel, record) pair of phase A: what its evaluation leaves for the scan and the write-out
-struct PairEval {
-    float cd, ar_e, a_e, inv, tfbinv, A0;
-    float mA, bA, mT, bT;   // the pair's maps: accum_rec <- mA accum_rec + bA, T <- mT T + bT
-    uint32_t slot, pixoff;
-    bool valid, head, tail;
-};
 
 struct BlendBwdArgs {
     const DeviceCounts* counts;
@@ -1405,32 +1382,6 @@ struct BlendBwdArgs {
     float* accum;
     uint32_t dense_pairs;
 };
-
-// Two affine maps x -> m x + b per lane, composed along the lanes (inclusive scan, lane order = application order): on
-// return b is the value of the composition of the maps of lanes 0 .. l applied to anything that a lane with m = 0 (a
-// segment head) has replaced.  DPP row shifts inside the 16-lane rows, row_bcast:15 / :31 across them; the shifted
-// operand comes straight out of the DPP crossbar (v_fmac_f32_dpp / v_mul_f32_dpp: a lane whose source does not exist is
-// not written).  22 instructions for both scans; the builtin form costs twice that (the compiler materialises every
-// shifted operand with a v_mov_b32_dpp of its own).
-__device__ __forceinline__ void affine_scan_pair(float& mA, float& bA, float& mT, float& bT)
-{
-#define FR_AFF_STEP(C)                           \
-    "v_fmac_f32_dpp %0, %0, %1 " C "\n\t"        \
-    "v_fmac_f32_dpp %2, %2, %3 " C "\n\t"        \
-    "v_mul_f32_dpp %1, %1, %1 " C "\n\t"         \
-    "v_mul_f32_dpp %3, %3, %3 " C "\n\t"
-    asm volatile("s_nop 1\n\t"   // (a DPP read needs two wait states behind the VALU write of its source)
-                 FR_AFF_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-                 FR_AFF_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 FR_AFF_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-                 FR_AFF_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 FR_AFF_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 "v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %2, %2, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(bA), "+v"(mA), "+v"(bT), "+v"(mT));
-#undef FR_AFF_STEP
-}
 
 __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a)
 {
@@ -1459,9 +1410,6 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     asm volatile("" ::"v"(d_first.x), "v"(u_of_first), "s"(nu), "s"(capacity));
     const BinningView b = BinningView::make(binning, (size_t)capacity, (size_t)n_tiles);
     SparseLds& S = s_all[wave_in_wg];
-    char* const s_rec = reinterpret_cast<char*>(S.rec);
-    char* const s_pix = reinterpret_cast<char*>(S.pix);
-    uint32_t* const s_desc = reinterpret_cast<uint32_t*>(S.pair);   // word 2 i: descriptor of pair i until phase A replaces it
     const uint32_t wave_stride = gridDim.x * kWavesPerWG;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     // flush: lanes 0..62 = 7 records x 9 components; lane l of a septet starting at record r0 reads word r0 * 9 + l of
@@ -1472,7 +1420,6 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     const int vv = bitrev6(lane);
     const int own_u = vv / 9, own_c = vv - own_u * 9;
     const size_t HW = (size_t)H * W;
-    const uint32_t mybit = 1u << (lane & 31);
     for (uint32_t w = w_first; w < nu; w += wave_stride) {
         // ---- every load below depends on the descriptor only: all of them are in flight together (clamped indices keep
         // them unconditional; the compiler serialises loads that sit behind exec-masked branches)
@@ -1516,17 +1463,13 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         const uint32_t cum = wave_incl_scan_u32(cnt);             // pairs of records [0, lane]
         const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)cum, 63);
         // A unit in which a large share of the 64 x 64 pairs is named is cheaper in the all-pairs form (wave-uniform
-        // record reads, four independent alpha evaluations in flight, no pair list).
+        // record reads, four independent alpha evaluations in flight, no divergent walk, no pair slots).
         const bool dense = npairs > dense_pairs;
         const uint32_t my_id = __float_as_uint(rq2.y);
-        const float rxl = rq0.x - (float)tx0, ryl = rq0.y - (float)ty0;           // own record centre, tile-local
-        // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch.)
-        // The pair-major phase A measures from the tile's corner (its pixel comes out of a descriptor as column and row),
-        // the all-pairs form from the image's
-        S.rec[lane * kRecQuads + 0] = make_float4(valid_rec ? (dense ? rq0.x : rxl) : 0.f, valid_rec ? (dense ? rq0.y : ryl) : 0.f,
-                                                  valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
+        // (padding: opacity 0 -> alpha 0.  Component-wise on purpose: a select between two float4 goes through scratch)
+        S.rec[lane * kRecQuads + 0] = make_float4(valid_rec ? rq0.x : 0.f, valid_rec ? rq0.y : 0.f, valid_rec ? rq0.z : 0.f, valid_rec ? rq0.w : 0.f);
         S.rec[lane * kRecQuads + 1] = make_float4(valid_rec ? rq1.x : 0.f, valid_rec ? rq1.y : 0.f, valid_rec ? rq1.z : 0.f, valid_rec ? rq1.w : 0.f);
-        // phase A reads (colour b, first pair slot, mask) from the third quad, the all-pairs form (colour b, id)
+        // the walks read (colour b, first pair slot, mask) from the third quad, the all-pairs form (colour b, id)
         S.rec[lane * kRecQuads + 2] = make_float4(rq2.x, dense ? rq2.y : __uint_as_float(cum - cnt), __uint_as_float(mj.x), __uint_as_float(mj.y));
         // the pixel's walk set, limited to the records in front of its last contributor
         const int lim = (int)last - (int)base;      // records [0, lim) of this unit can contribute to this pixel
@@ -1535,6 +1478,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
 
         const float T_final = inside ? Tf_raw : 0.f;
         const float dpr = inside ? d0 : 0.f, dpg = inside ? d1 : 0.f, dpb = inside ? d2 : 0.f;
+        const float fx = (float)px, fy = (float)py;
         const float bgd = (bg0 * dpr + bg1 * dpg) + bg2 * dpb;
         const float tfb = -T_final * bgd;                                      // -T_final * (bg . dL_dpixel)
         float T = lim > 0 ? (last_unit ? Tf_raw : st.w) : 0.f;
@@ -1542,11 +1486,12 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         if (dense) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            bwd_unit_all_pairs(S.rec, (int)m, lim, (float)px, (float)py, T, A, T_final, bgd, dpr, dpg, dpb, accum, lane, vv, own_u, own_c);
+            bwd_unit_all_pairs(S.rec, (int)m, lim, fx, fy, T, A, T_final, bgd, dpr, dpg, dpb, accum, lane, vv, own_u, own_c);
             __builtin_amdgcn_wave_barrier();   // (S.rec is restaged by the next unit)
             continue;
         }
-        S.pix[2 * lane] = make_float4(dpr, dpg, dpb, tfb);
+        S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
+        const float rxl = rq0.x - (float)tx0, ryl = rq0.y - (float)ty0;           // own record centre, tile-local
 
         // ---- record ranges [lo, hi), from the back, each with at most kPairCap mask bits
         int hi = (int)m;
@@ -1561,170 +1506,88 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
             }
             const u64 range = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
             const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)(cum - cnt), lo);   // first slot of the range
-            const uint32_t nslots = cum_hi - slot0;
-
-            // ---- the range's pairs, PIXEL-major and back to front inside a pixel: lane = pixel writes a descriptor per
-            // pair — bits 0-10 = byte offset of the pixel's row in S.pix (p * 32: byte 0 = 32 * column, byte 1 = row), bits
-            // 16-27 = byte offset of the record in S.rec (j * 48), bit 31 / 30 = the pixel's first / last pair.  This is
-            // the only loop left whose trip count is the longest chain of the tile, and its body is six instructions.
-            const u64 Bg = Bp & range;
-            const uint32_t blo = (uint32_t)Bg, bhi = (uint32_t)(Bg >> 32);
-            const uint32_t cntp = (uint32_t)__popc(blo) + (uint32_t)__popc(bhi);
-            const uint32_t endp = wave_incl_scan_u32(cntp);
-            const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)endp, 63);
-            // (T, accum_rec . dL_dpixel) entering the pixel's pairs, and the lanes below pixel p: what v_mbcnt would use
-            // if the lane were the pixel
-            S.pix[2 * lane + 1] = make_float4(T, A, __uint_as_float(lane < 32 ? mybit - 1u : ~0u), __uint_as_float(lane < 32 ? 0u : mybit - 1u));
-#ifdef FR_DIAG_STATS
-            const uint32_t stat_trips = wave_max_u32((uint32_t)__popc(bhi)) + wave_max_u32((uint32_t)__popc(blo));
-            const uint32_t stat_btrips = (wave_max_u32((lane >= lo && lane < hi) ? cnt : 0u) + 1u) >> 1;
-#endif
-            FR_STAT_ADD(counts, 0, 1u);                                                                   // record ranges
-            FR_STAT_ADD(counts, 1, stat_trips);                                                           // descriptor-loop trips
-            FR_STAT_ADD(counts, 2, (np + 127u) >> 7);                                                     // phase A chunks
-            FR_STAT_ADD(counts, 3, np);                                                                   // pairs
-            FR_STAT_ADD(counts, 4, stat_btrips);                                                          // phase B trips
-            {
-                uint32_t* dst = s_desc + (endp - cntp);
-                const int desc_hi = (int)((uint32_t)lane * 32u | (63u * 48u) << 16), desc_lo = (int)((uint32_t)lane * 32u | (31u * 48u) << 16);
-                for (uint32_t ww = FR_ABLATE(1) ? 0u : bhi; ww != 0u;) {
-                    const int f = __builtin_clz(ww);
-                    ww &= ~(0x80000000u >> f);
-                    *dst++ = (uint32_t)(desc_hi - f * (48 << 16));
-                }
-                for (uint32_t ww = FR_ABLATE(1) ? 0u : blo; ww != 0u;) {
-                    const int f = __builtin_clz(ww);
-                    ww &= ~(0x80000000u >> f);
-                    *dst++ = (uint32_t)(desc_lo - f * (48 << 16));
-                }
-                if (cntp) {   // (a pixel's descriptors are its own words: plain read-modify-write)
-                    s_desc[endp - cntp] |= 0x80000000u;
-                    s_desc[endp - 1u] |= 0x40000000u;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            FR_TR(2);   // descriptors written
-            // The descriptors move to registers (one LDS round trip for all of them): phase A's results go into the same
-            // LDS words, in another order.  Lane l of chunk c takes pairs 128 c + 2 l and + 1.
-            uint2 dsc_of[kMaxChunks];
-#pragma unroll
-            for (int c = 0; c < kMaxChunks; c++) {
-                const uint32_t i = (uint32_t)(c * 128 + 2 * lane);
-                const uint2 draw = *reinterpret_cast<const uint2*>(s_desc + min(i, (uint32_t)(kPairCap - 2) & ~1u));
-                // (no pair: kNoPair, the identity map)
-                dsc_of[c] = make_uint2(i < np ? draw.x : kNoPair, i + 1u < np ? draw.y : kNoPair);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            const uint32_t np = cum_hi - slot0;
             // pairs no pixel walks (record behind the pixel's last contributor, pixel outside the image) must read as
             // zero in phase B: only then is anything left unwritten by phase A
-            if (np != nslots) {
-                for (uint32_t z = (uint32_t)lane; z * 2u < nslots; z += 64u)
+            if (!__all(inside && lim >= hi))
+                for (uint32_t z = (uint32_t)lane; z * 2u < np; z += 64u)
                     reinterpret_cast<float4*>(S.pair)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (uint32_t z = (uint32_t)lane; z * 4u < nslots; z += 64u) reinterpret_cast<uint32_t*>(S.pidx)[z] = 0u;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 
-            FR_TR(3);   // descriptors in registers, slots zeroed
-            // ---- phase A: lane = two consecutive PAIRS.  alpha, the power test and colour . dL_dpixel once per pair, all
-            // lanes busy; the reference's per-pixel recurrences (backward.cu:503-534) — T <- T / (1 - alpha), accum_rec <-
-            // (1 - alpha) accum_rec + alpha colour — are affine maps x -> m x + b: a lane composes its two, the lanes'
-            // compositions are composed along the wave by affine_scan_pair.  A pixel's first pair carries m = 0 and the
-            // pixel's entering state in b, which cuts the scan at the pixel boundaries without a single conditional; the
-            // pixel whose pairs straddle two chunks enters the next chunk through its first lane (carry).
-            // Results go to the RECORD-major slot: the record's first slot + the rank of the pixel in the record's mask.
-            float carry_T = 0.f, carry_A = 0.f;   // (wave-uniform)
+            // ---- phase A: lane = pixel, back to front over the records its mask column names.  Two records per
+            // iteration: their alpha evaluations and slot computations are independent instruction streams; only the
+            // T / accum_rec recurrence is serial
+            u64 Bg = Bp & range;
+#ifdef FR_DIAG_STATS
+            const uint32_t stat_a = (wave_max_u32((uint32_t)__popcll(Bg)) + 1u) >> 1;
+            const uint32_t stat_b = (wave_max_u32((lane >= lo && lane < hi) ? cnt : 0u) + 1u) >> 1;
+#endif
+            FR_STAT_ADD(counts, 0, 1u);       // record ranges
+            FR_STAT_ADD(counts, 1, stat_a);   // phase A trips (two records each)
+            FR_STAT_ADD(counts, 3, np);       // pair slots
+            FR_STAT_ADD(counts, 4, stat_b);   // phase B trips (two pixels each)
+            FR_TR(3);   // range set up, slots zeroed
+            if (__any(Bg != 0ull) && !FR_ABLATE(2)) do {   // (do-while: as a while loop the compiler copies the loop-carried registers every trip)
+                bool act[kARecs];
+                int j[kARecs];
 #pragma unroll
-            for (int c = 0; c < kMaxChunks; c++) {
-                if ((uint32_t)(c * 128) >= np || FR_ABLATE(2)) break;
-                PairEval ev[2];
+                for (int k = 0; k < kARecs; k++) {
+                    act[k] = Bg != 0ull;
+                    j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
+                    Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
+                }
+                float ar_e[kARecs], cd[kARecs];
+                uint32_t slot[kARecs];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t dsc = k ? dsc_of[c].y : dsc_of[c].x;
-                    PairEval& x = ev[k];
-                    x.valid = dsc != kNoPair;
-                    x.head = (int)dsc < 0;
-                    x.tail = (dsc & 0x40000000u) != 0u;
-                    x.pixoff = dsc & 0xFFFFu;
-                    const uint32_t recoff = (dsc >> 16) & 0xFFFu;
-                    const float4 q0 = *reinterpret_cast<const float4*>(s_rec + recoff);
-                    const float4 q1 = *reinterpret_cast<const float4*>(s_rec + recoff + 16);
-                    const float4 q2 = *reinterpret_cast<const float4*>(s_rec + recoff + 32);   // (colour b, first slot, mask lo, hi)
-                    const float4 dp = *reinterpret_cast<const float4*>(s_pix + x.pixoff);
-                    const float4 st0 = *reinterpret_cast<const float4*>(s_pix + x.pixoff + 16);   // (T, accum_rec . dL_dpixel, lanes below)
-                    const float dx = fmaf((float)(dsc & 0xFFu), -1.0f / 32.0f, q0.x), dy = q0.y - (float)((dsc >> 8) & 0xFFu);
+                for (int k = 0; k < kARecs; k++) {
+                    const float4 q0 = S.rec[j[k] * kRecQuads + 0];
+                    const float4 q1 = S.rec[j[k] * kRecQuads + 1];
+                    const float4 q2 = S.rec[j[k] * kRecQuads + 2];
+                    const float dx = q0.x - fx, dy = q0.y - fy;
                     const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-                    const float araw = q1.y * __builtin_amdgcn_exp2f(power);       // opacity * G (alpha before the 0.99 clamp)
-                    const bool ok = x.valid && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
-                    x.cd = (q1.z * dp.x + q1.w * dp.y) + q2.x * dp.z;               // colour . dL_dpixel
-                    x.ar_e = ok ? araw : 0.f;                                      // failed pair: alpha = 0, every update is the identity
-                    x.a_e = __builtin_amdgcn_fmed3f(x.ar_e, 0.f, 0.99f);
-                    const float om = 1.f - x.a_e;
-                    x.inv = __builtin_amdgcn_rcpf(om);
-                    x.tfbinv = dp.w * x.inv;
-                    x.A0 = st0.y;
-                    x.mA = x.head ? 0.f : om, x.bA = fmaf(om, x.head ? st0.y : 0.f, x.a_e * x.cd);
-                    x.mT = x.head ? 0.f : x.inv, x.bT = (x.head ? st0.x : 0.f) * x.inv;
-                    // rank of the pixel among the record's pixels = mask bits below it
-                    x.slot = (uint32_t)__popc(__float_as_uint(q2.w) & __float_as_uint(st0.w)) +
-                             ((uint32_t)__popc(__float_as_uint(q2.z) & __float_as_uint(st0.z)) + (__float_as_uint(q2.y) - slot0));
+                    const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
+                    const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+                    cd[k] = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;              // colour . dL_dpixel
+                    ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity
+                    // rank of this pixel among the record's pixels: mask bits below this lane (v_mbcnt: popcount of
+                    // (operand & lanes-below-mine) + accumulator, two instructions for the 64 bits)
+                    slot[k] = __builtin_amdgcn_mbcnt_hi(__float_as_uint(q2.w),
+                                                        __builtin_amdgcn_mbcnt_lo(__float_as_uint(q2.z), __float_as_uint(q2.y) - slot0));
+                    slot[k] = act[k] ? slot[k] : (uint32_t)kPairCap + (uint32_t)lane;   // (idle lane: its own scratch slot, no exec games)
                 }
-                // the lane's two maps composed, the carry applied to the first lane's, then along the wave
-                const float cT = lane == 0 ? carry_T : 0.f, cA = lane == 0 ? carry_A : 0.f;
-                float MA = ev[1].mA * ev[0].mA, BA = fmaf(ev[1].mA, ev[0].bA, ev[1].bA);
-                float MT = ev[1].mT * ev[0].mT, BT = fmaf(ev[1].mT, ev[0].bT, ev[1].bT);
-                BA = fmaf(MA, cA, BA), BT = fmaf(MT, cT, BT);
-                affine_scan_pair(MA, BA, MT, BT);
-                // the state in front of the lane's first pair: the previous lane's result (the first lane: the carry)
-                const float XA = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, cA), __builtin_bit_cast(int, BA), 0x138, 0xF, 0xF, false));   // wave_shr:1
-                const float XT = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, cT), __builtin_bit_cast(int, BT), 0x138, 0xF, 0xF, false));
-                carry_A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, BA), 63));
-                carry_T = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, BT), 63));
-                // T in front of each pair's Gaussian (backward.cu:503) and accum_rec . dL_dpixel BEFORE it (backward.cu:509-520)
-                const float T0v = fmaf(ev[0].mT, XT, ev[0].bT), A0inc = fmaf(ev[0].mA, XA, ev[0].bA);
-                const float Tk[2] = {T0v, BT};
-                const float Aex[2] = {ev[0].head ? ev[0].A0 : XA, ev[1].head ? ev[1].A0 : A0inc};
-                const float Ainc[2] = {A0inc, BA};
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const PairEval& x = ev[k];
-                    const float e = x.cd - Aex[k];
-                    const float dL_dalpha = fmaf(e, Tk[k], x.tfbinv);               // backward.cu:525-534
-                    if (x.valid) {
-                        S.pair[x.slot] = make_float2(dL_dalpha * x.ar_e, x.a_e * Tk[k]);   // (q = dL_dG G, w = dchannel_dcolor)
-                        S.pidx[x.slot] = (uint8_t)(x.pixoff >> 5);
-                        if (lo > 0 && x.tail) *reinterpret_cast<float2*>(s_pix + x.pixoff + 16) = make_float2(Tk[k], Ainc[k]);   // (the next range continues from it)
-                    }
+                for (int k = 0; k < kARecs; k++) {
+                    const float a_e = __builtin_amdgcn_fmed3f(ar_e[k], 0.f, 0.99f);
+                    const float inv = __builtin_amdgcn_rcpf(1.f - a_e);
+                    T *= inv;                                                   // backward.cu:503
+                    const float e = cd[k] - A;
+                    const float dL_dalpha = e * T + tfb * inv;                  // backward.cu:525-534
+                    A += a_e * e;
+                    S.pair[slot[k]] = make_float2(dL_dalpha * ar_e[k], a_e * T);   // (q = dL_dG G, w = dchannel_dcolor)
                 }
-            }
+            } while (__any(Bg != 0ull));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             FR_TR(4);   // phase A
-            // lane = pixel again: the state in front of the range (the next range continues from it)
-            if (lo > 0) {
-                const float2 sb = *reinterpret_cast<const float2*>(&S.pix[2 * lane + 1]);
-                T = cntp ? sb.x : T, A = cntp ? sb.y : A;
-            }
 
-            // ---- phase B: lane = record, over its own pairs — consecutive slots — two per iteration
+            // ---- phase B: lane = record, over its own pixels (two per iteration); its pairs are consecutive slots
             typedef float v2f __attribute__((ext_vector_type(2)));
             v2f s_m = {0.f, 0.f}, s_ab = {0.f, 0.f}, s_rg = {0.f, 0.f};   // (MX, MY) (CA, CB) (R, G)
             float s_cc = 0.f, s_op = 0.f, s_b = 0.f;
-            const uint32_t mine = (lane >= lo && lane < hi) ? cnt : 0u;
-            const uint32_t slot_b = (cum - cnt) - slot0;
-            const uint32_t trips = FR_ABLATE(3) ? 0u : wave_max_u32(mine);
-            for (uint32_t k = 0; k < trips; k += 2u) {
+            u64 Mg = (lane >= lo && lane < hi) ? Mj : 0ull;
+            uint32_t slot = (cum - cnt) - slot0;
+            if (__any(Mg != 0ull) && !FR_ABLATE(3)) do {
 #pragma unroll
-                for (uint32_t kk = 0; kk < 2u; kk++) {
-                    const bool act = k + kk < mine;
-                    const uint32_t sl = act ? slot_b + k + kk : 0u;
-                    const float2 qw = S.pair[sl];
-                    const uint32_t p = S.pidx[sl];
-                    const float4 dp = S.pix[2u * p];
+                for (int k = 0; k < 2; k++) {
+                    const bool act = Mg != 0ull;
+                    const int p = act ? (int)__builtin_ctzll(Mg) : 0;
+                    Mg &= Mg - 1ull;
+                    float2 qw = S.pair[act ? slot : (uint32_t)kPairCap + (uint32_t)lane];
                     const float q = act ? qw.x : 0.f, wgt = act ? qw.y : 0.f;
-                    const v2f dd = {rxl - (float)(p & 7u), ryl - (float)(p >> 3)};
+                    slot += act ? 1u : 0u;
+                    const float4 dp = S.pix[p];
+                    const v2f dd = {rxl - (float)(p & 7), ryl - (float)(p >> 3)};
                     const v2f qd = q * dd;
                     s_m += qd;
                     s_ab += qd.x * dd;
@@ -1733,7 +1596,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
                     s_rg += wgt * (v2f){dp.x, dp.y};
                     s_b += wgt * dp.z;
                 }
-            }
+            } while (__any(Mg != 0ull));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             FR_TR(5);   // phase B

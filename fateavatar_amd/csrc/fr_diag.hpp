@@ -27,7 +27,7 @@ extern "C" int fr_diag_read_trace(void* dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fr::g_diag_trace), bytes < sizeof(fr::g_diag_trace) ? bytes : sizeof(fr::g_diag_trace));
 }
-#define FR_TR_DECL unsigned long long tr_acc[::fr::kDiagSlots] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = __builtin_readcyclecounter()
+#define FR_TR_DECL unsigned long long tr_acc[::fr::kDiagSlots] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = __builtin_readcyclecounter(), tr_rt0 = __builtin_amdgcn_s_memrealtime()
 // cycles since the previous stamp go to slot k
 #define FR_TR(k)                                                          \
     do {                                                                  \
@@ -37,6 +37,7 @@ extern "C" int fr_diag_read_trace(void* dst, size_t bytes)
     } while (0)
 #define FR_TR_STORE(unit)                                                                                   \
     do {                                                                                                    \
+        tr_acc[7] = (tr_rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);   /* 100 MHz wall clock: start, end */ \
         if (lane == 0 && (unit) < ::fr::kDiagUnits)                                                         \
             for (unsigned tr_k = 0; tr_k < ::fr::kDiagSlots; tr_k++) ::fr::g_diag_trace[(size_t)(unit) * ::fr::kDiagSlots + tr_k] = tr_acc[tr_k]; \
     } while (0)
@@ -58,4 +59,20 @@ extern "C" int fr_diag_read_trace(void* dst, size_t bytes)
 #define FR_ABLATE(k) (((FR_DIAG_ABLATE) >> (k)) & 1)
 #else
 #define FR_ABLATE(k) false
+#endif
+
+//   -DFR_DIAG_FWD_TRACE   per-unit time stamps of k_unit_blend_chained's phases (tools/diag/fwd_trace.py)
+#ifdef FR_DIAG_FWD_TRACE
+namespace fr {
+__device__ unsigned long long g_fwd_trace[16384 * 16];
+}
+extern "C" int fr_debug_read_fwd_trace(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fr::g_fwd_trace), bytes < sizeof(fr::g_fwd_trace) ? bytes : sizeof(fr::g_fwd_trace));
+}
+#define FW_STAMP(K) do { if (lane == 0 && u < 16384u) ::fr::g_fwd_trace[(size_t)u * 16 + (K)] = __builtin_readcyclecounter(); } while (0)
+#define FW_STAMPV(K, V) do { if (lane == 0 && u < 16384u) ::fr::g_fwd_trace[(size_t)u * 16 + (K)] = (unsigned long long)(V); } while (0)
+#else
+#define FW_STAMP(K) do { } while (0)
+#define FW_STAMPV(K, V) do { } while (0)
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a variant of the library with extra -D flags on fr_blend.hip (HERE, in the build container):
-#   tools/diag/build_variant.sh <name> -DFR_BWD_TRACE ...   ->  .ab/libfr_<name>.so
+#   tools/diag/build_variant.sh <name> -DFR_DIAG_TRACE ...   ->  .ab/libfr_<name>.so     (fr_diag.hpp lists the switches)
 # The other objects come from the regular build (run `make -C fateavatar_amd/csrc` first).
 set -e
 name=$1; shift

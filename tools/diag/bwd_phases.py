@@ -1,7 +1,8 @@
 """Where the cycles of k_unit_blend_bwd_sparse go, per phase (GPU box).  Needs the -DFR_DIAG_TRACE build:
     tools/diag/build_variant.sh trace -DFR_DIAG_TRACE        (here)
     FR_HIP_LIB=$PWD/.ab/libfr_trace.so python tools/diag/bwd_phases.py [--P 100000 --res 512 --opacity 0.1]
-Prints mean / p90 / max cycles per unit of: loads, staging, descriptor loop, preload + zero, phase A, phase B, flush."""
+Prints mean / p90 / max cycles per unit of: loads, staging, range set-up, phase A, phase B, flush, and the wall-clock
+spread of the waves' starts and ends."""
 import argparse, ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -25,10 +26,19 @@ buf = np.zeros((32768, 8), np.uint64)
 L.fr_diag_read_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert L.fr_diag_read_trace(buf.ctypes.data, buf.nbytes) == 0
 t = buf[:min(nu, 32768)].astype(np.float64)
-names = ["loads", "staging", "desc loop", "preload+zero", "phase A", "phase B", "flush"]
+names = ["loads", "staging", "-", "range set-up", "phase A", "phase B", "flush"]
 print(f"units {nu}; cycles per unit (mean / p90 / max), share of the mean total")
 tot = t[:, :7].sum(1)
 for k, n in enumerate(names):
     c = t[:, k]
     print(f"  {n:14s} {c.mean():9.0f} {np.percentile(c, 90):9.0f} {c.max():9.0f}   {100 * c.mean() / tot.mean():5.1f} %")
 print(f"  {'total':14s} {tot.mean():9.0f} {np.percentile(tot, 90):9.0f} {tot.max():9.0f}")
+rt = buf[:min(nu, 32768), 7]
+rt = rt[rt != 0]
+st = (rt >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF
+en = (rt & np.uint64(0xFFFFFFFF)).astype(np.int64)
+t0 = st.min()
+st, en = (st - t0) * 0.01, (en - t0) * 0.01   # us (100 MHz)
+print("wave start after the first wave (us): p10 %.2f median %.2f p90 %.2f max %.2f" % (np.percentile(st, 10), np.median(st), np.percentile(st, 90), st.max()))
+print("wave end   after the first wave's start (us): median %.2f p90 %.2f max %.2f" % (np.median(en), np.percentile(en, 90), en.max()))
+print("wave life (us): mean %.2f p90 %.2f max %.2f" % ((en - st).mean(), np.percentile(en - st, 90), (en - st).max()))

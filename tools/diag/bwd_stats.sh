@@ -26,7 +26,7 @@ for P, res, kw in ((100_000, 512, {}), (100_000, 512, dict(opacity=0.9)), (500_0
     w = img[:64].view(torch.int32).cpu().numpy()   # DeviceCounts sits at the head of the image buffer (fr_common.hpp)
     c = R.read_counts(0)
     u = max(int(w[14]), 1)
-    print(f"P={P} res={res} {kw}: instances={c.num_instances} units={w[14]} ranges={w[9]} desc_trips={w[10]} ({w[10]/u:.1f}/unit) "
-          f"chunks={w[11]} ({w[11]/u:.2f}/unit) pairs={w[12]} ({w[12]/u:.0f}/unit, {w[12]/max(int(w[11]),1):.1f}/chunk) "
-          f"B_trips={w[13]} ({w[13]/u:.1f}/unit)")
+    print(f"P={P} res={res} {kw}: instances={c.num_instances} units={w[14]} ranges={w[9]} ({w[9]/u:.2f}/unit) "
+          f"A_trips={w[10]} ({w[10]/u:.1f}/unit, two records each) pair_slots={w[12]} ({w[12]/u:.0f}/unit) "
+          f"B_trips={w[13]} ({w[13]/u:.1f}/unit, two pixels each)")
 PY

@@ -1,5 +1,5 @@
-"""Per-unit phase timeline of the forward blend (GPU box).  Needs the -DFR_FWD_TRACE build:
-    tools/diag/build_variant.sh ftrace -DFR_FWD_TRACE        (here)
+"""Per-unit phase timeline of the forward blend (GPU box).  Needs the -DFR_DIAG_FWD_TRACE build:
+    tools/diag/build_variant.sh ftrace -DFR_DIAG_FWD_TRACE        (here)
     FR_HIP_LIB=$PWD/.ab/libfr_ftrace.so python tools/diag/fwd_trace.py [--P 100000 --res 512]   (GPU box)
 Stamps (shader cycles): 0 entry, 1 records in registers (counts -> descriptor -> ids -> records), 2 staged + masks + transpose,
 3 local walk done, 4 entering transmittance known (look-back), 5 row written, 6 (a tile's last unit) the others' rows are in,
