@@ -84,6 +84,15 @@ def stage_bytes(P: int, M: int, R: int, H: int, W: int) -> dict:
             "preprocess_bwd": P * (111 + 12 * M) + P * (64 + 12 * M)}
 
 
+def stage_bytes_required(P: int, M: int, R: int, H: int, W: int) -> dict:
+    """Where this implementation's data layout needs fewer bytes than SURVEY.md's formula bills: the per-Gaussian backward
+    reads the forward's 36-byte d colour / d direction instead of its 12 M-byte SH row: P * 147 in,
+    P * (64 + 12 M) out.  The other stages' formulas are what they must move."""
+    sb = stage_bytes(P, M, R, H, W)
+    sb["preprocess_bwd"] = P * 147 + P * (64 + 12 * M)
+    return sb
+
+
 def cpu_baseline(scene, budget_s: float = 20.0):
     """Oracle forward+backward on the host: a quick sweep over thread counts picks the best; one thread beside it."""
     from oracle import oracle
@@ -399,6 +408,45 @@ class HipEngine:
     def sync(self):
         torch.cuda.synchronize()
 
+    def run_avatar_mode(self, args, world):
+        """The third N > 1 mode: `--steps` FateAvatar optimisation steps (AvatarStep: the exchange captured in the step's
+        graph on the nccl backend), one frame per rank and step."""
+        import importlib.util
+        from fateavatar_amd import dp
+        spec = importlib.util.spec_from_file_location("fr_train_synthetic", os.path.join(ROOT, "tools", "train_synthetic.py"))
+        ts = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ts)
+        try:
+            su = ts.fateavatar_setup(args.P, args.res, self.dev, use_graph=args.graph)
+            st, cams, posed, gts, nf = su["st"], su["cams"], su["posed"], su["gts"], su["n_frames"]
+
+            def step(it):
+                f = (it * world + self.rank) % nf
+                st.step(cams[f], posed[f], gts[f])
+
+            for it in range(max(args.warmup, 10)):
+                step(it)
+            torch.cuda.synchronize()
+            dp.barrier()
+            t0 = time.perf_counter()
+            for it in range(args.steps):
+                step(args.warmup + it)
+            torch.cuda.synchronize()
+            dp.barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            if world > 1:
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+            st.check()
+            return {"frames_per_step_per_gpu": 1, "rounds_per_step": 1, "frames_in_flight_per_gpu": 1, "overlap": False,
+                    "ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(world * args.steps / dt, 2), "unit": "frames/s",
+                    "steps_per_s": round(args.steps / dt, 2), "allreduce_payload_bytes": 12 * args.P * 4,
+                    "exchange_in_graph": bool(getattr(st, "exchange_in_graph", False)), "sh_degree": 0,
+                    "step": "bind + render + L1 + backward + all-reduce(AVG) of the 'gs' group + densification statistics + Adam"}
+        except Exception as e:   # (the headline modes must not be lost to this one)
+            return {"status": "failed: " + repr(e)[:300]}
+
     def finish(self):
         """After the timed region: overflow check of the captured frames, per-kernel durations, counts."""
         from fateavatar_amd import _lib
@@ -430,6 +478,21 @@ class HipEngine:
 class StubEngine:
     """FR_BENCH_STUB=1: a deterministic gradient per (rank, step) on the CPU instead of the rasterizer, so that the
     launch / exchange / timing control flow of this file runs without a GPU.  Not a measurement."""
+
+    def run_avatar_mode(self, args, world):
+        from fateavatar_amd import dp
+        buf = torch.zeros(12 * 64, dtype=torch.float32)
+        dp.barrier()
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            buf.fill_(float(self.rank + it))
+            dp.allreduce_mean_async(buf).wait()
+        dp.barrier()
+        dt = time.perf_counter() - t0
+        return {"frames_per_step_per_gpu": 1, "rounds_per_step": 1, "frames_in_flight_per_gpu": 1, "overlap": False,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(world * args.steps / dt, 2), "unit": "frames/s",
+                "steps_per_s": round(args.steps / dt, 2), "allreduce_payload_bytes": buf.numel() * 4, "exchange_in_graph": False,
+                "sh_degree": 0, "step": "stub", "mean_check": float(buf[0])}
 
     def __init__(self, args, rank, world, local):
         self.dev = torch.device("cpu")
@@ -549,24 +612,57 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _child_line(extra, timeout=240):
+    """This script again as a child process of ONE rank (its own HIP context), after the timed region: its JSON line."""
+    # (not torchrun's environment: the child is a world of its own — with TORCHELASTIC_USE_AGENT_STORE set it would wait for
+    # the parent job's rendezvous store)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+           and not k.startswith(("TORCHELASTIC_", "ROLE_", "GROUP_", "TORCH_NCCL_", "NCCL_ASYNC"))}
+    env["MASTER_PORT"] = str(_free_port())
+    out = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench exited {out.returncode}: {(out.stderr or out.stdout)[-300:]}")
+    return json.loads(lines[-1])
+
+
+def _scene_args(args):
+    a = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--P", str(args.P), "--res", str(args.res),
+         "--sh-degree", str(args.sh_degree), "--rounds", str(args.rounds)]
+    if args.scale is not None:
+        a += ["--scale", str(args.scale)]
+    return a
+
+
 def _dp_reference_at_1(args):
     """`bench.py --exchange-at-1` as a child process (its own HIP context and one-rank RCCL group), after this process's timed
-    region: the literal and the amortised N > 1 steps at one rank.  None if it cannot be run."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-at-1", "--cpu-seconds", "0", "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--P", str(args.P), "--res", str(args.res), "--sh-degree", str(args.sh_degree),
-           "--opacity", str(args.opacity), "--rounds", str(args.rounds)]
-    if args.scale is not None:
-        cmd += ["--scale", str(args.scale)]
+    region: the N > 1 steps at one rank.  A run that cannot produce it says why in `status`."""
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
-        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--opacity", str(args.opacity)] + _scene_args(args))
         m = rec["dp"]["modes"]
-        return {"what": "the N > 1 steps on a one-rank RCCL group (`bench.py --exchange-at-1`, a second process after the timed region)",
-                "literal": {k: m["literal"][k] for k in ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")},
-                "amortised": {k: m["amortised"][k] for k in ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")},
+        keys = ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")
+        return {"status": "ok",
+                "what": "the N > 1 steps on a one-rank RCCL group (`bench.py --exchange-at-1`, a second process after the timed region)",
+                "literal": {k: m["literal"][k] for k in keys}, "amortised": {k: m["amortised"][k] for k in keys},
+                "avatar": None if not m.get("avatar") else {k: m["avatar"].get(k) for k in keys + ("steps_per_s", "allreduce_payload_bytes")},
                 "allreduce_table": rec["dp"]["allreduce_table"], "rccl_version": rec["dp"]["rccl_version"]}
-    except Exception as e:   # (no RCCL, no free port, ...: the record goes without it)
-        return {"error": repr(e)[:200]}
+    except Exception as e:   # (no RCCL, no free port, ...)
+        return {"status": "failed: " + repr(e)[:300]}
+
+
+def _opaque_scene(args):
+    """The operating point training moves to (opacity 0.9; config/fateavatar.yaml:40-47 prunes below 0.005, the rest
+    saturates): the same scene and run, one frame at a time, as a child process — frames/s and the blend backward's launch."""
+    try:
+        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque"]
+                          + _scene_args(args)[:-2] + ["--rounds", "1"])
+        r = rec.get("roofline") or {}
+        return {"status": "ok", "opacity": 0.9, "value": rec["value"], "unit": rec["unit"], "frames_in_flight": 1,
+                "num_rendered": rec["config"]["num_rendered"], "blend_bwd_us": r.get("avg_launch_us"), "blend_bwd_frac": r.get("frac"),
+                "stage_us": rec.get("stage_us")}
+    except Exception as e:
+        return {"status": "failed: " + repr(e)[:300]}
 
 
 def main():
@@ -596,6 +692,9 @@ def main():
     ap.add_argument("--no-dp-reference", dest="dp_reference", action="store_false", default=True,
                     help="N = 1: do not add `dp_reference_at_1` (the N > 1 step — one view, one all-reduce on a one-rank RCCL "
                          "group — measured by a second run of this script after the timed region)")
+    ap.add_argument("--no-opaque", dest="opaque", action="store_false", default=True,
+                    help="N = 1: do not add `opaque` (the same scene at opacity 0.9, one frame at a time, measured by a second run "
+                         "of this script after the timed region)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
@@ -678,6 +777,10 @@ def main():
                               "ms_per_step": round(ea / args.steps * 1e3, 4),
                               "value": round(world * K_best * rounds * args.steps / ea, 2), "unit": "frames/s"}
         elapsed, frames_per_step = el, 1
+        # ... and the reference's OWN step (train/optim.py:15-21, train/iteration.py:50-60): FateAvatar's mesh-bound
+        # parameters at SH degree 0 — the 'gs' group, 12 floats per Gaussian (4.8 MB at 100 k) — one frame per rank:
+        # bind, render, L1, backward, all-reduce(AVG), Adam as ONE captured graph, the collective a node of it
+        modes["avatar"] = eng.run_avatar_mode(args, world)
     else:
         elapsed, xchg = run_mode(K_best, rounds, False)
         frames_per_step = K_best * rounds
@@ -749,24 +852,35 @@ def main():
                   "modes": modes,
                   "value_is": "modes.literal (BASELINE configs[3]: one view per rank per exchange, no overlap with the next step)",
                   "grad_checksum": float(reduced.double().abs().sum().item())}
+        # The generic literal step is wire-bound by construction: every gradient array leaves one kernel at the end of the
+        # step and the next forward needs the update, so nothing can overlap the exchange.  Its ceiling, from this run's own
+        # numbers: frame / (frame + un-overlapped all-reduce of the same payload).
+        frame_us = modes["literal"]["ms_per_step"] * 1e3 - table[0]["us"]
+        dpinfo["literal_ceiling"] = {"frame_us": round(max(frame_us, 0.0), 1), "allreduce_us": table[0]["us"],
+                                     "efficiency_ceiling": round(max(frame_us, 0.0) / max(modes["literal"]["ms_per_step"] * 1e3, 1e-9), 4),
+                                     "what": "frame_us / (frame_us + allreduce_us): the scaling efficiency the literal mode can reach "
+                                             "against the same step without a wire (frame_us = its step time minus the un-overlapped "
+                                             "all-reduce of its payload, allreduce_table[0])"}
 
     if rank == 0:
         fps = world * frames_per_step * args.steps / elapsed
         H = W = args.res
         M = (args.sh_degree + 1) ** 2
         R = counts["num_rendered"]
-        roof = stage_frac = stages = None
+        roof = stage_frac = stage_frac_required = stages = None
         if prof:
             sb = stage_bytes(args.P, M, R, H, W)
             stages = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]}
             us = dict(stages)
             us["binning_sort"] = sum(us.get(k, 0.0) for k in ("scan", "emit", "tile_sort"))
             stage_frac = {k: round(sb[k] / (us[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) for k in sb if us.get(k)}
+            sbr = stage_bytes_required(args.P, M, R, H, W)
+            stage_frac_required = {k: round(sbr[k] / (us[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) for k in sbr if us.get(k)}
             ms, n = prof["blend_bwd"]
             if n:
                 avg_s = ms / n * 1e-3
                 ach = sb["blend_bwd"] / avg_s / 1e9
-                traffic = valu = src = None
+                traffic = valu = valu_meas = src = None
                 cpath = os.path.join(ROOT, "profiles", "blend_bwd_counters.json")
                 if os.path.exists(cpath):   # written by tools/pmc.sh + tools/pmcstats.py from rocprofv3 --pmc passes
                     try:
@@ -774,12 +888,17 @@ def main():
                         if cj.get("P") == args.P and cj.get("res") == args.res and args.scale is None and args.opacity == 0.1:
                             traffic, src = cj.get("hbm_bytes_per_launch"), "profiles/blend_bwd_counters.json (" + str(cj.get("collected")) + ")"
                             if cj.get("sq_insts_valu_per_launch"):
-                                # wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
-                                valu = round(cj["sq_insts_valu_per_launch"] * 4 / (1024 * 2.4e9 * avg_s), 4)
+                                # MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles on CDNA4's SIMD-32 ->
+                                # wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
+                                valu = round(cj["sq_insts_valu_per_launch"] * 2 / (1024 * 2.4e9 * avg_s), 4)
+                                # ... and at the issue rate this kernel's instruction mix was MEASURED to sustain once 2-3
+                                # waves share a SIMD: 1.3 ns per wave-instruction (tools/diag/micro_issue.hip)
+                                valu_meas = round(cj["sq_insts_valu_per_launch"] * 1.3e-9 / (1024 * avg_s), 4)
                     except Exception:
                         pass
                 roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd_sparse", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
+                        "valu_frac_measured_issue": valu_meas,
                         "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": n,
                         "measured": "dispatch-tied HIP events around ISOLATED launches (eager no-wait frames of one view, queued "
@@ -789,9 +908,21 @@ def main():
             cpu = cpu_baseline(eng.scene, args.cpu_seconds)
         # What `value` is on N > 1 GPUs (the literal configs[3] step) measured at ONE rank, so that a scaling curve has a
         # like-for-like first point: `value` at N = 1 is frames in flight without any exchange, a different mode.
-        dp_ref = None
-        if not STUB and world == 1 and not exchanging and args.dp_reference and args.graph:
-            dp_ref = _dp_reference_at_1(args)
+        dp_ref = opaque = None
+        if not exchanging or world > 1:
+            if args.dp_reference and args.graph and (not STUB or world > 1):
+                dp_ref = _dp_reference_at_1(args)
+        if not STUB and world == 1 and not exchanging and args.opaque and args.graph and args.opacity == 0.1:
+            opaque = _opaque_scene(args)
+        # the like-for-like first point of a scaling curve over the N > 1 `value` (the literal step), and this run against it
+        scaling_reference = efficiency = None
+        if dp_ref and dp_ref.get("status") == "ok":
+            scaling_reference = dp_ref["literal"]["value"]
+            if world > 1:
+                efficiency = round(fps / (world * scaling_reference), 4)
+                for name in ("amortised", "avatar"):
+                    if modes.get(name) and modes[name].get("value") and dp_ref.get(name) and dp_ref[name].get("value"):
+                        modes[name]["efficiency"] = round(modes[name]["value"] / (world * dp_ref[name]["value"]), 4)
         stock = args.scale is None and args.opacity == 0.1
         cfg_name = ("BASELINE.json configs[1]" if (args.P, args.res) == (100_000, 512) and stock else
                     "SURVEY.md §8d config 5 (not the metric's configuration)" if (args.P, args.res) == (500_000, 1024) and stock
@@ -819,9 +950,16 @@ def main():
                                         f"dp1 ({rounds} round(s) of {K_best} view(s) in flight per step, each view on its own stream)")),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
-            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac, "dp": dpinfo,
+            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac,
+            # (stage_frac bills SURVEY.md's formulas; stage_frac_required the bytes this layout has to move: stage_bytes_required)
+            "stage_frac_required": stage_frac_required, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            # the N > 1 `value` (literal step) at ONE rank: divide an N > 1 run's `value` by N times this, not by the N = 1 `value`
+            "scaling_reference": scaling_reference, "scaling_reference_status": None if dp_ref is None else dp_ref.get("status"),
+            "efficiency": efficiency,
             "dp_reference_at_1": dp_ref,
+            # the scene at opacity 0.9 (where training takes the Gaussians), one frame at a time
+            "opaque": opaque,
             # (when `value` is the launch-chain mode) the best per-view-stream count of the calibration: a stream, a handle
             # and a graph per view, as `value` was measured until round 3
             "views_on_streams": (None if not chains or not eng.calibration else

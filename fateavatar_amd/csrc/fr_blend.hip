@@ -1613,7 +1613,10 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
                 const int rj = r0 + fl_rec;
                 const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute(min(rj, 63) << 2, (int)my_id);
                 const float val = fl[r0 * 9 + lane];
-                if (lane < 63 && rj < hi && val != 0.f && !FR_ABLATE(4)) atomic_add_f32(accum_c + (size_t)id * kAccumStride, val);
+                if (lane < 63 && rj < hi && val != 0.f && !FR_ABLATE(4)) {
+                    if (FR_ABLATE(5)) accum_c[(size_t)id * kAccumStride] = val;   // (timing experiment: plain stores)
+                    else atomic_add_f32(accum_c + (size_t)id * kAccumStride, val);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -53,8 +53,8 @@ extern "C" int fr_diag_read_trace(void* dst, size_t bytes)
     } while (0)
 #endif
 
-//   -DFR_DIAG_ABLATE=mask   timing experiments on k_unit_blend_bwd_sparse (results are WRONG): bit 1 skips the descriptor
-//                     loop, bit 2 phase A, bit 3 phase B, bit 4 the flush's atomics
+//   -DFR_DIAG_ABLATE=mask   timing experiments on k_unit_blend_bwd_sparse (results are WRONG): bit 2 skips phase A, bit 3
+//                     phase B, bit 4 the flush's atomics, bit 5 turns them into plain stores
 #ifdef FR_DIAG_ABLATE
 #define FR_ABLATE(k) (((FR_DIAG_ABLATE) >> (k)) & 1)
 #else

@@ -56,13 +56,27 @@ def test_bench_spawns_two_ranks_and_reports_both_modes(overlap, K, R):
     kmean = (warm + steps - 1) * R + (R + 1) / 2
     want = sum(i * 1e-3 + (2 * K + 1) / 2 * kmean for i in range(4096))
     assert abs(d["grad_checksum"] - want) <= 1e-4 * want, (d["grad_checksum"], want)
+    # ---- the third mode: the reference's own step (FateAvatar's 'gs' group, 12 floats per Gaussian, one frame per rank)
+    av = d["modes"]["avatar"]
+    assert (av["frames_per_step_per_gpu"], av["rounds_per_step"], av["frames_in_flight_per_gpu"]) == (1, 1, 1)
+    assert av["allreduce_payload_bytes"] % 48 == 0 and av["value"] > 0 and av["sh_degree"] == 0
+    assert abs(av["mean_check"] - ((steps - 1) + 0.5)) < 1e-6      # (stub: the last step's buffer is the mean over the two ranks)
+    # ---- a scaling curve over `value` has a like-for-like first point and this run's efficiency against it
+    assert j["scaling_reference_status"] == "ok" and j["scaling_reference"] == j["dp_reference_at_1"]["literal"]["value"] > 0
+    assert abs(j["efficiency"] - j["value"] / (2 * j["scaling_reference"])) <= 1e-3
+    assert "efficiency" in amo and "efficiency" in av
+    # ... and the generic literal step's ceiling from the run's own all-reduce table
+    c = d["literal_ceiling"]
+    assert c["allreduce_us"] == d["allreduce_table"][0]["us"] and 0.0 <= c["efficiency_ceiling"] <= 1.0
+    assert abs(c["efficiency_ceiling"] - c["frame_us"] / (lit["ms_per_step"] * 1e3)) <= 2e-3
 
 
 def test_bench_single_rank_stub_line_is_well_formed():
     j = _run(["--steps", "3", "--warmup", "1", "--cpu-seconds", "0"])
     assert j["n_gpus"] == 1 and j["dp"] is None and j["data"] == "stub"
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "config",
-              "roofline", "cpu_baseline", "stage_us", "stage_frac"):
+              "roofline", "cpu_baseline", "stage_us", "stage_frac", "stage_frac_required", "scaling_reference", "efficiency",
+              "opaque", "one_frame_at_a_time"):
         assert k in j
 
 

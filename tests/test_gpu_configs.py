@@ -326,6 +326,11 @@ def test_bench_exchange_machinery_on_one_gpu_accumulates_rounds_in_place(gpu_dev
         assert j["value"] == d["modes"]["literal"]["value"] > 0
         assert d["modes"]["amortised"]["frames_per_step_per_gpu"] == 2 * rounds and d["modes"]["amortised"]["value"] > 0
         assert [t["payload_bytes"] for t in d["allreduce_table"]] == [20000 * 59 * 4, 20000 * 12 * 4]
+        # the third mode: FateAvatar's own step (one frame per rank), its 4.8-MB-class exchange a node of the step's graph
+        av = d["modes"]["avatar"]
+        assert av.get("status") is None, av
+        assert av["value"] > 0 and av["exchange_in_graph"] and av["allreduce_payload_bytes"] == 20000 * 12 * 4
+        assert 0.0 < d["literal_ceiling"]["efficiency_ceiling"] <= 1.0
         sums[rounds] = (d["grad_checksum"], d["modes"]["literal"]["grad_checksum"])
     # (amortised: the mean over rounds x 2 views; literal: view 0 alone — each the same whatever the number of rounds)
     assert sums[1][0] > 0 and abs(sums[3][0] - sums[1][0]) <= 2e-6 * sums[1][0], sums

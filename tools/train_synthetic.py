@@ -88,15 +88,18 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def main_fateavatar(a, rank, world, dev):
+def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, chain=True):
+    """FateAvatar's optimisation step on the synthetic INSTA-layout sequence: the mesh-bound Gaussian
+    set, its step object (AvatarStep, or AvatarBatchStep for K > 1 frames per step), cameras, posed meshes and targets
+    rendered from a hidden ground-truth set.  Used by this script and by bench.py's `avatar` mode."""
     from fateavatar_amd import insta, mesh_sampling
     from fateavatar_amd.avatar import AvatarGaussians, AvatarStep, _BoundFrame
     from fateavatar_amd.binding import bind_gaussians
     from fateavatar_amd.knn import init_scale_by_knn
-    n_frames = max(a.views, 8)
-    transform, posed, faces = insta.synthetic_sequence(n_frames, a.res, seed=0)
+    n_frames = max(views, 8)
+    transform, posed, faces = insta.synthetic_sequence(n_frames, res, seed=0)
     verts, _, _ = scenes.head_geometry()
-    fi, bc = mesh_sampling.random_sampling_barycoords(a.P, verts, faces, np.random.default_rng(0))
+    fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, np.random.default_rng(0))
     pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)
     scale_init = float(init_scale_by_knn(torch.from_numpy(pts).to(dev))[2])
     cams = [TorchCamera(c, dev) for c in insta.camera_arrays(transform)]
@@ -117,13 +120,19 @@ def main_fateavatar(a, rank, world, dev):
                                            gt._rotation, gt._scaling, ref.shell_len, True)
             gts.append(render(cams[f], _BoundFrame(xyz, gt, rot, scl, None), bg)["render"].clone())
     pc = AvatarGaussians(fi, bc, scale_init, dev)
-    K = max(1, a.views_per_step)
+    K = max(1, views_per_step)
     cam0 = TorchCamera(insta.camera_arrays(transform)[0], dev)
     if K == 1:
-        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=not a.no_graph)
+        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=use_graph)
     else:   # the reference's batch of K frames per step (model/fateavatar.py:251-276), in flight together
         from fateavatar_amd.avatar import AvatarBatchStep
-        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=not a.no_graph, chain=a.chain)
+        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=use_graph, chain=chain)
+    return dict(st=st, cams=cams, posed=posed_t, gts=gts, n_frames=n_frames, K=K)
+
+
+def main_fateavatar(a, rank, world, dev):
+    su = fateavatar_setup(a.P, a.res, dev, views=a.views, views_per_step=a.views_per_step, use_graph=not a.no_graph, chain=a.chain)
+    st, cams, posed_t, gts, n_frames, K = su["st"], su["cams"], su["posed"], su["gts"], su["n_frames"], su["K"]
 
     def one_step(it, keep=True):
         if K == 1:
