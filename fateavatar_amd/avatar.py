@@ -523,13 +523,21 @@ class AvatarBatchStep(AvatarStep):
         if self.use_graph and not captured and self._eager_steps >= 2 and (not self.exchange or self.exchange_in_graph):
             self._capture_chain()
             captured = True
-        self._steps_since_poll = getattr(self, "_steps_since_poll", 0) + 1
-        if captured and self._steps_since_poll >= 8:
-            self._steps_since_poll = 0
+        # Every step polls the lanes' pinned count slots (a host read, no synchronisation): the counts are those of the
+        # most recent replay that has FINISHED, so an overflow inside the captured chain is seen one or two steps late.
+        # Those replays back-propagated zeros for the overflowed view (Adam still stepped on its momentum): they are
+        # counted and named — `overflow_steps` — and the chain is captured again with the raised capacity.
+        self._step_no = getattr(self, "_step_no", 0) + 1
+        if captured:
             for L in self.lanes:
                 with rasterizer.handle_slot(L.k):
                     if rasterizer.check_async_overflow(self.dev.index or 0):
                         self.overflows += 1
+                        self.overflow_steps = getattr(self, "overflow_steps", []) + [self._step_no - 1]
+                        if self.overflows == 1:
+                            import warnings
+                            warnings.warn(f"AvatarBatchStep: the binning capacity overflowed inside the captured chain around step "
+                                          f"{self._step_no - 1} (view {L.k}); its gradient was lost, the chain is captured again")
                         self._drop_graphs()
                         captured = False
                         break

@@ -640,6 +640,19 @@ static int debug_sync(bool debug, hipStream_t s, const char* stage)
     return FR_OK;
 }
 
+// The handle's buffers (gradient accumulators, per-tile counters, key buckets) grow with the scene and the tile grid.
+// Growing means hipMalloc (and freeing or retiring the old buffer), which a capturing stream does not allow — and trying
+// would invalidate the caller's capture.  Asked for EVERY view of a call before any of them touches the stream or a handle.
+static bool capture_would_grow(const ForwardCall& c)
+{
+    const fr_handle_impl* h = c.h;
+    const ImageView v = ImageView::make(nullptr, c.prm->W, c.prm->H);
+    const size_t T = (size_t)v.tiles_x * v.tiles_y;
+    const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
+    return (size_t)c.prm->P > h->accum_rows || v.tpad > h->tile_counter_tiles || !h->key_buckets || T > h->bucket_tiles ||
+           h->bucket_cap < need + need / 4;
+}
+
 // Everything one view's forward needs done on the host before its kernels can be enqueued: handle buffers sized, stream
 // ordered behind the handle's previous frame, views of the caller's buffers, the kernels' argument blocks.
 static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, FrameView& f, PreArgs& a, TotalsArgs& tot,
@@ -654,18 +667,7 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
     BinningView b = BinningView::make(c.binning, (size_t)c.cap, (size_t)T);
     int rc;
-    // The handle's buffers (gradient accumulators, per-tile counters, key buckets) grow with the scene and the tile
-    // grid.  Growing means hipMalloc (and freeing or retiring the old buffer), which a capturing stream does not allow —
-    // and trying would invalidate the caller's capture.  Say so before touching the stream.
-    if (capturing) {
-        const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
-        const bool grows = (size_t)P > h->accum_rows || v.tpad > h->tile_counter_tiles || !h->key_buckets
-                           || (size_t)T > h->bucket_tiles || h->bucket_cap < need + need / 4;
-        if (grows)
-            return fail_msg(FR_ERR_UNSUPPORTED,
-                            "this frame needs handle buffers (re)allocated, which cannot happen while the stream is "
-                            "being captured: run one eager frame of this size on this handle first");
-    }
+    // (launch_forward has already refused a capturing stream whose frame would need handle buffers grown: capture_would_grow)
     // the backward's gradient accumulators live in the handle (zero between backward passes): size them here, where an
     // allocation is still allowed (a backward may be part of a captured graph)
     if ((rc = ensure_accum(h, (size_t)P, s))) return rc;
@@ -738,6 +740,12 @@ int launch_forward(int n, const ForwardCall* calls, hipStream_t s)
     int rc;
     bool capturing = false;
     for (int k = 0; k < n; k++) capturing = note_capture(calls[k].h, s) || capturing;
+    if (capturing)   // (first pass over ALL views: nothing has been enqueued, no handle modified, when this returns)
+        for (int k = 0; k < n; k++)
+            if (capture_would_grow(calls[k]))
+                return fail_msg(FR_ERR_UNSUPPORTED,
+                                "this frame needs handle buffers (re)allocated, which cannot happen while the stream is "
+                                "being captured: run one eager frame of this size on this handle first");
     size_t pre_lds = 0;
     uint32_t pre_blocks = 0, tot_blocks = 0;
     bool debug = false, no_wait = true;

@@ -24,7 +24,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # FR_DP_GROUP_OF_ONE=1: a one-rank process group, so that the N > 1 machinery can be run on the REAL backend on one GPU
+    global _diagnostic_group_of_one
     if (world > 1 or os.environ.get("FR_DP_GROUP_OF_ONE") == "1") and not dist.is_initialized():
+        _diagnostic_group_of_one = world == 1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -41,9 +43,14 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local
 
 
+_diagnostic_group_of_one = False   # set by init_from_env when IT created the one-rank group for FR_DP_GROUP_OF_ONE=1
+
+
 def group_of_one() -> bool:
-    """True for the diagnostic one-rank process group (FR_DP_GROUP_OF_ONE=1): the N > 1 code paths on one GPU."""
-    return dist.is_initialized() and dist.get_world_size() == 1
+    """True for the DIAGNOSTIC one-rank process group only (FR_DP_GROUP_OF_ONE=1, created by init_from_env): the N > 1 code
+    paths on one GPU.  A one-rank group somebody else initialised (a single-GPU launch through torchrun, say) is a plain
+    single-process run: its steps exchange nothing and keep their captured graph."""
+    return _diagnostic_group_of_one and dist.is_initialized() and dist.get_world_size() == 1
 
 
 def world_size() -> int:

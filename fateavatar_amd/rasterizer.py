@@ -111,7 +111,7 @@ def check_async_overflow(device_index: int = 0) -> bool:
     c = read_counts(device_index)
     last_counts[device_index] = c
     if c.overflow:
-        _capacity_hint[device_index] = int(c.num_instances * 1.25) + 1024
+        _capacity_hint[device_index] = max(_capacity_hint.get(device_index, 0), int(c.num_instances * 1.25) + 1024)
     return bool(c.overflow)
 
 

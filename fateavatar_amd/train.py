@@ -43,6 +43,10 @@ class TrainStep:
         # (gloo cannot be captured: the CPU tests keep the eager exchange.)
         self.exchange = torch.distributed.is_initialized() and (self.world > 1 or dp.group_of_one())
         self.exchange_in_graph = self.exchange and torch.distributed.get_backend() == "nccl"
+        if use_graph and self.exchange and not self.exchange_in_graph:
+            import warnings
+            warnings.warn(f"TrainStep: the {torch.distributed.get_backend()} exchange cannot be captured; the all-reduce and Adam "
+                          "run eagerly behind the captured frame")
         lr = dict(DEFAULT_LRS, **(lrs or {}))
         P, M = pc.P, pc.M
         self.adam = FusedAdam(pc.flat, pc.flat_grad, [

@@ -47,6 +47,8 @@ def lib():
         L.fro_cov3d.argtypes = [fp, C.c_float, fp, fp]
         L.fro_num_threads.restype = C.c_int
         L.fro_set_num_threads.argtypes = [C.c_int]
+        L.fro_set_bwd_float_order.argtypes = [C.c_int]
+        L.fro_set_bwd_contract.argtypes = [C.c_int]
         for name, ty in [("depths", C.c_float), ("clamped", C.c_uint8), ("means2D", C.c_float), ("cov3D", C.c_float),
                          ("conic_opacity", C.c_float), ("rgb", C.c_float), ("tiles_touched", C.c_uint32),
                          ("final_T", C.c_float), ("n_contrib", C.c_uint32), ("ranges", C.c_uint32),
@@ -206,6 +208,19 @@ def num_threads() -> int:
 
 def set_num_threads(n: int) -> None:
     lib().fro_set_num_threads(int(n))
+
+
+def set_bwd_float_order(seed: int) -> None:
+    """Diagnostic (tests/test_gpu_parity.py's noise floor): seed != 0 makes backward() add every Gaussian's per-pixel terms in
+    FLOAT and in a seeded order, as the reference's atomics do (fr_oracle.c: fro_set_bwd_float_order); 0 restores the
+    double sums."""
+    lib().fro_set_bwd_float_order(int(seed))
+
+
+def set_bwd_contract(on: bool) -> None:
+    """Diagnostic: evaluate the backward's Gaussian exponent with an FMA contraction, as nvcc's default would (fr_oracle.c:
+    fro_set_bwd_contract)."""
+    lib().fro_set_bwd_contract(1 if on else 0)
 
 
 def eval_sh(deg: int, sh, mean, campos):

@@ -91,12 +91,39 @@ def _flip_affected_gaussians(o, h):
 SKIPPED = {}   # scene -> (flip pixels, rows exempted from the tight test, fraction of the visible rows): printed with -rP
 
 
-def _check_backward(o, h, dpix, name, max_skip_frac=0.02):
-    """`max_skip_frac`: the largest share of the VISIBLE Gaussians that threshold flips may exempt from the 1e-4 / 2e-4
-    test (they are still held to rel-L2 0.2).  A flip in a 16x16 list of thousands of entries exempts thousands of rows,
-    so dense stress scenes state a larger bound — but every scene states one, and it is asserted."""
+NOISE_K = 8.0   # the aggregate gradient bound is max(1e-4, NOISE_K x the float-order noise floor of the array)
+ACHIEVED = {}   # name -> {array: (rel-L2 of the kept rows, floor, rel-L2 of the flip-exempt rows)}
+
+
+def _rel_l2_kept(got, ref, keep):
+    """L2 error of the rows without a threshold flip, relative to their norm — but to no less than 0.1 % of the whole
+    array's: in a scene of image-sized splats nearly every Gaussian shares a pixel with a flip, and what is left are
+    rows whose gradients are 1e-6 of the array's scale, i.e. fp32 noise of sums that cancel."""
+    return float(np.linalg.norm((got[keep] - ref[keep]).astype(np.float64))
+                 / max(np.linalg.norm(ref[keep].astype(np.float64)), 1e-3 * np.linalg.norm(ref.astype(np.float64)), 1e-300))
+
+
+def _check_backward(o, h, dpix, name, max_skip_frac=0.02, agg_bound=1e-4):
+    """Gradients against the oracle.  north_star's bound is 1e-4 relative; the reference itself is not reproducible to
+    better than the order of its float atomics and the FMA contractions of its compiler, so the aggregate bound per array
+    is max(agg_bound, NOISE_K x floor), where `floor` is MEASURED on this scene: the oracle's backward with float sums in
+    seeded orders, and with nvcc-style contractions (two results the reference could produce), against its double sums.
+    At every BASELINE configuration the floor is ~1e-7, the bound 1e-4, and the HIP path sits at 3e-7 .. 9e-7.
+    `agg_bound`: only scenes of IMAGE-SIZED splats state more than 1e-4 (3e-4; see test_fuzz_regression_image_sized_splats).
+    `max_skip_frac`: the largest share of the VISIBLE Gaussians that threshold flips may exempt from the tight test
+    (they are still held to rel-L2 0.2, and what they achieve is printed).  A flip in a 16x16 list of thousands of entries
+    exempts thousands of rows, so dense stress scenes state a larger bound — but every scene states one, and it is asserted."""
     from oracle import oracle
     ob = oracle.backward(o, dpix)
+    floors = []
+    for seed, contract in ((1, False), (2, True)):
+        oracle.set_bwd_float_order(seed)
+        oracle.set_bwd_contract(contract)
+        try:
+            floors.append(oracle.backward(o, dpix))
+        finally:
+            oracle.set_bwd_float_order(0)
+            oracle.set_bwd_contract(False)
     hb = h.backward(dpix)
     skip, n_flips = _flip_affected_gaussians(o, h)
     assert n_flips <= max(1, int(1e-4 * dpix.shape[1] * dpix.shape[2])), (name, n_flips)
@@ -105,6 +132,7 @@ def _check_backward(o, h, dpix, name, max_skip_frac=0.02):
     SKIPPED[name] = (n_flips, int(skip.sum()), round(frac, 5))
     print(f"[skipped rows] {name}: {n_flips} flip pixel(s) exempt {int(skip.sum())} of {n_vis} visible Gaussians ({frac:.4%}) from the tight test")
     keep = ~skip
+    ACHIEVED[name] = {}
     for k in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
               "dL_drotations"]:
         ref, got = getattr(ob, k), hb[k]
@@ -117,18 +145,19 @@ def _check_backward(o, h, dpix, name, max_skip_frac=0.02):
         # (absolute floor 5 ppm of the largest entry: a splat that covers thousands of pixels sums thousands of signed
         # terms to a small net gradient, and the two implementations add them in different orders)
         fr = util.frac_close(got[keep], ref[keep], 1e-4, 5e-6 * scale)
-        # (L2 error of the rows without a threshold flip, relative to their norm — but to no less than 0.1 % of the
-        # whole array's: in a scene of image-sized splats nearly every Gaussian shares a pixel with a flip, and what is
-        # left are rows whose gradients are 1e-6 of the array's scale, i.e. fp32 noise of sums that cancel)
-        rl = float(np.linalg.norm((got[keep] - ref[keep]).astype(np.float64))
-                   / max(np.linalg.norm(ref[keep].astype(np.float64)), 1e-3 * np.linalg.norm(ref.astype(np.float64)), 1e-300))
+        rl = _rel_l2_kept(got, ref, keep)
+        floor = max(_rel_l2_kept(getattr(f, k), ref, keep) for f in floors)
+        bound = max(agg_bound, NOISE_K * floor)
+        rl_skip = util.rel_l2(got[skip], ref[skip]) if skip.any() else 0.0
+        ACHIEVED[name][k] = (rl, floor, rl_skip)
+        print(f"[gradient] {name} {k}: rel-L2 {rl:.2e} (float-order floor {floor:.1e}, bound {bound:.1e}); flip-exempt rows {rl_skip:.2e}")
         # (0.1 % of the entries, but never fewer than three: a scene of 100 Gaussians has 400 quaternion entries, and an
         # entry that is the small difference of large terms misses a 1e-4 relative test in fp32 either way)
         n_off = round((1.0 - fr) * got[keep].size)
-        assert (fr >= 0.999 or n_off <= 3) and rl <= 2e-4, (name, k, fr, rl, n_flips, int(skip.sum()))
+        assert (fr >= 0.999 or n_off <= 3) and rl <= bound, (name, k, fr, rl, floor, bound, n_flips, int(skip.sum()))
         # Gaussians that share a pixel with a threshold flip: same sign and size, not garbage
         if skip.any():
-            assert util.rel_l2(got[skip], ref[skip]) <= 0.2, (name, k, "flip-affected rows")
+            assert rl_skip <= 0.2, (name, k, "flip-affected rows", rl_skip)
     # (last, so that a real mismatch is reported as such and not as a scene that exempts too much)
     assert frac <= max_skip_frac, (name, "threshold flips exempt too many rows from the tight gradient test", n_flips, int(skip.sum()), n_vis, frac)
 
@@ -143,6 +172,37 @@ def test_forward_backward_vs_oracle(name, gpu_device):
     H, W = s.camera.image_height, s.camera.image_width
     dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
     _check_backward(o, h, dpix, name)
+
+
+def _flip_pixels(o, h):
+    col, fT = h.color.cpu().numpy(), h.final_T.cpu().numpy()
+    return (np.abs(col - o.color) > 1e-5 + 1e-4 * np.abs(o.color)).any(0) | (np.abs(fT - o.final_T) > 1e-5 + 1e-4 * np.abs(o.final_T))
+
+
+@pytest.mark.parametrize("name", ["dense_opaque", "wide_offscreen"])
+def test_backward_without_exemptions_on_dense_scenes(name, gpu_device):
+    """The two scenes whose threshold flips exempt the most rows, with NO row exempt: the upstream gradient is zero at the
+    pixels whose forward value flipped (a pixel with dL/dpixel = 0 contributes nothing to any gradient, whatever its
+    blend sequence was), so every Gaussian's gradient must pass the tight test — a regression confined to a few tile
+    lists cannot hide behind an exemption here."""
+    s = SCENES[name]
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, name)
+    H, W = s.camera.image_height, s.camera.image_width
+    dpix = (np.random.default_rng(13).uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+    bad = _flip_pixels(o, h)
+    dpix[:, bad] = 0.0
+    print(f"[no exemptions] {name}: {int(bad.sum())} flip pixel(s) masked out of dL/dpixel")
+    # (the same machinery with an empty exemption set: the forward outputs are made to agree before the comparison)
+    class _Agree:
+        def __init__(self, h, o):
+            self._h, self.color, self.final_T = h, __import__("torch").from_numpy(o.color.copy()), __import__("torch").from_numpy(o.final_T.copy())
+        def backward(self, d):
+            return self._h.backward(d)
+    _check_backward(o, _Agree(h, o), dpix, name + "-no-exemptions", max_skip_frac=0.0,
+                    agg_bound=3e-4 if name == "wide_offscreen" else 1e-4)
+    assert SKIPPED[name + "-no-exemptions"][1] == 0
 
 
 def test_colors_precomp_and_cov3d_precomp(gpu_device):

@@ -24,6 +24,11 @@ for it in range(n):
               opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
               bg=tuple(rng.uniform(0, 1, 3)))
     name = f"fuzz{it}: P={P} {H}x{W} deg={deg} scale=[{slo:.4f},{shi:.4f}] op=[{olo:.3f},{ohi:.3f}] spread={spread:.2f}"
+    if os.environ.get("FR_FUZZ_ONLY") and it != int(os.environ["FR_FUZZ_ONLY"]):
+        rng.uniform(-1, 1, (3, H, W))   # (keeps the stream of draws of the full run)
+        continue
+    if os.environ.get("FR_FUZZ_PRINT_KW"):
+        print("kw", it, dict(P=P, H=H, W=W, **kw), flush=True)
     try:
         s = scenes.random_scene(P, H, W, **kw)
         o = util.oracle_forward(s)
@@ -32,7 +37,8 @@ for it in range(n):
         dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
         # (the share of rows a threshold flip may exempt from the tight test: as tests/test_gpu_configs.py bounds it —
         # one flipped pixel under image-sized splats shares its list with a large part of the scene)
-        _check_backward(o, h, dpix, name, max_skip_frac=0.6 if shi >= 0.05 else 0.08)   # (asserted after the gradient checks)
+        _check_backward(o, h, dpix, name, max_skip_frac=0.6 if shi >= 0.05 else 0.08,   # (asserted after the gradient checks)
+                        agg_bound=3e-4 if shi >= 0.05 else 1e-4)
         print("ok  ", name, "inst", h.counts.num_instances, "maxlist", h.counts.max_tile_list, flush=True)
     except Exception as e:
         bad += 1
