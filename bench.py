@@ -48,7 +48,8 @@ The JSON line carries
                  exchange at all, `value` at N > 1 the literal configs[3] step — a scaling curve over `value` compares the
                  two; the like-for-like first point of the N > 1 series is `dp_reference_at_1.literal.value`.
 
-Diagnostics: FR_BENCH_HOST_TIME=1 prints how long the host took to enqueue a step; FR_BENCH_BATCH_X_STREAMS=1 adds more
+Diagnostics: FR_BENCH_HOST_TIME=1 prints how long the host took to enqueue a step; FR_BENCH_ORDER=coherent stores the scene's
+Gaussians in a spatially coherent order (not the metric's scene: what a coherent input order would be worth); FR_BENCH_BATCH_X_STREAMS=1 adds more
 (views per chain, chains) shapes to `batched_views`.
 FR_BENCH_STUB=1 replaces the rasterizer by a deterministic CPU gradient generator so that the N > 1 control flow can
 be exercised without GPUs (tests/test_bench_dp.py); such a line says "data": "stub" and is not a measurement.
@@ -137,6 +138,12 @@ class _View:
 
     def __init__(self, eng, k, scene):
         from fateavatar_amd.model import FlatGaussians, TorchCamera
+        if os.environ.get("FR_BENCH_ORDER") == "coherent":   # (diagnostic: the same Gaussians stored in a spatially coherent
+            lo, hi = scene.means3D.min(0), scene.means3D.max(0)   # order — grid cells of the bounding box, x fastest — instead of
+            c = np.minimum(((scene.means3D - lo) / np.maximum(hi - lo, 1e-12) * 32).astype(np.int64), 31)   # the metric's random one)
+            o = np.argsort(c[:, 2] * 1024 + c[:, 1] * 32 + c[:, 0], kind="stable")
+            for a in ("means3D", "scales", "rotations", "opacities", "shs"):
+                setattr(scene, a, np.ascontiguousarray(getattr(scene, a)[o]))
         self.k, self.scene = k, scene
         # N > 1: two replicas (and two captured graphs), used by alternate steps, so that the gradient exchange of step i
         # reads one set of gradient buffers while the frames of step i + 1 already write the other

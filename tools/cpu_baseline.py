@@ -47,5 +47,9 @@ if __name__ == "__main__":
             ("config 5: 500k head template, 1024^2, SH deg 3", scenes.head_scene(P=500000, res=1024), True)]
     for name, s, bwd in cfgs:
         run(name, s, bwd, all_cores, 6.0)
+    # config 2 over the thread counts: where does the port stop scaling on this host?
+    name, s, bwd = cfgs[1]
+    for t in sorted({t for t in (8, 16, 32, 64, 96, 128, 192, 256) if t < all_cores}):
+        run(name, s, bwd, t, 4.0)
     for name, s, bwd in cfgs[:2]:
         run(name, s, bwd, 1, 12.0)

@@ -26,4 +26,6 @@ $R/tools/pmc.sh ${tag}_sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VM
 $R/tools/pmc.sh ${tag}_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" python $R/tools/probe.py --iters 10 > /dev/null 2>&1
 python $R/tools/probe_coherent.py > $O/${tag}_coherent_order.txt 2>/dev/null
 python $R/tools/cpu_baseline.py > $O/${tag}_cpu_baseline.txt 2>/dev/null
+bash $R/tools/diag/bwd_stats.sh > $O/${tag}_bwd_stats.txt 2>/dev/null
+FR_HIP_LIB=$R/.ab/libfr_trace.so python $R/tools/diag/bwd_phases.py > $O/${tag}_bwd_phases.txt 2>/dev/null
 ls $O | grep $tag
