@@ -111,9 +111,10 @@ def cpu_baseline(scene, budget_s: float = 20.0):
         return time.perf_counter() - t0
 
     ncpu = oracle.num_threads()
+    quota = oracle.cpu_quota_cores()   # what the container may use (16 CPUs on the GPU boxes, of 256 hardware threads)
     run(1)  # page-in, thread pool
     sweep = {}
-    for t in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for t in sorted({quota, max(1, quota // 2), min(ncpu, 2 * quota), min(ncpu, 4 * quota)}, reverse=True):
         oracle.set_num_threads(t)
         run(1)
         sweep[t] = run(2) / 2
@@ -128,7 +129,8 @@ def cpu_baseline(scene, budget_s: float = 20.0):
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": best, "kind": "port",
             "sample": f"{n} frames fwd+bwd of the same workload at {best} threads ({dt:.1f} s); thread sweep "
                       + ", ".join(f"{k}: {1 / v:.2f}" for k, v in sorted(sweep.items())) + " frames/s",
-            "value_1thread": round(n1 / dt1, 3), "host_threads": ncpu}
+            "value_1thread": round(n1 / dt1, 3), "host_threads": ncpu, "cpu_quota_cores": quota,
+            "note": "the container's CPU quota bounds the port: thread counts beyond `cpu_quota_cores` time-slice against each other"}
 
 
 # ---------------------------------------------------------------- engines: what a "frame" is

@@ -206,6 +206,28 @@ def num_threads() -> int:
     return lib().fro_num_threads()
 
 
+def cpu_quota_cores() -> int:
+    """Cores this process may actually use: the scheduler affinity, capped by the container's CPU quota (cgroup v2
+    `cpu.max`, v1 `cpu.cfs_quota_us`).  os.cpu_count() reports the host's hardware threads (256 on the GPU boxes) while the
+    quota there is 16 CPUs: threads beyond it only time-slice against each other."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except Exception:
+            pass
+    return n
+
+
 def set_num_threads(n: int) -> None:
     lib().fro_set_num_threads(int(n))
 
