@@ -37,8 +37,11 @@ rt = buf[:min(nu, 32768), 7]
 rt = rt[rt != 0]
 st = (rt >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF
 en = (rt & np.uint64(0xFFFFFFFF)).astype(np.int64)
+last = en > en.max() - 20000          # (rows of the LAST launch only: units it skipped keep an earlier launch's stamps)
+st, en = st[last], en[last]
 t0 = st.min()
 st, en = (st - t0) * 0.01, (en - t0) * 0.01   # us (100 MHz)
-print("wave start after the first wave (us): p10 %.2f median %.2f p90 %.2f max %.2f" % (np.percentile(st, 10), np.median(st), np.percentile(st, 90), st.max()))
+print("waves of the last launch: %d" % st.size)
+print("wave start after the first wave (us): p1 %.2f p10 %.2f median %.2f p90 %.2f max %.2f" % (np.percentile(st, 1), np.percentile(st, 10), np.median(st), np.percentile(st, 90), st.max()))
 print("wave end   after the first wave's start (us): median %.2f p90 %.2f max %.2f" % (np.median(en), np.percentile(en, 90), en.max()))
 print("wave life (us): mean %.2f p90 %.2f max %.2f" % ((en - st).mean(), np.percentile(en - st, 90), (en - st).max()))
