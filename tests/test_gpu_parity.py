@@ -7,7 +7,8 @@ Tolerances (BASELINE.json north_star: rendered RGBA and per-Gaussian grads withi
   * blended outputs (RGB, final transmittance = the alpha channel): |d| <= 1e-5 + 1e-4*|ref| on
     >= 99.99 % of the pixels; the rest must be explainable as threshold flips (alpha < 1/255,
     T < 1e-4, power > 0), i.e. bounded by one splat's contribution;
-  * gradients: |d| <= 1e-4*|ref| + 1e-6*max|ref| on >= 99.9 % of the entries and rel-L2 <= 2e-4
+  * gradients: |d| <= 1e-4*|ref| + 1e-6*max|ref| on >= 99.9 % of the entries and rel-L2 <= max(1e-4, 8 x the measured
+    float-order / contraction floor)
     (float atomics make the reference itself order-dependent at the 1e-6 level).
 """
 import numpy as np
@@ -223,7 +224,7 @@ def test_colors_precomp_and_cov3d_precomp(gpu_device):
         ref, got = getattr(ob, k), hb[k]
         scale = np.abs(ref).max()
         assert util.frac_close(got, ref, 1e-4, 1e-6 * scale) >= 0.999, k
-        assert util.rel_l2(got, ref) <= 2e-4, k
+        assert util.rel_l2(got, ref) <= 1e-4, k
     assert np.abs(hb["dL_dscales"]).max() == 0 and np.abs(hb["dL_drotations"]).max() == 0
 
 
@@ -282,8 +283,8 @@ def test_long_tile_lists_take_the_multi_wave_and_fallback_sorts(P, lo, hi, gpu_d
     dpix = (rng.uniform(-1, 1, (3, 32, 32)) / (32 * 32)).astype(np.float32)
     from oracle import oracle
     ob, hb = oracle.backward(o, dpix), h.backward(dpix)
-    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 2e-4
-    assert util.rel_l2(hb["dL_dopacity"], ob.dL_dopacity) < 2e-4
+    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 1e-4
+    assert util.rel_l2(hb["dL_dopacity"], ob.dL_dopacity) < 1e-4
 
 
 def test_large_non_square_image(gpu_device):
@@ -298,8 +299,8 @@ def test_large_non_square_image(gpu_device):
     dpix = (rng.uniform(-1, 1, (3, 1000, 1536)) / (1000 * 1536)).astype(np.float32)
     from oracle import oracle
     ob, hb = oracle.backward(o, dpix), h.backward(dpix)
-    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 2e-4
-    assert util.rel_l2(hb["dL_dsh"], ob.dL_dsh) < 2e-4
+    assert util.rel_l2(hb["dL_dmeans2D"], ob.dL_dmeans2D) < 1e-4
+    assert util.rel_l2(hb["dL_dsh"], ob.dL_dsh) < 1e-4
 
 
 def test_mark_visible(gpu_device):
@@ -388,14 +389,14 @@ def test_render_api_autograd_path(gpu_device):
     b = oracle.backward(f, w)
     assert util.frac_close(img.detach().cpu().numpy(), f.color, 1e-4, 1e-5) >= 0.9999
     assert np.array_equal(out["visibility_filter"].cpu().numpy(), f.radii > 0)
-    assert util.rel_l2(out["viewspace_points"].grad.cpu().numpy(), b.dL_dmeans2D) < 2e-4
-    assert util.rel_l2(pc.grad_of("_xyz").cpu().numpy(), b.dL_dmeans3D) < 2e-4
-    assert util.rel_l2(pc.grad_of("_features").cpu().numpy(), b.dL_dsh) < 2e-4
+    assert util.rel_l2(out["viewspace_points"].grad.cpu().numpy(), b.dL_dmeans2D) < 1e-4
+    assert util.rel_l2(pc.grad_of("_xyz").cpu().numpy(), b.dL_dmeans3D) < 1e-4
+    assert util.rel_l2(pc.grad_of("_features").cpu().numpy(), b.dL_dsh) < 1e-4
     # chain rule through sigmoid / exp in stock PyTorch
     op = pc.get_opacity.detach().cpu().numpy()
-    assert util.rel_l2(pc.grad_of("_opacity").cpu().numpy(), b.dL_dopacity * op * (1 - op)) < 2e-4
+    assert util.rel_l2(pc.grad_of("_opacity").cpu().numpy(), b.dL_dopacity * op * (1 - op)) < 1e-4
     sc = pc.get_scaling.detach().cpu().numpy()
-    assert util.rel_l2(pc.grad_of("_scaling").cpu().numpy(), b.dL_dscales * sc) < 2e-4
+    assert util.rel_l2(pc.grad_of("_scaling").cpu().numpy(), b.dL_dscales * sc) < 1e-4
 
 
 def test_fused_visibility_mask_and_densification_stats(gpu_device):
@@ -453,7 +454,7 @@ def test_fused_activations_match_torch_activations(gpu_device):
     assert np.mean(a["radii"] == b["radii"]) > 0.999
     assert util.frac_close(b["img"], a["img"], 1e-4, 1e-5) >= 0.9999
     for k in ["g2", "_xyz", "_features", "_opacity", "_scaling", "_rotation"]:
-        assert util.rel_l2(b[k], a[k]) < 2e-4, (k, util.rel_l2(b[k], a[k]))
+        assert util.rel_l2(b[k], a[k]) < 1e-4, (k, util.rel_l2(b[k], a[k]))
         assert np.abs(a[k]).max() > 0
 
 
