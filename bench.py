@@ -141,9 +141,8 @@ class _View:
     def __init__(self, eng, k, scene):
         from fateavatar_amd.model import FlatGaussians, TorchCamera
         if os.environ.get("FR_BENCH_ORDER") == "coherent":   # (diagnostic: the same Gaussians stored in a spatially coherent
-            lo, hi = scene.means3D.min(0), scene.means3D.max(0)   # order — grid cells of the bounding box, x fastest — instead of
-            c = np.minimum(((scene.means3D - lo) / np.maximum(hi - lo, 1e-12) * 32).astype(np.int64), 31)   # the metric's random one)
-            o = np.argsort(c[:, 2] * 1024 + c[:, 1] * 32 + c[:, 0], kind="stable")
+            from fateavatar_amd.scenes import spatial_order           # order (scenes.spatial_order) instead of the metric's random one)
+            o = spatial_order(scene.means3D)
             for a in ("means3D", "scales", "rotations", "opacities", "shs"):
                 setattr(scene, a, np.ascontiguousarray(getattr(scene, a)[o]))
         self.k, self.scene = k, scene
@@ -648,7 +647,7 @@ def _dp_reference_at_1(args):
     """`bench.py --exchange-at-1` as a child process (its own HIP context and one-rank RCCL group), after this process's timed
     region: the N > 1 steps at one rank.  A run that cannot produce it says why in `status`."""
     try:
-        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--opacity", str(args.opacity)] + _scene_args(args))
+        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--no-coherent", "--opacity", str(args.opacity)] + _scene_args(args))
         m = rec["dp"]["modes"]
         keys = ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")
         return {"status": "ok",
@@ -660,11 +659,27 @@ def _dp_reference_at_1(args):
         return {"status": "failed: " + repr(e)[:300]}
 
 
+def _coherent_layout(args):
+    """What a CALLER gets by storing the same Gaussians in a spatially coherent order (scenes.spatial_order; the reference's
+    UV-raster initialisation produces one): this run again as a child process with FR_BENCH_ORDER=coherent.  Not the metric's
+    scene (its order is random) and never `value`."""
+    try:
+        os.environ["FR_BENCH_ORDER"] = "coherent"
+        rec = _child_line(["--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--opacity", str(args.opacity)] + _scene_args(args))
+        return {"status": "ok", "value": rec["value"], "unit": rec["unit"], "one_frame_at_a_time": (rec.get("one_frame_at_a_time") or {}).get("value"),
+                "preprocess_fwd_us": (rec.get("stage_us") or {}).get("preprocess_fwd"),
+                "what": "the same Gaussians stored in grid-cell order (fateavatar_amd.scenes.spatial_order), same modes as `value`"}
+    except Exception as e:
+        return {"status": "failed: " + repr(e)[:300]}
+    finally:
+        os.environ.pop("FR_BENCH_ORDER", None)
+
+
 def _opaque_scene(args):
     """The operating point training moves to (opacity 0.9; config/fateavatar.yaml:40-47 prunes below 0.005, the rest
     saturates): the same scene and run, one frame at a time, as a child process — frames/s and the blend backward's launch."""
     try:
-        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque"]
+        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent"]
                           + _scene_args(args)[:-2] + ["--rounds", "1"])
         r = rec.get("roofline") or {}
         return {"status": "ok", "opacity": 0.9, "value": rec["value"], "unit": rec["unit"], "frames_in_flight": 1,
@@ -704,6 +719,9 @@ def main():
     ap.add_argument("--no-opaque", dest="opaque", action="store_false", default=True,
                     help="N = 1: do not add `opaque` (the same scene at opacity 0.9, one frame at a time, measured by a second run "
                          "of this script after the timed region)")
+    ap.add_argument("--no-coherent", dest="coherent", action="store_false", default=True,
+                    help="N = 1: do not add `coherent_layout` (the same Gaussians stored in a spatially coherent order, measured by a "
+                         "second run of this script after the timed region)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
@@ -923,6 +941,10 @@ def main():
                 dp_ref = _dp_reference_at_1(args)
         if not STUB and world == 1 and not exchanging and args.opaque and args.graph and args.opacity == 0.1:
             opaque = _opaque_scene(args)
+        coherent = None
+        if (not STUB and world == 1 and not exchanging and args.coherent and args.graph and args.scale is None
+                and os.environ.get("FR_BENCH_ORDER") is None):
+            coherent = _coherent_layout(args)
         # the like-for-like first point of a scaling curve over the N > 1 `value` (the literal step), and this run against it
         scaling_reference = efficiency = None
         if dp_ref and dp_ref.get("status") == "ok":
@@ -969,6 +991,8 @@ def main():
             "dp_reference_at_1": dp_ref,
             # the scene at opacity 0.9 (where training takes the Gaussians), one frame at a time
             "opaque": opaque,
+            # the same Gaussians in a spatially coherent storage order (what a caller's layout is worth; never `value`)
+            "coherent_layout": coherent,
             # (when `value` is the launch-chain mode) the best per-view-stream count of the calibration: a stream, a handle
             # and a graph per view, as `value` was measured until round 3
             "views_on_streams": (None if not chains or not eng.calibration else

@@ -212,3 +212,17 @@ def head_scene(P: int = 100_000, res: int = 512, sh_degree: int = 3, seed: int =
         R, T = Rn, Tn
     cam = make_camera(R, T, fov, fov, res, res)
     return GaussianScene(means, scales, rots, op, shs, sh_degree, np.ones(3, np.float32), cam)
+
+
+def spatial_order(means3D: np.ndarray, cells: int = 32) -> np.ndarray:
+    """A permutation that stores Gaussians in a spatially coherent order: grid cells of the bounding box (`cells` per axis),
+    x fastest.  The rasterizer's results do not depend on the order of its inputs, its speed does: a wave of the forward
+    preprocess handles 64 consecutive Gaussians, and when those are neighbours their (tile, Gaussian) instances share
+    tiles — the counting pass groups their atomics and their key stores coalesce (+6.5 % frames/s at BASELINE config 2
+    against a random order, EXPERIMENTS.md).  The reference's UV-raster initialisation (mesh_sampling.py:86-138) already
+    produces such an order; a caller with randomly ordered Gaussians can permute its parameter arrays once with this."""
+    m = np.asarray(means3D, np.float64)
+    lo, hi = m.min(0), m.max(0)
+    c = np.minimum(((m - lo) / np.maximum(hi - lo, 1e-12) * cells).astype(np.int64), cells - 1)
+    return np.argsort((c[:, 2] * cells + c[:, 1]) * cells + c[:, 0], kind="stable")
+
