@@ -64,8 +64,12 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# (before torch initialises the ROCm runtime: eager launches keep their kernel arguments in device memory, as replayed graphs
+# do — the roofline's isolated eager launches then see the kernel a graph replay sees; fateavatar_amd sets the same default)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
