@@ -24,8 +24,17 @@ FR_FLAG_ACCUMULATE_SHIFT = 8   # fr_backward: bit (8 + k) = add into the k-th ar
 _fp = C.c_void_p  # device pointers travel as integers
 
 
+class fr_binding(C.Structure):
+    _fields_ = [("N", C.c_int32), ("V", C.c_int32), ("F", C.c_int32), ("verts", C.c_void_p), ("faces", C.c_void_p),
+                ("face_index", C.c_void_p), ("bary", C.c_void_p), ("face_scale_canonical", C.c_void_p),
+                ("shell_len", C.c_float), ("resize_scale", C.c_int32), ("offset", C.c_void_p), ("rotation", C.c_void_p),
+                ("scaling", C.c_void_p)]
+
+
 class fr_aux(C.Structure):
-    _fields_ = [("visible", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p)]
+    _fields_ = [("visible", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("binding", C.POINTER(fr_binding)), ("d_verts", C.c_void_p), ("d_offset", C.c_void_p),
+                ("d_rotation", C.c_void_p), ("d_scaling", C.c_void_p)]
 
 
 class fr_params(C.Structure):
@@ -46,13 +55,6 @@ class fr_adam_config(C.Structure):
                 ("segment_lr", C.c_float * FR_ADAM_MAX_SEGMENTS), ("segment_period", C.c_uint32 * FR_ADAM_MAX_SEGMENTS),
                 ("segment_split", C.c_uint32 * FR_ADAM_MAX_SEGMENTS), ("segment_lr2", C.c_float * FR_ADAM_MAX_SEGMENTS),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("grad_scale", C.c_float)]
-
-
-class fr_binding(C.Structure):
-    _fields_ = [("N", C.c_int32), ("V", C.c_int32), ("F", C.c_int32), ("verts", C.c_void_p), ("faces", C.c_void_p),
-                ("face_index", C.c_void_p), ("bary", C.c_void_p), ("face_scale_canonical", C.c_void_p),
-                ("shell_len", C.c_float), ("resize_scale", C.c_int32), ("offset", C.c_void_p), ("rotation", C.c_void_p),
-                ("scaling", C.c_void_p)]
 
 
 class fr_inputs(C.Structure):

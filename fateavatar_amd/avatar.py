@@ -25,6 +25,7 @@ import torch
 
 from . import dp
 from .binding import bind_gaussians, face_scale
+from .bound import MeshBinding, render_bound_batch
 from .model import TorchCamera
 from .optim import FusedAdam
 from .rasterizer import GradOut
@@ -148,13 +149,27 @@ class _BoundFrame:
         self.fused_densification_stats = stats
 
 
+class _RawFrame:
+    """What render_bound_batch() reads: the RAW parameters of a frame whose binding the rasterizer evaluates itself."""
+    max_sh_degree = 0
+
+    def __init__(self, pc: AvatarGaussians, stats):
+        self._opacity, self._offset, self._rotation, self._scaling = pc._opacity, pc._offset, pc._rotation, pc._scaling
+        self.get_features = pc._features_dc
+        self.fused_densification_stats = stats
+
+
 class AvatarStep(TrainStep):
     """One optimisation step of FateAvatar per call: `step(camera, posed_verts, gt_image)`."""
 
     def __init__(self, pc: AvatarGaussians, faces: torch.Tensor, canonical_verts: torch.Tensor, camera: TorchCamera,
                  bg: torch.Tensor, lrs: Optional[dict] = None, shell_len: float = 0.05, resize_scale: bool = True,
-                 use_graph: bool = True):
+                 use_graph: bool = True, fold_binding: bool = True):
+        """`fold_binding` (default): the binding is evaluated inside the rasterizer's per-Gaussian kernels (bound.py,
+        fr_aux::binding) — no binding launches, no bound arrays written by one kernel to be read by the next.  False: the
+        stand-alone `bind_gaussians` op in front of `render()` (same results; kept as the A/B and as the op's own user)."""
         self.pc, self.bg = pc, bg
+        self.fold_binding = bool(fold_binding)
         self.dev = pc.flat.device
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.exchange = torch.distributed.is_initialized() and (self.world > 1 or dp.group_of_one())
@@ -194,13 +209,21 @@ class AvatarStep(TrainStep):
         _dimage, xyz_gradient_accum, denom, out: this object itself, or one lane of an AvatarBatchStep."""
         pc = L.pc
         pc.begin_step()                                             # zero_grad(set_to_none=True), iteration.py:48-49
-        xyz, rot, scl = bind_gaussians(L.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
-                                       pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
-        frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom))
-        out = render(L.cam, frame, self.bg)
+        if self.fold_binding:
+            from . import rasterizer
+            out = render_bound_batch([L.cam], [_RawFrame(pc, (L.xyz_gradient_accum, L.denom))], [L.verts], self._binding(pc),
+                                     self.bg, slots=[rasterizer._slot])[0]
+        else:
+            xyz, rot, scl = bind_gaussians(L.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
+                                           pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
+            frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom))
+            out = render(L.cam, frame, self.bg)
         _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage, workspace=L._l1_ws)   # see TrainStep
         out["render"].backward(g)
         L.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
+
+    def _binding(self, pc: AvatarGaussians) -> MeshBinding:
+        return MeshBinding(self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical, self.shell_len, self.resize_scale)
 
     def step(self, camera: TorchCamera, posed_verts: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
         self._extra_inputs = [(self.verts, posed_verts)]
@@ -419,10 +442,17 @@ class AvatarBatchStep(AvatarStep):
         frames = []
         for L in self.lanes:
             L.pc.begin_step()
+            if self.fold_binding:
+                frames.append(_RawFrame(L.pc, (L.xyz_gradient_accum, L.denom)))
+                continue
             xyz, rot, scl = bind_gaussians(L.verts, self.faces, L.pc.face_index, L.pc.bary_coords, self.face_scale_canonical,
                                            L.pc._offset, L.pc._rotation, L.pc._scaling, self.shell_len, self.resize_scale)
             frames.append(_BoundFrame(xyz, L.pc, rot, scl, (L.xyz_gradient_accum, L.denom)))
-        outs = render_batch([L.cam for L in self.lanes], frames, self.bg, slots=[L.k for L in self.lanes])
+        if self.fold_binding:
+            outs = render_bound_batch([L.cam for L in self.lanes], frames, [L.verts for L in self.lanes], self._binding(self.pc),
+                                      self.bg, slots=[L.k for L in self.lanes])
+        else:
+            outs = render_batch([L.cam for L in self.lanes], frames, self.bg, slots=[L.k for L in self.lanes])
         images, grads = [], []
         for L, out in zip(self.lanes, outs):
             _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage, workspace=L._l1_ws)

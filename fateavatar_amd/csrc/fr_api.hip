@@ -43,6 +43,14 @@ static int check_frame(const fr_params* prm, const fr_inputs* in, bool forward)
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "FR_FLAG_RAW_ACTIVATIONS needs scales + rotations");
     if (in->shs && prm->M < (prm->D + 1) * (prm->D + 1))
         return fail_msg(FR_ERR_INVALID_ARGUMENT, "M smaller than (D+1)^2");
+    if (prm->aux && prm->aux->binding) {
+        const fr_binding& b = *prm->aux->binding;
+        if (!(prm->flags & FR_FLAG_RAW_ACTIVATIONS) || !sr)
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_aux::binding needs FR_FLAG_RAW_ACTIVATIONS and scales + rotations");
+        if (b.N != prm->P || !b.verts || !b.faces || !b.face_index || !b.bary || !b.offset || !b.rotation || !b.scaling ||
+            (b.resize_scale && !b.face_scale_canonical))
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_aux::binding: N must equal P and every array must be given");
+    }
     return FR_OK;
 }
 

@@ -410,6 +410,8 @@ int ensure_accum(fr_handle_impl* h, size_t P, hipStream_t s);
 bool note_capture(fr_handle_impl* h, hipStream_t s);
 // give up a handle-owned device buffer: freed behind the stream's work, or retired if a captured graph may still name it
 int release_buffer(fr_handle_impl* h, void* p, hipStream_t s);
+struct BindArgs;
+BindArgs bind_args(const fr_binding& b);   // (fr_bind_math.hpp / fr_binding.hip)
 int launch_bind_forward(const fr_binding& b, float* xyz, float* rot, float* scale, hipStream_t s);
 int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g_rot, const float* g_scale, float* d_verts,
                          float* d_offset, float* d_rotation, float* d_scaling, hipStream_t s);

@@ -5,7 +5,7 @@
 // operation order as the reference (forward.cu:74-152,155-256; auxiliary.h:41-77), so radii,
 // pixel centres, conics, depths and colours are bit-comparable with the CPU oracle.  These
 // kernels are bandwidth-trivial; the missing FMAs cost nothing measurable.
-#include "fr_common.hpp"
+#include "fr_bind_math.hpp"
 
 namespace fr {
 
@@ -31,6 +31,8 @@ struct PreArgs {
     const float* campos;
     int* radii;
     uint8_t* visible;       // optional (fr_aux): radii > 0
+    int bound;              // fr_aux::binding: means3D / rotations / scales are WRITTEN here, from `bind`
+    BindArgs bind;
     GeomView g;
     uint32_t* tile_count;
     uint64_t* buckets;      // key buckets [tiles][8][bucket_cap]
@@ -154,12 +156,29 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
     const CameraRegs cam = load_camera(a.view, a.proj, a.campos, lane);
     const bool live = idx < a.P;
     const int li = live ? idx : 0;
-    const float3 p_orig = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
+    float3 p_orig;
     float in_sc[3] = {0.f, 0.f, 0.f}, in_rot[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.scales) in_sc[0] = a.scales[3 * li], in_sc[1] = a.scales[3 * li + 1], in_sc[2] = a.scales[3 * li + 2];
-    if (a.rotations)
-        in_rot[0] = a.rotations[4 * li], in_rot[1] = a.rotations[4 * li + 1], in_rot[2] = a.rotations[4 * li + 2],
-        in_rot[3] = a.rotations[4 * li + 3];
+    if (a.bound) {
+        // the frame comes straight from its mesh binding (model/fateavatar.py:225-258): position, rotation and log-scale
+        // of this Gaussian are evaluated here (fr_bind_forward's expressions) and stored for the backward and the caller
+        float bp[3];
+        bind_one_fwd(a.bind, li, bp, in_rot, in_sc);
+        p_orig = make_float3(bp[0], bp[1], bp[2]);
+        if (live) {
+            float* m = const_cast<float*>(a.means3D) + 3 * (size_t)li;
+            float* r = const_cast<float*>(a.rotations) + 4 * (size_t)li;
+            float* sc = const_cast<float*>(a.scales) + 3 * (size_t)li;
+            m[0] = bp[0], m[1] = bp[1], m[2] = bp[2];
+            r[0] = in_rot[0], r[1] = in_rot[1], r[2] = in_rot[2], r[3] = in_rot[3];
+            sc[0] = in_sc[0], sc[1] = in_sc[1], sc[2] = in_sc[2];
+        }
+    } else {
+        p_orig = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
+        if (a.scales) in_sc[0] = a.scales[3 * li], in_sc[1] = a.scales[3 * li + 1], in_sc[2] = a.scales[3 * li + 2];
+        if (a.rotations)
+            in_rot[0] = a.rotations[4 * li], in_rot[1] = a.rotations[4 * li + 1], in_rot[2] = a.rotations[4 * li + 2],
+            in_rot[3] = a.rotations[4 * li + 3];
+    }
     const float in_opacity = a.opacities[li];
     float sh_touch = 0.f;
     if (a.shs && !a.colors_precomp) {
@@ -721,6 +740,9 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     a.shs = in.shs, a.cov3D_precomp = in.cov3D_precomp, a.colors_precomp = in.colors_precomp;
     a.view = in.viewmatrix, a.proj = in.projmatrix, a.campos = in.campos;
     a.visible = prm.aux ? prm.aux->visible : nullptr;
+    a.bound = (prm.aux && prm.aux->binding) ? 1 : 0;
+    if (a.bound) a.bind = bind_args(*prm.aux->binding);
+    else a.bind = BindArgs{};
     a.radii = c.radii, a.g = g, a.tile_count = v.tile_count, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
     a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;

@@ -7,7 +7,7 @@
 // fr_preprocess.hip).  Every output row is written (zeros for culled Gaussians), so callers
 // need not pre-zero anything — or, per array, ADDED to what the array holds (FR_FLAG_ACCUMULATE:
 // gradient accumulation over the frames of a batch without a second buffer and an add kernel).
-#include "fr_common.hpp"
+#include "fr_bind_math.hpp"
 
 namespace fr {
 
@@ -36,6 +36,9 @@ struct PreBwdArgs {
     float* denom;       // optional (fr_aux): += 1 for visible Gaussians
     const DeviceCounts* counts;   // the frame's counts: an overflowed frame (nothing was blended) adds nothing to the statistics
     uint32_t acc;       // bit k: ADD into the k-th array of fr_grads instead of overwriting it (FR_FLAG_ACCUMULATE)
+    int bound;          // fr_aux::binding: the gradients of mean / rotation / scale continue through `bind` into `bg`
+    BindArgs bind;
+    BindGrads bg;
 };
 
 // bit positions of `acc` = position of the pointer in fr_grads
@@ -73,6 +76,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         if (!adds(G_SCALES)) store3(a.out.dL_dscales, i, 0.f, 0.f, 0.f, false);
         if (a.out.dL_drotations && !adds(G_ROTATIONS))
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
+        if (a.bound) bind_one_bwd_zero(idx, a.bg);
         return;
     }
     // accumulating arrays: what they hold is requested NOW, so that the round trip runs under the arithmetic below
@@ -287,6 +291,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         for (int k = 0; k < Mc * 3; k++) a.out.dL_dsh[i * Mc * 3 + k] = 0.f;
     }
     store3(a.out.dL_dmeans3D, i, old_m3[0] + dmx, old_m3[1] + dmy, old_m3[2] + dmz, false);
+    const float g_mean[3] = {dmx, dmy, dmz};   // (this frame's, for the binding)
+    float g_scl[3] = {0.f, 0.f, 0.f}, g_rot[4] = {0.f, 0.f, 0.f, 0.f};
 
     // ---------------- Sigma3D -> scale, quaternion (backward.cu:278-341)
     if (a.scales) {
@@ -313,11 +319,11 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         const float dsy = Rc[0][1] * dMt[1][0] + Rc[1][1] * dMt[1][1] + Rc[2][1] * dMt[1][2];
         const float dsz = Rc[0][2] * dMt[2][0] + Rc[1][2] * dMt[2][1] + Rc[2][2] * dMt[2][2];
         // raw-parameter mode: d exp = the activated scale
-        if (a.raw) store3(a.out.dL_dscales, i, old_sc[0] + dsx * sc[0], old_sc[1] + dsy * sc[1], old_sc[2] + dsz * sc[2], false);
-        else store3(a.out.dL_dscales, i, old_sc[0] + dsx, old_sc[1] + dsy, old_sc[2] + dsz, false);
+        g_scl[0] = a.raw ? dsx * sc[0] : dsx, g_scl[1] = a.raw ? dsy * sc[1] : dsy, g_scl[2] = a.raw ? dsz * sc[2] : dsz;
+        store3(a.out.dL_dscales, i, old_sc[0] + g_scl[0], old_sc[1] + g_scl[1], old_sc[2] + g_scl[2], false);
         for (int w = 0; w < 3; w++) dMt[0][w] *= s[0], dMt[1][w] *= s[1], dMt[2][w] *= s[2];
 #define Dm(c_, r_) dMt[c_][r_]
-        if (a.out.dL_drotations) {
+        if (a.out.dL_drotations || a.bound) {
             float dq[4];
             dq[0] = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
             dq[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
@@ -331,7 +337,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
                 dq[2] = (dq[2] - y * dot) * rot_inv;
                 dq[3] = (dq[3] - z * dot) * rot_inv;
             }
-            for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = old_q[k] + dq[k];
+            if (a.out.dL_drotations)
+                for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = old_q[k] + dq[k];
+            for (int k = 0; k < 4; k++) g_rot[k] = dq[k];
         }
 #undef Dm
     } else {
@@ -339,6 +347,8 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
         if (a.out.dL_drotations && !adds(G_ROTATIONS))
             for (int k = 0; k < 4; k++) a.out.dL_drotations[4 * i + k] = 0.f;
     }
+    // ---------------- through the mesh binding (model/fateavatar.py:225-258): fr_bind_backward's expressions
+    if (a.bound) bind_one_bwd(a.bind, idx, g_mean, g_rot, g_scl, a.bg);
 }
 
 // A wave's [64][row_len] block of dL_dsh rows goes from LDS to HBM in coalesced 16-byte stores (the inverse of the
@@ -463,6 +473,14 @@ int launch_backward(int n, const BackwardCall* calls, hipStream_t s)
         a.denom = prm.aux ? prm.aux->denom : nullptr;
         a.counts = v[k].counts;
         a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
+        a.bound = (prm.aux && prm.aux->binding) ? 1 : 0;
+        if (a.bound) {
+            a.bind = bind_args(*prm.aux->binding);
+            a.bg = BindGrads{prm.aux->d_verts, prm.aux->d_offset, prm.aux->d_rotation, prm.aux->d_scaling};
+        } else {
+            a.bind = BindArgs{};
+            a.bg = BindGrads{};
+        }
         const size_t l = (in.shs && calls[k].grads->dL_dsh) ? (size_t)kPreBwdWaves * 64 * ((prm.M * 3) | 1) * sizeof(float) : 0;
         lds = l > lds ? l : lds;
         blocks = max(blocks, (uint32_t)((P + wg - 1) / wg));

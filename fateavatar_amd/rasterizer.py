@@ -126,14 +126,26 @@ def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered,
     return prm
 
 
-def _aux(visible=None, grad_accum=None, denom=None):
-    """fr_aux (optional fused side outputs) from torch tensors, or None if nothing is asked for."""
-    if visible is None and grad_accum is None and denom is None:
+def _aux(visible=None, grad_accum=None, denom=None, binding=None, bind_grads=None):
+    """fr_aux (optional fused side inputs / outputs) from torch tensors, or None if nothing is asked for.  `binding`: an
+    `_lib.fr_binding` descriptor (the frame is rendered straight from its mesh binding); `bind_grads`: dict with the
+    backward's d_verts / d_offset / d_rotation / d_scaling tensors (any may be None)."""
+    if visible is None and grad_accum is None and denom is None and binding is None:
         return None
     for t, dt in ((visible, (torch.bool, torch.uint8)), (grad_accum, (torch.float32,)), (denom, (torch.float32,))):
         if t is not None and (t.dtype not in dt or not t.is_contiguous() or not t.is_cuda):
             raise RuntimeError("fused side outputs must be contiguous device tensors (bool/uint8 mask, float32 stats)")
-    return _lib.fr_aux(*(t.data_ptr() if t is not None else None for t in (visible, grad_accum, denom)))
+    aux = _lib.fr_aux(*(t.data_ptr() if t is not None else None for t in (visible, grad_accum, denom)))
+    if binding is not None:
+        aux._binding_keepalive = binding
+        aux.binding = C.pointer(binding)
+        for n in ("d_verts", "d_offset", "d_rotation", "d_scaling"):
+            t = (bind_grads or {}).get(n)
+            if t is not None:
+                if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                    raise RuntimeError(f"binding gradient {n} must be a contiguous float32 device tensor")
+                setattr(aux, n, t.data_ptr())
+    return aux
 
 
 def _inputs(bg, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
@@ -251,11 +263,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 
 # ------------------------------------------------------------------ batched frames (fr_forward_batch / fr_backward_batch)
-def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None):
+def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None, bindings=None):
     """K views through ONE launch chain (include/fr_rasterizer.h, fr_forward_batch): `views` is a list of the positional
     argument tuples of `rasterize_gaussians` (background ... debug), one per view; view k uses the device's handle
     `slots[k]` (default k).  Returns the list of `rasterize_gaussians` result tuples.  The results are those of K separate
-    calls; what changes is that every kernel of the frame is launched once for all views."""
+    calls; what changes is that every kernel of the frame is launched once for all views.
+    `bindings` (extension, fr_aux::binding): per view an `_lib.fr_binding` or None — the view's means3D / scales / rotations
+    tensors are then OUTPUTS (written by the preprocess kernel from the mesh binding)."""
     K = len(views)
     if not 1 <= K <= _lib.FR_MAX_BATCH:
         raise RuntimeError(f"rasterize_gaussians_batch: 1 .. {_lib.FR_MAX_BATCH} views")
@@ -263,12 +277,15 @@ def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None):
     if len(set(slots)) != K:
         raise RuntimeError("rasterize_gaussians_batch: the views of a batch need a handle slot each")
     visibles = visibles or [None] * K
+    bindings = bindings or [None] * K
     L = _lib.lib()
     st = []
     dev = None
     for k, a in enumerate(views):
         (background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
          tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug) = a
+        if bindings[k] is not None and not all(t.is_contiguous() and t.dtype == torch.float32 for t in (means3D, scales, rotations)):
+            raise RuntimeError("rasterize_gaussians_batch: a bound view's means3D / scales / rotations are written in place")
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         d = _dev_index(means3D)
@@ -286,7 +303,8 @@ def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None):
         M = sh.size(1) if sh.numel() != 0 else 0
         v = dict(P=P, H=H, W=W, opts=opts,
                  keep=(background, means3D, opacity, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos),
-                 prm=_params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw, _aux(visible=visibles[k])),
+                 prm=_params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered, debug, raw,
+                             _aux(visible=visibles[k], binding=bindings[k])),
                  inp=_inputs(background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos),
                  out_color=torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, **opts),
                  radii=torch.empty((P,), dtype=torch.int32, **opts),
@@ -326,15 +344,19 @@ def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None):
     return out
 
 
-def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None, outs=None, stats=None, accumulates=None):
+def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None, outs=None, stats=None, accumulates=None,
+                                       bindings=None, bind_grads=None):
     """`rasterize_gaussians_backward` for K views in ONE launch chain (fr_backward_batch): `views` is a list of its
     positional argument tuples (background ... debug); `wants` / `outs` / `stats` / `accumulates`: per-view lists of the
-    corresponding keyword arguments.  Returns the list of gradient tuples."""
+    corresponding keyword arguments.  Returns the list of gradient tuples.  `bindings` / `bind_grads` (extension,
+    fr_aux::binding): per view the descriptor the forward was given and a dict of the d_verts / d_offset / d_rotation /
+    d_scaling tensors the kernel writes (d_verts: adds)."""
     K = len(views)
     if not 1 <= K <= _lib.FR_MAX_BATCH:
         raise RuntimeError(f"rasterize_gaussians_backward_batch: 1 .. {_lib.FR_MAX_BATCH} views")
     slots = list(range(K)) if slots is None else [int(x) for x in slots]
-    wants, outs, stats, accumulates = (x or [None] * K for x in (wants, outs, stats, accumulates))
+    wants, outs, stats, accumulates, bindings, bind_grads = (x or [None] * K for x in (wants, outs, stats, accumulates, bindings,
+                                                                                      bind_grads))
     L = _lib.lib()
     st = []
     dev = None
@@ -366,7 +388,8 @@ def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None,
         viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
         dL_dout_color = _f32c(dL_dout_color)
         radii = radii.contiguous()
-        aux = _aux(grad_accum=stats[k][0], denom=stats[k][1]) if stats[k] is not None else None
+        aux = _aux(grad_accum=stats[k][0] if stats[k] is not None else None, denom=stats[k][1] if stats[k] is not None else None,
+                   binding=bindings[k], bind_grads=bind_grads[k])
         v = dict(g=g, keep=(background, means3D, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos,
                             dL_dout_color, radii, geomBuffer, binningBuffer, imageBuffer),
                  prm=_params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, raw, aux, acc_flags),

@@ -74,13 +74,31 @@ extern "C" {
  * frame outgrows are retired (kept until fr_destroy) instead of freed, so replays stay valid. */
 typedef struct fr_handle fr_handle;
 
-/* Optional fused side outputs: per-Gaussian values the caller's step otherwise derives
- * from the rasterizer's outputs with extra elementwise kernels.  Device pointers; any member may be NULL. */
+/* (defined with fr_bind_forward below) */
+typedef struct fr_binding fr_binding;
+
+/* Optional fused side inputs / outputs: per-Gaussian work the caller's step otherwise does
+ * with extra kernels around the rasterizer.  Device pointers unless stated otherwise; any member may be NULL. */
 typedef struct fr_aux {
     uint8_t* visible;   /* fr_forward  out    [P]: radii > 0, i.e. render()'s visibility_filter (render_3dgs.py:80) */
     float* grad_accum;  /* fr_backward in/out [P]: += ||dL_dmeans2D[i,:2]|| where radii > 0 — xyz_gradient_accum of
                            _add_densification_stats (model/fateavatar.py:734-737) */
     float* denom;       /* fr_backward in/out [P]: += 1 where radii > 0 (same function) */
+    /* The frame rendered straight from its MESH BINDING (model/fateavatar.py:225-258; HOST pointer to the descriptor
+     * fr_bind_forward takes, binding->N == P).  Needs FR_FLAG_RAW_ACTIVATIONS and scales + rotations.
+     * fr_forward: the per-Gaussian kernel evaluates fr_bind_forward's expressions in front of its own work — same bits —
+     * and inputs.means3D / rotations / scales are then OUTPUTS of the call: every row is written with the bound values
+     * (what the reference assigns to gaussian._xyz / _rotation / _scaling before render()); they are not read.
+     * fr_backward (same descriptor, the arrays fr_forward wrote handed back in inputs): the per-Gaussian backward
+     * continues through the binding — fr_bind_backward's expressions on the gradients it would have written to
+     * dL_dmeans3D / dL_drotations / dL_dscales (which may then be NULL) — and writes d_offset [P], d_rotation [P,4],
+     * d_scaling [P,3] (every row; zeros for culled Gaussians) and ADDS dL/dverts into d_verts [V,3] (float atomics; the
+     * caller zeroes it).  FR_FLAG_ACCUMULATE does not apply to these four. */
+    const fr_binding* binding;
+    float* d_verts;
+    float* d_offset;
+    float* d_rotation;
+    float* d_scaling;
 } fr_aux;
 
 /* Frame parameters: the scalar arguments of Rasterizer::forward/backward. */
@@ -271,7 +289,7 @@ int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src
  *   xyz = sum_k bary_k v_k + (e1 x e2) * shell_len * tanh(offset);  rotation = standardize(q_face (x) rotation);
  *   scaling = scaling + log(face_scale / face_scale_canonical)   (resize_scale != 0; unchanged otherwise).
  * All pointers are device pointers; one frame per call. */
-typedef struct fr_binding {
+struct fr_binding {
     int32_t N, V, F;
     const float* verts;                 /* [V,3] posed vertices */
     const int32_t* faces;               /* [F,3] */
@@ -283,7 +301,7 @@ typedef struct fr_binding {
     const float* offset;                /* [N]   raw: tanh is applied here */
     const float* rotation;              /* [N,4] raw quaternion (r,x,y,z) */
     const float* scaling;               /* [N,3] raw log-scale */
-} fr_binding;
+};
 int fr_face_scale(int32_t V, int32_t F, const float* verts, const int32_t* faces, float* out_scale, void* hip_stream);
 int fr_bind_forward(const fr_binding* b, float* xyz, float* rotation_out, float* scaling_out, void* hip_stream);
 /* Gradients of the three outputs in, gradients of offset / rotation / scaling out (fully written), and dL/dverts

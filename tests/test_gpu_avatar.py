@@ -401,3 +401,108 @@ def test_batch_step_survives_the_maintenance_schedule(gpu_device, chain):
     a = [float(x) for x in st.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])]
     b = [float(x) for x in st2.step([S["cams"][f] for f in fs], [S["posed"][f] for f in fs], [gts[f] for f in fs])]
     assert np.allclose(a, b, rtol=1e-4), (a, b)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_binding_inside_the_rasterizer_kernels_equals_the_binding_op(gpu_device, K):
+    """fr_aux::binding (bound.render_bound_batch: the preprocess kernels evaluate the binding, the per-Gaussian backward
+    continues through it) against `bind_gaussians` + `render_batch`: same expressions from one header, so the image, the
+    radii and the bound arrays are the same BITS, and every gradient — offset, rotation, scaling, opacity, colour, the
+    screen-space points, the densification statistics and dL/dverts — agrees to the order of float atomics."""
+    import torch
+    from fateavatar_amd.avatar import _BoundFrame, _RawFrame
+    from fateavatar_amd.binding import bind_gaussians, face_scale
+    from fateavatar_amd.bound import MeshBinding, render_bound_batch
+    from fateavatar_amd.render import render_batch
+    dev = gpu_device
+    S = _setup(dev, 20_000, 128, 4, seed=3)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    canon = face_scale(S["canon"], S["faces"].to(torch.int32))
+    g = torch.Generator().manual_seed(4)
+    base = S["make"]()
+    with torch.no_grad():
+        base._features_dc.add_(0.2)
+        base._offset.add_((0.2 * torch.randn(base.P, 1, generator=g)).to(dev))
+        base._scaling.add_((0.5 * torch.randn(base.P, 3, generator=g)).to(dev))
+        base._rotation.add_((0.5 * torch.randn(base.P, 4, generator=g)).to(dev))
+        base._opacity.add_(2.0)
+    faces = S["faces"].to(torch.int32).contiguous()
+
+    def run(folded):
+        leaves = [{n: getattr(base, n).detach().clone().requires_grad_(True) for n, _ in base.FIELDS} for _ in range(K)]
+        verts = [S["posed"][k].clone().requires_grad_(True) for k in range(K)]
+        stats = [(torch.zeros(base.P, 1, device=dev), torch.zeros(base.P, 1, device=dev)) for _ in range(K)]
+
+        class PC:
+            pass
+        pcs = []
+        for k in range(K):
+            pc = PC()
+            for n in leaves[k]:
+                setattr(pc, n, leaves[k][n])
+            pc.face_index, pc.bary_coords = base.face_index, base.bary_coords
+            pcs.append(pc)
+        cams = S["cams"][:K]
+        if folded:
+            outs = render_bound_batch(cams, [_RawFrame(pc, st) for pc, st in zip(pcs, stats)], verts,
+                                      MeshBinding(faces, base.face_index, base.bary_coords, canon, 0.05, True), bg)
+            bound = [o["bound"] for o in outs]
+        else:
+            frames, bound = [], []
+            for k in range(K):
+                xyz, rot, scl = bind_gaussians(verts[k], faces, base.face_index, base.bary_coords, canon, leaves[k]["_offset"],
+                                               leaves[k]["_rotation"], leaves[k]["_scaling"], 0.05, True)
+                frames.append(_BoundFrame(xyz, pcs[k], rot, scl, stats[k]))
+                bound.append((xyz.detach(), rot.detach(), scl.detach()))
+            outs = render_batch(cams, frames, bg)
+        loss = sum(torch.nn.functional.l1_loss(o["render"], gts[k]) for k, o in enumerate(outs))
+        loss.backward()
+        torch.cuda.synchronize()
+        return outs, bound, leaves, verts, stats
+
+    o_f, b_f, l_f, v_f, s_f = run(True)
+    o_u, b_u, l_u, v_u, s_u = run(False)
+    for k in range(K):
+        assert torch.equal(o_f[k]["render"], o_u[k]["render"]) and torch.equal(o_f[k]["radii"], o_u[k]["radii"])
+        assert torch.equal(o_f[k]["visibility_filter"], o_u[k]["visibility_filter"])
+        assert int((o_f[k]["radii"] > 0).sum()) > 1000
+        for a, b in zip(b_f[k], b_u[k]):
+            assert torch.equal(a, b)
+        for n in l_f[k]:
+            a, b = l_f[k][n].grad, l_u[k][n].grad
+            assert a is not None and b is not None and a.shape == b.shape, n
+            err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert err < 1e-5 and float(b.abs().max()) > 0, (n, err)
+        a, b = v_f[k].grad, v_u[k].grad
+        assert float((a - b).norm() / b.norm()) < 1e-5 and float(b.abs().max()) > 0
+        a, b = o_f[k]["viewspace_points"].grad, o_u[k]["viewspace_points"].grad
+        assert float((a - b).norm() / b.norm()) < 1e-5
+        assert torch.equal(s_f[k][1], s_u[k][1]) and float((s_f[k][0] - s_u[k][0]).abs().max()) <= 1e-5 * float(s_u[k][0].abs().max())
+
+
+def test_fateavatar_step_with_and_without_the_folded_binding(gpu_device):
+    """AvatarStep(fold_binding=True) (the default) follows AvatarStep(fold_binding=False) — eager and as a replayed graph."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep
+    from tests import util as _u
+    dev = gpu_device
+    S = _setup(dev, 30_000, 192, 6, seed=6)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+
+    def run(fold, use_graph):
+        pc = S["make"]()
+        st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=use_graph, fold_binding=fold)
+        losses = [float(st.step(S["cams"][it % 6], S["posed"][it % 6], gts[it % 6])) for it in range(24)]
+        torch.cuda.synchronize()
+        st.check()
+        return pc, losses, st
+
+    pc_u, loss_u, st_u = run(False, False)
+    for use_graph in (False, True):
+        pc_f, loss_f, st_f = run(True, use_graph)
+        assert (st_f._graph is not None) == use_graph
+        assert np.allclose(loss_f, loss_u, rtol=2e-2), (loss_f[-4:], loss_u[-4:])
+        assert torch.equal(st_f.denom, st_u.denom)
+        _u.assert_same_trajectory(pc_f.flat, pc_u.flat, f"folded binding, graph={use_graph}", tight=2e-2)

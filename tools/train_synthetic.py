@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--lanes", dest="chain", action="store_false",
                     help="--views-per-step K: K lanes on K streams (a graph per frame) instead of ONE launch chain on one "
                          "stream (render_batch: the default)")
+    ap.add_argument("--binding-op", action="store_true",
+                    help="FateAvatar step: the stand-alone binding kernels instead of the binding inside the rasterizer's kernels")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="--fateavatar: frames per optimisation step, rendered in flight together (the reference's batch)")
     ap.add_argument("--fateavatar", action="store_true",
@@ -88,7 +90,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, chain=True):
+def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, chain=True, fold_binding=True):
     """FateAvatar's optimisation step on the synthetic INSTA-layout sequence: the mesh-bound Gaussian
     set, its step object (AvatarStep, or AvatarBatchStep for K > 1 frames per step), cameras, posed meshes and targets
     rendered from a hidden ground-truth set.  Used by this script and by bench.py's `avatar` mode."""
@@ -123,15 +125,17 @@ def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, cha
     K = max(1, views_per_step)
     cam0 = TorchCamera(insta.camera_arrays(transform)[0], dev)
     if K == 1:
-        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=use_graph)
+        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=use_graph, fold_binding=fold_binding)
     else:   # the reference's batch of K frames per step (model/fateavatar.py:251-276), in flight together
         from fateavatar_amd.avatar import AvatarBatchStep
-        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=use_graph, chain=chain)
+        st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=use_graph, chain=chain,
+                             fold_binding=fold_binding)
     return dict(st=st, cams=cams, posed=posed_t, gts=gts, n_frames=n_frames, K=K)
 
 
 def main_fateavatar(a, rank, world, dev):
-    su = fateavatar_setup(a.P, a.res, dev, views=a.views, views_per_step=a.views_per_step, use_graph=not a.no_graph, chain=a.chain)
+    su = fateavatar_setup(a.P, a.res, dev, views=a.views, views_per_step=a.views_per_step, use_graph=not a.no_graph, chain=a.chain,
+                           fold_binding=not a.binding_op)
     st, cams, posed_t, gts, n_frames, K = su["st"], su["cams"], su["posed"], su["gts"], su["n_frames"], su["K"]
 
     def one_step(it, keep=True):
