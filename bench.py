@@ -455,6 +455,7 @@ class HipEngine:
                     "ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(world * args.steps / dt, 2), "unit": "frames/s",
                     "steps_per_s": round(args.steps / dt, 2), "allreduce_payload_bytes": 12 * args.P * 4,
                     "exchange_in_graph": bool(getattr(st, "exchange_in_graph", False)), "sh_degree": 0,
+                    "binding": "inside the per-Gaussian kernels (fr_aux::binding)",
                     "step": "bind + render + L1 + backward + all-reduce(AVG) of the 'gs' group + densification statistics + Adam"}
         except Exception as e:   # (the headline modes must not be lost to this one)
             return {"status": "failed: " + repr(e)[:300]}

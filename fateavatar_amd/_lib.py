@@ -74,7 +74,7 @@ class fr_counts(C.Structure):
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",
            "fr_binning_bytes", "fr_forward", "fr_forward_batch", "fr_read_counts", "fr_backward", "fr_backward_batch", "fr_mark_visible", "fr_image_final_T",
-           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_adam_step_multi", "fr_l1_workspace_bytes", "fr_l1_loss_grad", "fr_multi_copy", "fr_scaled_sum", "fr_face_scale",
+           "fr_image_n_contrib", "fr_debug_geometry_field", "fr_debug_selftest_reduce", "fr_knn_workspace_bytes", "fr_knn_mean_dist2", "fr_knn_nearest_dist2", "fr_adam_step", "fr_adam_step_multi", "fr_l1_workspace_bytes", "fr_l1_loss_grad", "fr_l1_loss_grad_batch", "fr_multi_copy", "fr_scaled_sum", "fr_face_scale",
            "fr_bind_forward", "fr_bind_backward"]
 
 
@@ -166,6 +166,8 @@ def lib():
     L.fr_l1_workspace_bytes.restype = C.c_size_t
     L.fr_l1_loss_grad.argtypes = [C.c_uint64, _fp, _fp, _fp, _fp, C.c_void_p, C.c_void_p]
     L.fr_l1_loss_grad.restype = C.c_int
+    L.fr_l1_loss_grad_batch.argtypes = [C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fr_l1_loss_grad_batch.restype = C.c_int
     L.fr_multi_copy.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
     L.fr_multi_copy.restype = C.c_int
     L.fr_scaled_sum.argtypes = [C.c_int32, C.POINTER(C.c_void_p), _fp, C.c_uint64, C.c_float, C.c_void_p]

@@ -453,11 +453,11 @@ class AvatarBatchStep(AvatarStep):
                                       self.bg, slots=[L.k for L in self.lanes])
         else:
             outs = render_batch([L.cam for L in self.lanes], frames, self.bg, slots=[L.k for L in self.lanes])
-        images, grads = [], []
+        from .loss import l1_loss_and_grad_batch
+        images = [out["render"] for out in outs]
+        _, grads = l1_loss_and_grad_batch(images, [L.gt for L in self.lanes], [L.loss for L in self.lanes],
+                                          [L._dimage for L in self.lanes], [L._l1_ws for L in self.lanes])
         for L, out in zip(self.lanes, outs):
-            _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage, workspace=L._l1_ws)
-            images.append(out["render"])
-            grads.append(g)
             L.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
         torch.autograd.backward(images, grad_tensors=grads)
         flat = [L.pc.collect_grads() for L in self.lanes]

@@ -426,6 +426,22 @@ int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, 
     return launch_l1_loss_grad(n, img, gt, grad, loss, workspace, static_cast<hipStream_t>(stream));
 }
 
+int fr_l1_loss_grad_batch(int32_t n_images, uint64_t n, const float* const* img, const float* const* gt, float* const* grad,
+                          float* const* loss, void* const* workspace, void* stream)
+{
+    if (n_images < 1 || n_images > kMaxBatch) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad_batch: 1 .. FR_MAX_BATCH images");
+    if (!img || !gt || !loss || !workspace) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad_batch: null argument array");
+    for (int k = 0; k < n_images; k++) {
+        if (n > 0 && (!img[k] || !gt[k] || !loss[k] || !workspace[k]))
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad_batch: null array");
+        if ((reinterpret_cast<uintptr_t>(img[k]) | reinterpret_cast<uintptr_t>(gt[k]) | (grad ? reinterpret_cast<uintptr_t>(grad[k]) : 0)) & 15)
+            return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad_batch: arrays must be 16-byte aligned");
+        for (int j = 0; j < k; j++)
+            if (workspace[j] == workspace[k]) return fail_msg(FR_ERR_INVALID_ARGUMENT, "fr_l1_loss_grad_batch: one workspace per image");
+    }
+    return launch_l1_loss_grad_batch(n_images, n, img, gt, grad, loss, workspace, static_cast<hipStream_t>(stream));
+}
+
 int fr_multi_copy(int32_t n_segments, float* const* dst, const float* const* src, const uint64_t* count, void* stream)
 {
     if (n_segments < 0 || n_segments > FR_COPY_MAX_SEGMENTS || (n_segments > 0 && (!dst || !src || !count)))

@@ -418,6 +418,8 @@ int launch_bind_backward(const fr_binding& b, const float* g_xyz, const float* g
 int launch_face_scale(int F, const float* verts, const int* faces, float* out, hipStream_t s);
 int launch_adam(const fr_adam_config& cfg, float* param, const float* const* grad_bufs, int n_grads, float* exp_avg,
                 float* exp_avg_sq, unsigned long long n, float* state, hipStream_t s);
+int launch_l1_loss_grad_batch(int n_images, unsigned long long n, const float* const* img, const float* const* gt, float* const* grad,
+                              float* const* loss, void* const* workspace, hipStream_t s);
 int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                         hipStream_t s);
 int launch_scaled_sum(int n_src, const float* const* src, float* dst, unsigned long long count, float scale, hipStream_t s);

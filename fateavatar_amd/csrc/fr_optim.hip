@@ -154,10 +154,23 @@ int launch_adam(const fr_adam_config& cfg, float* param, const float* const* gra
 // pass; the workgroup that finishes last adds the partials up in index order (deterministic) and stores the loss.
 constexpr unsigned kL1MaxBlocks = 1024;
 
-__global__ void __launch_bounds__(256) k_l1_loss_grad(const float* __restrict__ img, const float* __restrict__ gt,
-                                                      float* __restrict__ grad, unsigned long long n, float inv_n,
-                                                      float* partial, unsigned* counter, float* __restrict__ loss)
+struct L1View {   // one image of a (possibly batched) launch
+    const float* img;
+    const float* gt;
+    float* grad;
+    float* partial;
+    unsigned* counter;
+    float* loss;
+};
+
+__device__ __forceinline__ void l1_loss_grad_body(const L1View& v, unsigned long long n, float inv_n)
 {
+    const float* __restrict__ img = v.img;
+    const float* __restrict__ gt = v.gt;
+    float* __restrict__ grad = v.grad;
+    float* const partial = v.partial;
+    unsigned* const counter = v.counter;
+    float* __restrict__ loss = v.loss;
     __shared__ float s_red[4];
     __shared__ bool s_last;
     const unsigned long long n4 = n / 4, stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -200,6 +213,13 @@ __global__ void __launch_bounds__(256) k_l1_loss_grad(const float* __restrict__ 
     if (threadIdx.x == 0) *loss = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_n;
 }
 
+__global__ void __launch_bounds__(256) k_l1_loss_grad(L1View v, unsigned long long n, float inv_n) { l1_loss_grad_body(v, n, inv_n); }
+// the images of the frames of a batch (same size), one workspace each: grid (x, images)
+__global__ void __launch_bounds__(256) k_l1_loss_grad_batch(BatchOf<L1View> b, unsigned long long n, float inv_n)
+{
+    l1_loss_grad_body(b.v[blockIdx.y], n, inv_n);
+}
+
 int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                         hipStream_t s)
 {
@@ -208,8 +228,26 @@ int launch_l1_loss_grad(unsigned long long n, const float* img, const float* gt,
     blocks = blocks < 1 ? 1 : (blocks > kL1MaxBlocks ? kL1MaxBlocks : blocks);
     unsigned* counter = static_cast<unsigned*>(workspace);
     float* partial = reinterpret_cast<float*>(counter + (kDoneGroups + 1) * kDoneStride);
-    hipLaunchKernelGGL(k_l1_loss_grad, dim3((unsigned)blocks), dim3(256), 0, s, img, gt, grad, n, (float)(1.0 / (double)n),
-                       partial, counter, loss);
+    hipLaunchKernelGGL(k_l1_loss_grad, dim3((unsigned)blocks), dim3(256), 0, s, L1View{img, gt, grad, partial, counter, loss}, n,
+                       (float)(1.0 / (double)n));
+    FR_HIP(hipGetLastError());
+    return FR_OK;
+}
+
+int launch_l1_loss_grad_batch(int n_images, unsigned long long n, const float* const* img, const float* const* gt, float* const* grad,
+                              float* const* loss, void* const* workspace, hipStream_t s)
+{
+    if (n == 0 || n_images <= 0) return FR_OK;
+    unsigned long long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > kL1MaxBlocks ? kL1MaxBlocks : blocks);
+    BatchOf<L1View> b;
+    for (int k = 0; k < kMaxBatch; k++) {
+        const int j = k < n_images ? k : 0;   // (unused entries: never indexed, blockIdx.y < n_images)
+        unsigned* counter = static_cast<unsigned*>(workspace[j]);
+        b.v[k] = L1View{img[j], gt[j], grad ? grad[j] : nullptr, reinterpret_cast<float*>(counter + (kDoneGroups + 1) * kDoneStride),
+                        counter, loss[j]};
+    }
+    hipLaunchKernelGGL(k_l1_loss_grad_batch, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, s, b, n, (float)(1.0 / (double)n));
     FR_HIP(hipGetLastError());
     return FR_OK;
 }

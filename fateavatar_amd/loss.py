@@ -68,6 +68,34 @@ def l1_loss_and_grad(img: torch.Tensor, gt: torch.Tensor, loss_out: Optional[tor
     return loss, grad
 
 
+def l1_loss_and_grad_batch(imgs, gts, loss_outs, grad_outs, workspaces):
+    """`l1_loss_and_grad` for the images of the 1 .. 4 frames of a batch in ONE launch (`fr_l1_loss_grad_batch`): lists of
+    equally-sized contiguous float32 device tensors; every image has its own loss scalar, gradient buffer and workspace
+    (`l1_workspace()`).  Returns (loss_outs, grad_outs)."""
+    import ctypes as C
+    K = len(imgs)
+    if not (1 <= K <= _lib.FR_MAX_BATCH and len(gts) == len(loss_outs) == len(grad_outs) == len(workspaces) == K):
+        raise RuntimeError(f"l1_loss_and_grad_batch: 1 .. {_lib.FR_MAX_BATCH} images, one gt / loss / grad / workspace each")
+    imgs = [i.detach() for i in imgs]
+    dev, n = imgs[0].device, imgs[0].numel()
+    for t in list(imgs) + list(gts) + list(grad_outs):
+        if not t.is_cuda:
+            raise RuntimeError("l1_loss_and_grad_batch needs device tensors (there is no CPU path)")
+        if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("l1_loss_and_grad_batch: contiguous float32 tensors of one device and one size")
+    L = _lib.lib()
+    for w, l in zip(workspaces, loss_outs):
+        if not (w.is_cuda and w.device == dev and w.dtype == torch.uint8 and w.numel() >= L.fr_l1_workspace_bytes()) or l.numel() != 1:
+            raise RuntimeError("l1_loss_and_grad_batch: workspaces from l1_workspace(), one-element loss tensors")
+    arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])  # noqa: E731
+    with torch.cuda.device(dev):
+        rc = L.fr_l1_loss_grad_batch(K, n, arr(imgs), arr(gts), arr(grad_outs), arr(loss_outs), arr(workspaces),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    if rc != _lib.FR_OK:
+        raise RuntimeError(f"fr_l1_loss_grad_batch failed: {_lib.last_error()}")
+    return loss_outs, grad_outs
+
+
 def multi_copy(pairs) -> None:
     """`dst.copy_(src)` for up to twelve (dst, src) pairs of contiguous float32 device tensors in ONE launch
     (`fr_multi_copy`): the per-frame inputs of a captured step (of every frame of a batch)."""

@@ -271,6 +271,11 @@ int fr_adam_step_multi(const fr_adam_config* cfg, float* param, const float* con
 size_t fr_l1_workspace_bytes(void);
 int fr_l1_loss_grad(uint64_t n, const float* img, const float* gt, float* grad, float* loss, void* workspace,
                     void* hip_stream);
+/* The same for the n_images (1 .. FR_MAX_BATCH) images of the frames of a batch (n floats each; the reference's batch loop,
+ * model/fateavatar.py:251-276 with train/loss.py:92-105) in ONE launch: image k has its own gt / grad / loss / workspace
+ * (distinct workspaces).  `grad` may be NULL (no gradients), or hold NULL entries. */
+int fr_l1_loss_grad_batch(int32_t n_images, uint64_t n, const float* const* img, const float* const* gt, float* const* grad,
+                          float* const* loss, void* const* workspace, void* hip_stream);
 
 /* ---- dst = scale * (src[0] + ... + src[n_src - 1]), n_src in 1 .. FR_ADAM_MAX_GRADS arrays of `count` floats, 16-byte
  * aligned: the mean of the gradient buffers of the views a rank rendered in flight together, written into the exchange

@@ -29,6 +29,30 @@ def test_l1_loss_and_grad_matches_autograd(gpu_device, shape):
     assert l2.data_ptr() == lo.data_ptr() and g2.data_ptr() == go.data_ptr() and torch.equal(go, ref_in.grad)
 
 
+@pytest.mark.parametrize("K,shape", [(1, (3, 64, 64)), (3, (3, 512, 512)), (4, (3, 37, 53))])
+def test_l1_of_the_frames_of_a_batch_in_one_launch(gpu_device, K, shape):
+    """fr_l1_loss_grad_batch == K calls of fr_l1_loss_grad: the same loss BITS (same partial sums, same order) and the same
+    gradients, repeatedly (the workspaces come back zeroed), and distinct workspaces are enforced."""
+    from fateavatar_amd.loss import l1_loss_and_grad, l1_loss_and_grad_batch, l1_workspace
+    g = torch.Generator(device="cpu").manual_seed(K + sum(shape))
+    imgs = [torch.rand(shape, generator=g).to(gpu_device) for _ in range(K)]
+    gts = [torch.rand(shape, generator=g).to(gpu_device) for _ in range(K)]
+    for a, b in zip(imgs, gts):
+        b.view(-1)[::5] = a.view(-1)[::5]
+    ref = [l1_loss_and_grad(a, b) for a, b in zip(imgs, gts)]
+    losses = [torch.zeros((), device=gpu_device) for _ in range(K)]
+    grads = [torch.full(shape, 7.0, device=gpu_device) for _ in range(K)]
+    wss = [l1_workspace(gpu_device) for _ in range(K)]
+    for _ in range(3):
+        l1_loss_and_grad_batch(imgs, gts, losses, grads, wss)
+        torch.cuda.synchronize()
+        for k in range(K):
+            assert torch.equal(losses[k], ref[k][0]) and torch.equal(grads[k], ref[k][1])
+    if K > 1:
+        with pytest.raises(RuntimeError, match="one workspace per image"):
+            l1_loss_and_grad_batch(imgs, gts, losses, grads, [wss[0]] * K)
+
+
 def test_l1_gradient_drives_the_rasterizer_backward(gpu_device):
     """render.backward(grad) with the fused gradient = l1_loss(render, gt).backward(): same parameter gradients."""
     from fateavatar_amd import scenes

@@ -140,6 +140,25 @@ def test_mesh_binding_refuses_cpu_tensors():
                        z(5, 3), 0.01)
 
 
+def test_frames_rendered_from_their_binding_refuse_cpu_tensors_and_bad_shapes():
+    """bound.render_bound_batch (fr_aux::binding) has no CPU path either, and counts its views."""
+    import types
+    import pytest
+    import torch
+    from fateavatar_amd.bound import MeshBinding, render_bound_batch
+    from fateavatar_amd.scenes import look_at_camera
+    from fateavatar_amd.model import TorchCamera
+    z = torch.zeros
+    pc = types.SimpleNamespace(_opacity=z(5, 1), _offset=z(5, 1), _rotation=z(5, 4), _scaling=z(5, 3), get_features=z(5, 1, 3),
+                               max_sh_degree=0)
+    mb = MeshBinding(z(2, 3, dtype=torch.int32), z(5, dtype=torch.int32), z(5, 3), z(2, 1), 0.01, True)
+    cam = TorchCamera(look_at_camera((0, 0, 2.0), (0, 0, 0), (0, 1, 0), 0.6, 0.6, 32, 32), torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        render_bound_batch([cam], pc, z(4, 3), mb, torch.ones(3))
+    with pytest.raises(RuntimeError, match="1 .. 4 views"):
+        render_bound_batch([cam] * 5, pc, z(4, 3), mb, torch.ones(3))
+
+
 def test_reference_render_runs_against_the_alias_packages_up_to_the_device_boundary():
     """The reference's OWN volume_rendering/render_3dgs.py (imported from the read-only checkout, present only in the
     build container) must import against the alias package and drive it with its keyword arguments; on CPU tensors the

@@ -169,6 +169,7 @@ def main_fateavatar(a, rank, world, dev):
         l = [float(x) for x in losses]
         print(json.dumps({"host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4),
                           "metric": "FateAvatar optimisation steps/s (bind + render + L1 + backward + stats + Adam)",
+                          "binding": "stand-alone kernels" if a.binding_op else "inside the per-Gaussian kernels (fr_aux::binding)",
                           "value": round(a.steps / dt, 1), "frames_per_s": round(world * K * a.steps / dt, 1), "n_gpus": world,
                           "views_per_step": K, "launch_chain": bool(a.chain) if K > 1 else None,
                           "ms_per_step": round(dt / a.steps * 1e3, 4), "P": a.P, "res": a.res, "frames": n_frames, "sh_degree": 0,
