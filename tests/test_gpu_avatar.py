@@ -506,3 +506,89 @@ def test_fateavatar_step_with_and_without_the_folded_binding(gpu_device):
         assert np.allclose(loss_f, loss_u, rtol=2e-2), (loss_f[-4:], loss_u[-4:])
         assert torch.equal(st_f.denom, st_u.denom)
         _u.assert_same_trajectory(pc_f.flat, pc_u.flat, f"folded binding, graph={use_graph}", tight=2e-2)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_binding_inside_the_kernels_on_random_configurations(gpu_device, seed):
+    """The same equality (test_binding_inside_the_rasterizer_kernels_equals_the_binding_op) over random sizes: Gaussian
+    counts that do not fill a wave or a workgroup (down to ONE), odd image sizes, 1 - 4 views, with and without
+    resize_scale, perturbed meshes (thin and nearly degenerate faces), random shell lengths."""
+    import torch
+    from fateavatar_amd import mesh_sampling, scenes
+    from fateavatar_amd.avatar import _BoundFrame, _RawFrame
+    from fateavatar_amd.binding import bind_gaussians, face_scale
+    from fateavatar_amd.bound import MeshBinding, render_bound_batch
+    from fateavatar_amd.model import TorchCamera
+    from fateavatar_amd.render import render_batch
+    dev = gpu_device
+    rng = np.random.default_rng(1000 + seed)
+    P = int([1, 63, 257, 4097, 900, 12000, 30000, 2][seed])
+    H, W = int(rng.integers(9, 200)), int(rng.integers(9, 200))
+    K = int(rng.integers(1, 5))
+    resize = bool(seed % 3 != 1)
+    shell = float(rng.uniform(0.0, 0.2))
+    verts, faces, _ = scenes.head_geometry()
+    faces = faces.astype(np.int32)
+    fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, rng)
+    canon_v = torch.from_numpy(verts).to(dev)
+    faces_t = torch.from_numpy(faces).to(dev)
+    canon = face_scale(canon_v, faces_t) if resize else None
+    fi_t = torch.from_numpy(np.asarray(fi, np.int32)).to(dev)
+    bc_t = torch.from_numpy(np.asarray(bc, np.float32)).to(dev)
+    g = torch.Generator().manual_seed(seed)
+    base = dict(_opacity=torch.randn(P, 1, generator=g) + 1.0, _offset=0.5 * torch.randn(P, 1, generator=g),
+                _features_dc=torch.rand(P, 1, 3, generator=g) * 2 - 1, _rotation=torch.randn(P, 4, generator=g),
+                _scaling=float(np.log(0.004)) + 0.7 * torch.randn(P, 3, generator=g))
+    cams, posed = [], []
+    for k in range(K):
+        ctr = verts.mean(0)
+        eye = ctr + np.array([0.3 * rng.uniform(-1, 1), 0.2 * rng.uniform(-1, 1), 0.9 + 0.2 * rng.uniform(-1, 1)], np.float32)
+        cams.append(TorchCamera(scenes.look_at_camera(eye, ctr, (0, 1, 0), 0.6, 0.6 * H / W, H, W), dev))
+        v = verts * (1.0 + 0.1 * rng.uniform(-1, 1)) + 0.03 * rng.standard_normal(verts.shape).astype(np.float32)
+        if seed % 2:   # squash: thin, nearly degenerate faces
+            v[:, 2] *= 1e-3
+        posed.append(torch.from_numpy(v.astype(np.float32)).to(dev))
+    bg = torch.tensor(rng.uniform(0, 1, 3).astype(np.float32), device=dev)
+    dimg = [torch.from_numpy((rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)).to(dev) for _ in range(K)]
+
+    def run(folded):
+        leaves = [{n: t.clone().to(dev).requires_grad_(True) for n, t in base.items()} for _ in range(K)]
+        vs = [p.clone().requires_grad_(True) for p in posed]
+
+        class PC:
+            pass
+        pcs = []
+        for k in range(K):
+            pc = PC()
+            for n in leaves[k]:
+                setattr(pc, n, leaves[k][n])
+            pcs.append(pc)
+        if folded:
+            outs = render_bound_batch(cams, [_RawFrame(pc, None) for pc in pcs], vs, MeshBinding(faces_t, fi_t, bc_t, canon, shell, resize), bg)
+            bound = [o["bound"] for o in outs]
+        else:
+            frames, bound = [], []
+            for k in range(K):
+                xyz, rot, scl = bind_gaussians(vs[k], faces_t, fi_t, bc_t, canon, leaves[k]["_offset"], leaves[k]["_rotation"],
+                                               leaves[k]["_scaling"], shell, resize)
+                frames.append(_BoundFrame(xyz, pcs[k], rot, scl, None))
+                bound.append((xyz.detach(), rot.detach(), scl.detach()))
+            outs = render_batch(cams, frames, bg)
+        torch.autograd.backward([o["render"] for o in outs], grad_tensors=dimg)
+        torch.cuda.synchronize()
+        return outs, bound, leaves, vs
+
+    o_f, b_f, l_f, v_f = run(True)
+    o_u, b_u, l_u, v_u = run(False)
+    close = lambda a, b: float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12  # noqa: E731
+    for k in range(K):
+        assert torch.equal(o_f[k]["render"], o_u[k]["render"]) and torch.equal(o_f[k]["radii"], o_u[k]["radii"]), (seed, k)
+        for a, b in zip(b_f[k], b_u[k]):
+            assert torch.equal(a, b), (seed, k)
+        for n in l_f[k]:
+            assert close(l_f[k][n].grad, l_u[k][n].grad), (seed, k, n)
+        assert close(v_f[k].grad, v_u[k].grad), (seed, k, "verts")
+        assert close(o_f[k]["viewspace_points"].grad, o_u[k]["viewspace_points"].grad), (seed, k)
+    if P >= 63:   # (the views do look at the Gaussians: the equalities above are not vacuous)
+        assert all(int((o["radii"] > 0).sum()) > P // 4 for o in o_u)
+        assert all(float(l["_rotation"].grad.abs().max()) > 0 and float(v.grad.abs().max()) > 0 for l, v in zip(l_u, v_u))
