@@ -119,12 +119,18 @@ class AvatarGaussians(torch.nn.Module):
         return self.flat_grad
 
     @torch.no_grad()
-    def resize(self, keep_mask=None, new_rows=None, new_face_index=None, new_bary=None):
-        """Drop the rows where keep_mask is False, then append `new_rows` (one tensor per field) with their binding.
+    def resize(self, keep_mask=None, new_rows=None, new_face_index=None, new_bary=None, order=None):
+        """Drop the rows where keep_mask is False — or take the rows in the sequence `order` (row indices: a permutation
+        re-stores the set in another order) —, then append `new_rows` (one tensor per field) with their binding.
         Returns the row map (old row of every new row, -1 for appended ones) the optimizer state has to follow."""
         dev = self.flat.device
-        keep = torch.ones(self.P, dtype=torch.bool, device=dev) if keep_mask is None else keep_mask.reshape(-1).bool()
-        old_index = torch.nonzero(keep).reshape(-1)
+        if order is not None:
+            if keep_mask is not None:
+                raise ValueError("resize: keep_mask or order, not both")
+            old_index = order.to(dev, torch.int64).reshape(-1)
+        else:
+            keep = torch.ones(self.P, dtype=torch.bool, device=dev) if keep_mask is None else keep_mask.reshape(-1).bool()
+            old_index = torch.nonzero(keep).reshape(-1)
         raw = [getattr(self, name).detach()[old_index] for name, _ in self.FIELDS]
         fi, bc = self.face_index[old_index], self.bary_coords[old_index]
         n_new = 0
@@ -164,12 +170,18 @@ class AvatarStep(TrainStep):
 
     def __init__(self, pc: AvatarGaussians, faces: torch.Tensor, canonical_verts: torch.Tensor, camera: TorchCamera,
                  bg: torch.Tensor, lrs: Optional[dict] = None, shell_len: float = 0.05, resize_scale: bool = True,
-                 use_graph: bool = True, fold_binding: bool = True):
-        """`fold_binding` (default): the binding is evaluated inside the rasterizer's per-Gaussian kernels (bound.py,
+                 use_graph: bool = True, fold_binding: bool = True, keep_coherent: bool = False):
+        """`keep_coherent`: after every `uv_densify` the rows are re-stored in a spatially coherent order (`sort_coherent`):
+        the reference appends the new rows at the end (model/fateavatar.py:640-665), so a set that started in UV-raster
+        order (mesh_sampling.py:86-138: neighbours in storage are neighbours on the mesh) grows an unordered tail; the
+        results do not depend on the order, the rasterizer's speed does.  Off by default: row i then stays
+        row i as in the reference.
+        `fold_binding` (default): the binding is evaluated inside the rasterizer's per-Gaussian kernels (bound.py,
         fr_aux::binding) — no binding launches, no bound arrays written by one kernel to be read by the next.  False: the
         stand-alone `bind_gaussians` op in front of `render()` (same results; kept as the A/B and as the op's own user)."""
         self.pc, self.bg = pc, bg
         self.fold_binding = bool(fold_binding)
+        self.keep_coherent = bool(keep_coherent)
         self.dev = pc.flat.device
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.exchange = torch.distributed.is_initialized() and (self.world > 1 or dp.group_of_one())
@@ -183,6 +195,7 @@ class AvatarStep(TrainStep):
         self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
         self.denom = torch.zeros((pc.P, 1), device=self.dev)
         self.cam = camera
+        self.canon_verts = canonical_verts.to(self.dev, torch.float32).clone().contiguous()
         self.verts = canonical_verts.to(self.dev, torch.float32).clone().contiguous()   # static input of the captured step
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
@@ -278,7 +291,34 @@ class AvatarStep(TrainStep):
         self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
         self.denom = torch.zeros((pc.P, 1), device=self.dev)
         self.last_densify = (idx, new_bary)
+        if self.keep_coherent:
+            AvatarStep.sort_coherent(self)     # (a subclass's lanes are rebuilt by its own uv_densify)
         return increase_num
+
+    @torch.no_grad()
+    def coherent_order(self, cells: int = 32) -> torch.Tensor:
+        """Row indices in a spatially coherent sequence: grid cells (`cells` per axis, x fastest) of the Gaussians' points
+        on the CANONICAL mesh (barycentric points: the posed offsets are small against a cell) — scenes.spatial_order on
+        the device, deterministic (stable sort), so identical on every rank of a data-parallel run."""
+        pc = self.pc
+        tri = self.canon_verts[self.faces.long()[pc.face_index.long()]]                 # [P,3,3]
+        pts = (tri * pc.bary_coords.unsqueeze(-1)).sum(1).double()
+        lo, hi = pts.min(0).values, pts.max(0).values
+        c = ((pts - lo) / (hi - lo).clamp_min(1e-12) * cells).long().clamp_(max=cells - 1)
+        return torch.argsort((c[:, 2] * cells + c[:, 1]) * cells + c[:, 0], stable=True)
+
+    @torch.no_grad()
+    def sort_coherent(self, cells: int = 32) -> torch.Tensor:
+        """Re-store the Gaussians (parameters, binding, Adam moments, densification statistics) in `coherent_order`.
+        Returns the order applied (old row of every new row)."""
+        pc = self.pc
+        order = self.coherent_order(cells)
+        old_rows = pc.P
+        acc, den = self.xyz_gradient_accum[order], self.denom[order]
+        old_index = pc.resize(order=order)
+        self._rebind_optimizer(old_index, old_rows)
+        self.xyz_gradient_accum, self.denom = acc.contiguous(), den.contiguous()
+        return order
 
     @torch.no_grad()
     def prune_low_opacity(self, min_opacity: float = 0.005) -> int:
@@ -616,6 +656,13 @@ class AvatarBatchStep(AvatarStep):
     def reset_opacity(self) -> None:
         torch.cuda.synchronize()
         super().reset_opacity()          # in place: the lanes' leaves see it (shared storage), their graphs stay valid
+
+    def sort_coherent(self, cells: int = 32):
+        torch.cuda.synchronize()
+        self._fold_stats()
+        order = super().sort_coherent(cells)
+        self._build_lanes()
+        return order
 
     def load_state_dict(self, sd: dict) -> list:
         torch.cuda.synchronize()

@@ -592,3 +592,66 @@ def test_binding_inside_the_kernels_on_random_configurations(gpu_device, seed):
     if P >= 63:   # (the views do look at the Gaussians: the equalities above are not vacuous)
         assert all(int((o["radii"] > 0).sum()) > P // 4 for o in o_u)
         assert all(float(l["_rotation"].grad.abs().max()) > 0 and float(v.grad.abs().max()) > 0 for l, v in zip(l_u, v_u))
+
+
+def test_restoring_the_gaussians_in_a_coherent_order_changes_no_result(gpu_device):
+    """AvatarStep.sort_coherent(): parameters, binding, Adam moments and densification statistics are permuted together, so
+    a run that re-stores its Gaussians half-way ends where the untouched run ends (row for row through the permutation, to
+    the order of float atomics) — and `keep_coherent` does it after every uv_densify."""
+    import torch
+    from fateavatar_amd.avatar import AvatarStep
+    from tests import util as _u
+    dev = gpu_device
+    S = _setup(dev, 20_000, 160, 6, seed=9)
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+
+    def run(sort_at, use_graph):
+        pc = S["make"]()
+        st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=use_graph)
+        order = None
+        for it in range(12):
+            if it == sort_at:
+                order = st.sort_coherent()
+            st.step(S["cams"][it % 6], S["posed"][it % 6], gts[it % 6])
+        torch.cuda.synchronize()
+        st.check()
+        return pc, st, order
+
+    pc_a, st_a, _ = run(None, False)
+    for use_graph in (False, True):
+        pc_b, st_b, order = run(5, use_graph)
+        assert sorted(order.tolist()) == list(range(pc_a.P)) and not torch.equal(order, torch.arange(pc_a.P, device=dev))
+        assert torch.equal(st_b.coherent_order(), torch.arange(pc_b.P, device=dev))          # stored sorted now
+        assert torch.equal(pc_b.face_index, pc_a.face_index[order]) and torch.equal(pc_b.bary_coords, pc_a.bary_coords[order])
+        assert torch.equal(st_b.denom, st_a.denom[order])
+        for n, _ in pc_a.FIELDS:
+            a, b = getattr(pc_a, n).detach()[order], getattr(pc_b, n).detach()
+            _u.assert_same_trajectory(b.reshape(-1), a.reshape(-1), f"{n}, graph={use_graph}", tight=2e-2)
+        assert st_b.adam.step_count == st_a.adam.step_count == 12
+
+    # keep_coherent: the set after a densification is the reference's set, stored sorted
+    g1, g2 = torch.Generator(device=dev).manual_seed(3), torch.Generator(device=dev).manual_seed(3)
+    pcs, sts = [], []
+    for keep, g in ((False, g1), (True, g2)):
+        pc = S["make"]()
+        st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, keep_coherent=keep)
+        for it in range(4):
+            st.step(S["cams"][it % 6], S["posed"][it % 6], gts[it % 6])
+        st.uv_densify(1500, generator=g)
+        for it in range(4):
+            st.step(S["cams"][it % 6], S["posed"][it % 6], gts[it % 6])
+        torch.cuda.synchronize()
+        st.check()
+        pcs.append(pc)
+        sts.append(st)
+    assert pcs[0].P == pcs[1].P == 21_500
+    key = lambda pc: torch.stack([pc.face_index.double(), pc.bary_coords[:, 0].double(), pc.bary_coords[:, 1].double()], 1)  # noqa: E731
+    ka, kb = key(pcs[0]), key(pcs[1])
+    ia = torch.from_numpy(np.lexsort(ka.cpu().numpy().T[::-1])).to(dev)
+    ib = torch.from_numpy(np.lexsort(kb.cpu().numpy().T[::-1])).to(dev)
+    assert torch.equal(ka[ia], kb[ib])                                                        # the same bound set
+    assert torch.equal(sts[1].coherent_order(), torch.arange(21_500, device=dev))
+    assert not torch.equal(sts[0].coherent_order(), torch.arange(21_500, device=dev))
+    _u.assert_same_trajectory(pcs[1]._opacity.detach().reshape(-1)[ib], pcs[0]._opacity.detach().reshape(-1)[ia], "densified",
+                              tight=2e-2)

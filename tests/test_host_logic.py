@@ -130,6 +130,31 @@ def test_flat_gaussians_resize_row_map():
         assert torch.equal(p[:7], old[n][keep]) and torch.equal(p[7:], old[n][[2, 5]])
 
 
+def test_avatar_gaussians_can_be_restored_in_another_order():
+    """AvatarGaussians.resize(order=...): a permutation re-stores parameters AND binding; the row map is the order."""
+    import numpy as np
+    import pytest
+    import torch
+    from fateavatar_amd.avatar import AvatarGaussians
+    rng = np.random.default_rng(1)
+    P = 11
+    pc = AvatarGaussians(rng.integers(0, 50, P), rng.uniform(0, 1, (P, 3)).astype(np.float32), -6.0, torch.device("cpu"))
+    with torch.no_grad():
+        for n, _ in pc.FIELDS:
+            getattr(pc, n).copy_(torch.from_numpy(rng.normal(size=tuple(getattr(pc, n).shape)).astype(np.float32)))
+    old = {n: getattr(pc, n).detach().clone() for n, _ in pc.FIELDS}
+    fi, bc = pc.face_index.clone(), pc.bary_coords.clone()
+    order = torch.from_numpy(rng.permutation(P))
+    row_map = pc.resize(order=order)
+    assert torch.equal(row_map, order) and pc.P == P
+    assert torch.equal(pc.face_index, fi[order]) and torch.equal(pc.bary_coords, bc[order])
+    for n, _ in pc.FIELDS:
+        assert torch.equal(getattr(pc, n).detach(), old[n][order])
+        assert getattr(pc, n)._fr_grad_out.buf.shape == getattr(pc, n).shape
+    with pytest.raises(ValueError, match="not both"):
+        pc.resize(keep_mask=torch.ones(P, dtype=torch.bool), order=order)
+
+
 def test_mesh_binding_refuses_cpu_tensors():
     import pytest
     import torch
