@@ -15,6 +15,8 @@ python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 --lanes > $O/
 # the same two steps with the binding as its own kernels (the A/B of fr_aux::binding), and the steps' timelines
 python $R/tools/train_synthetic.py --fateavatar --binding-op > $O/${tag}_train_step_fateavatar_binding_op.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 --binding-op > $O/${tag}_train_step_fateavatar_batch4_binding_op.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar --random-order > $O/${tag}_train_step_fateavatar_random_order.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 --random-order > $O/${tag}_train_step_fateavatar_batch4_random_order.json 2>> $O/${tag}_bench.err
 $R/tools/profile.sh ${tag}_fa1 python $R/tools/train_synthetic.py --fateavatar --steps 300 > /dev/null 2>&1
 $R/tools/profile.sh ${tag}_fa4 python $R/tools/train_synthetic.py --fateavatar --steps 300 --views-per-step 4 > /dev/null 2>&1
 FR_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 30 --warmup 5 > $O/${tag}_bench_2ranks_gloo_1gpu.json 2>> $O/${tag}_bench.err
