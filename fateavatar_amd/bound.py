@@ -47,11 +47,12 @@ class _RasterizeBoundBatch(torch.autograd.Function):
         ctx.K, ctx.settings, ctx.bindings, ctx.slots = K, settings, bindings, slots
         ctx.set_materialize_grads(False)
         empty = torch.Tensor([])
-        views, viss, descs, bound = [], [], [], []
+        views, viss, descs, bound, checked = [], [], [], [], []
         for k, (rs, mb) in enumerate(zip(settings, bindings)):
             verts, offset, rotation, scaling, means2D, sh, opacities = tensors[n * k:n * k + n]
             verts, offset = _chk(verts, torch.float32, "verts"), _chk(offset, torch.float32, "offset")
             rotation, scaling = _chk(rotation, torch.float32, "rotation"), _chk(scaling, torch.float32, "scaling")
+            checked.append((verts, offset, rotation, scaling))   # (what the descriptor points at: alive until the launch, saved for the backward)
             N, dev = mb.face_index.shape[0], verts.device
             if verts.dim() != 2 or offset.numel() != N or rotation.shape != (N, 4) or scaling.shape != (N, 3) or \
                     mb.bary_coords.shape != (N, 3):
@@ -85,9 +86,7 @@ class _RasterizeBoundBatch(torch.autograd.Function):
             owners = {"dL_dsh": sh, "dL_dopacity": opacities, "d_offset": offset, "d_rotation": rotation, "d_scaling": scaling}
             ctx.grad_slots.append(slots_k)
             ctx.grad_owners.append({m: t for m, t in owners.items() if slots_k.get(m) is not None and t.is_leaf})
-            saved += [_chk(verts, torch.float32, "verts"), _chk(offset, torch.float32, "offset"),
-                      _chk(rotation, torch.float32, "rotation"), _chk(scaling, torch.float32, "scaling"), sh, radii, geomBuffer,
-                      binningBuffer, imgBuffer, *bound[k]]
+            saved += [*checked[k], sh, radii, geomBuffer, binningBuffer, imgBuffer, *bound[k]]
             outs += [color, radii]
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(*outs[1::2])
