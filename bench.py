@@ -67,6 +67,10 @@ import time
 # (before torch initialises the ROCm runtime: eager launches keep their kernel arguments in device memory, as replayed graphs
 # do — the roofline's isolated eager launches then see the kernel a graph replay sees; fateavatar_amd sets the same default)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# (and replayed graphs enqueue their kernel nodes like ordinary launches instead of replaying recorded AQL packets: less
+# device time at the end of every replay for more host time per replay — fateavatar_amd/__init__.py; reported in
+# config.hip_env)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -981,6 +985,7 @@ def main():
                        "in_flight_calibration_frames_per_s": eng.calibration,
                        "activations": "fused in the HIP preprocess kernels" if args.fused_activations else "stock PyTorch",
                        "launch": "hipgraph replay" if args.graph else "eager",
+                       "hip_env": {k: os.environ.get(k) for k in ("HIP_FORCE_DEV_KERNARG", "DEBUG_CLR_GRAPH_PACKET_CAPTURE")},
                        "parallelism": (f"dp{world}: one view per GPU and step, then ONE flat-grad RCCL all-reduce(AVG), then the next "
                                        "step (BASELINE configs[3]); the amortised mode is in dp.modes" if exchanging else
                                        (f"dp1 ({rounds} round(s) per step of {chains[1]} launch chains in flight, {chains[0]} views per chain "

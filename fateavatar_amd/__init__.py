@@ -15,4 +15,12 @@ import os as _os
 # import, unless the caller has decided otherwise; replayed graphs are unaffected.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
+# Replayed graphs: ROCm 7 replays a captured graph from AQL packets it recorded at instantiation ("graph packet capture");
+# on this stack a replay then ends with ~8.6 us before the next thing on the stream starts, whatever that is.  With the
+# recording off the runtime enqueues the graph's kernel nodes like ordinary launches (the ROCm 6 path): ~40 us more HOST time
+# per replay of nine nodes, but 4 us less on the device per replay — +4.4 % frames/s one frame at a time, +3.5 % FateAvatar
+# steps/s, +0.8 % with twelve frames in flight (EXPERIMENTS.md).  Read by the runtime when it initialises, like the above;
+# set DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 in the environment to keep the runtime's default.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 __version__ = "0.1.0"

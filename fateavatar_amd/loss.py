@@ -96,9 +96,15 @@ def l1_loss_and_grad_batch(imgs, gts, loss_outs, grad_outs, workspaces):
     return loss_outs, grad_outs
 
 
+_copy_calls = {}   # (dst ptr, src ptr, floats) per pair -> the prepared argument arrays of fr_multi_copy
+
+
 def multi_copy(pairs) -> None:
     """`dst.copy_(src)` for up to twelve (dst, src) pairs of contiguous float32 device tensors in ONE launch
-    (`fr_multi_copy`): the per-frame inputs of a captured step (of every frame of a batch)."""
+    (`fr_multi_copy`): the per-frame inputs of a captured step (of every frame of a batch).  A step calls this with the
+    same few sets of tensors over and over (its static buffers, the frames of a resident sequence): the ctypes argument
+    arrays of a set are made once and looked up by the tensors' addresses afterwards — this call is on the host's critical
+    path of a 130 us step."""
     import ctypes as C
     pairs = [(d, s) for d, s in pairs if d.numel()]
     if not pairs:
@@ -106,18 +112,27 @@ def multi_copy(pairs) -> None:
     if len(pairs) > 12:
         raise RuntimeError("multi_copy: at most twelve pairs")
     dev = pairs[0][0].device
+    f32 = torch.float32
     for d, s in pairs:
         if not (d.is_cuda and s.is_cuda and d.device == dev and s.device == dev):
             raise RuntimeError("multi_copy needs tensors of one device")
-        if d.dtype != torch.float32 or s.dtype != torch.float32 or not d.is_contiguous() or not s.is_contiguous() or \
-                d.numel() != s.numel():
+        if d.dtype is not f32 or s.dtype is not f32 or not d.is_contiguous() or not s.is_contiguous() or d.numel() != s.numel():
             raise RuntimeError("multi_copy: contiguous float32 tensors of equal size")
-    n = len(pairs)
-    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
-    src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
-    cnt = (C.c_uint64 * n)(*[d.numel() for d, _ in pairs])
-    with torch.cuda.device(dev):
+    key = tuple((d.data_ptr(), s.data_ptr(), d.numel()) for d, s in pairs)
+    call = _copy_calls.get(key)
+    if call is None:
+        n = len(pairs)
+        call = (n, (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs]), (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs]),
+                (C.c_uint64 * n)(*[d.numel() for d, _ in pairs]))
+        if len(_copy_calls) > 4096:     # (addresses are only a key while their tensors live: bounded, rebuilt on demand)
+            _copy_calls.clear()
+        _copy_calls[key] = call
+    n, dst, src, cnt = call
+    if torch.cuda.current_device() == dev.index:
         rc = _lib.lib().fr_multi_copy(n, dst, src, cnt, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        with torch.cuda.device(dev):
+            rc = _lib.lib().fr_multi_copy(n, dst, src, cnt, torch.cuda.current_stream(dev).cuda_stream)
     if rc != _lib.FR_OK:
         raise RuntimeError(f"fr_multi_copy failed: {_lib.last_error()}")
 
