@@ -64,13 +64,13 @@ import subprocess
 import sys
 import time
 
-# (before torch initialises the ROCm runtime: eager launches keep their kernel arguments in device memory, as replayed graphs
-# do — the roofline's isolated eager launches then see the kernel a graph replay sees; fateavatar_amd sets the same default)
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-# (and replayed graphs enqueue their kernel nodes like ordinary launches instead of replaying recorded AQL packets: less
-# device time at the end of every replay for more host time per replay — fateavatar_amd/__init__.py; reported in
-# config.hip_env)
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# The ROCm runtime switches of fateavatar_amd.tune_runtime() (fateavatar_amd/__init__.py: kernel arguments of eager launches
+# in device memory; replayed graphs enqueue their nodes like ordinary launches) — set HERE, explicitly, before torch
+# initialises the runtime, and reported in config.hip_env.  FR_BENCH_RUNTIME_DEFAULTS=1 leaves the runtime alone: the
+# default run measures one frame at a time that way too, as a child process (`runtime_defaults` in the line).
+if os.environ.get("FR_BENCH_RUNTIME_DEFAULTS") != "1":
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -134,7 +134,8 @@ def cpu_baseline(scene, budget_s: float = 20.0):
     n1 = int(max(1, min(8, (budget_s * 0.3) / max(run(1), 1e-3))))
     dt1 = run(n1)
     oracle.set_num_threads(ncpu)
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": best, "kind": "port",
+    # `cores` = the CPUs the container may use (its quota) that the best run kept busy; `threads` = the OpenMP threads of that run
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": min(best, quota), "threads": best, "kind": "port",
             "sample": f"{n} frames fwd+bwd of the same workload at {best} threads ({dt:.1f} s); thread sweep "
                       + ", ".join(f"{k}: {1 / v:.2f}" for k, v in sorted(sweep.items())) + " frames/s",
             "value_1thread": round(n1 / dt1, 3), "host_threads": ncpu, "cpu_quota_cores": quota,
@@ -658,7 +659,7 @@ def _dp_reference_at_1(args):
     """`bench.py --exchange-at-1` as a child process (its own HIP context and one-rank RCCL group), after this process's timed
     region: the N > 1 steps at one rank.  A run that cannot produce it says why in `status`."""
     try:
-        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--no-coherent", "--opacity", str(args.opacity)] + _scene_args(args))
+        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--opacity", str(args.opacity)] + _scene_args(args))
         m = rec["dp"]["modes"]
         keys = ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")
         return {"status": "ok",
@@ -676,7 +677,7 @@ def _coherent_layout(args):
     scene (its order is random) and never `value`."""
     try:
         os.environ["FR_BENCH_ORDER"] = "coherent"
-        rec = _child_line(["--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--opacity", str(args.opacity)] + _scene_args(args))
+        rec = _child_line(["--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--opacity", str(args.opacity)] + _scene_args(args))
         return {"status": "ok", "value": rec["value"], "unit": rec["unit"], "one_frame_at_a_time": (rec.get("one_frame_at_a_time") or {}).get("value"),
                 "preprocess_fwd_us": (rec.get("stage_us") or {}).get("preprocess_fwd"),
                 "what": "the same Gaussians stored in grid-cell order (fateavatar_amd.scenes.spatial_order), same modes as `value`"}
@@ -686,11 +687,30 @@ def _coherent_layout(args):
         os.environ.pop("FR_BENCH_ORDER", None)
 
 
+def _runtime_defaults(args):
+    """One frame at a time with the ROCm runtime's OWN defaults (neither switch of fateavatar_amd.tune_runtime() set): this
+    script again as a child process with FR_BENCH_RUNTIME_DEFAULTS=1."""
+    saved = {k: os.environ.pop(k, None) for k in ("HIP_FORCE_DEV_KERNARG", "DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
+    try:
+        os.environ["FR_BENCH_RUNTIME_DEFAULTS"] = "1"
+        rec = _child_line(["--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults",
+                           "--opacity", str(args.opacity)] + _scene_args(args)[:-2] + ["--rounds", "1"])
+        return {"status": "ok", "one_frame_at_a_time": rec["value"], "unit": rec["unit"], "hip_env": rec["config"]["hip_env"],
+                "what": "the same frames, one at a time, in a process that sets neither runtime switch"}
+    except Exception as e:
+        return {"status": "failed: " + repr(e)[:300]}
+    finally:
+        os.environ.pop("FR_BENCH_RUNTIME_DEFAULTS", None)
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
 def _opaque_scene(args):
     """The operating point training moves to (opacity 0.9; config/fateavatar.yaml:40-47 prunes below 0.005, the rest
     saturates): the same scene and run, one frame at a time, as a child process — frames/s and the blend backward's launch."""
     try:
-        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent"]
+        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults"]
                           + _scene_args(args)[:-2] + ["--rounds", "1"])
         r = rec.get("roofline") or {}
         return {"status": "ok", "opacity": 0.9, "value": rec["value"], "unit": rec["unit"], "frames_in_flight": 1,
@@ -698,6 +718,10 @@ def _opaque_scene(args):
                 "stage_us": rec.get("stage_us")}
     except Exception as e:
         return {"status": "failed: " + repr(e)[:300]}
+
+
+def stock_run(args):
+    return args.scale is None and args.opacity == 0.1
 
 
 def main():
@@ -733,6 +757,9 @@ def main():
     ap.add_argument("--no-coherent", dest="coherent", action="store_false", default=True,
                     help="N = 1: do not add `coherent_layout` (the same Gaussians stored in a spatially coherent order, measured by a "
                          "second run of this script after the timed region)")
+    ap.add_argument("--no-runtime-defaults", dest="runtime_defaults", action="store_false", default=True,
+                    help="N = 1: do not add `runtime_defaults` (one frame at a time in a process that leaves the ROCm runtime's "
+                         "switches alone, measured by a second run of this script after the timed region)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
@@ -952,6 +979,9 @@ def main():
                 dp_ref = _dp_reference_at_1(args)
         if not STUB and world == 1 and not exchanging and args.opaque and args.graph and args.opacity == 0.1:
             opaque = _opaque_scene(args)
+        rt_defaults = None
+        if not STUB and world == 1 and not exchanging and args.runtime_defaults and args.graph and stock_run(args):
+            rt_defaults = _runtime_defaults(args)
         coherent = None
         if (not STUB and world == 1 and not exchanging and args.coherent and args.graph and args.scale is None
                 and os.environ.get("FR_BENCH_ORDER") is None):
@@ -997,6 +1027,8 @@ def main():
             # (stage_frac bills SURVEY.md's formulas; stage_frac_required the bytes this layout has to move: stage_bytes_required)
             "stage_frac_required": stage_frac_required, "dp": dpinfo,
             "one_frame_at_a_time": single,
+            # ... and in a process that sets neither ROCm runtime switch (config.hip_env is what THIS process ran under)
+            "runtime_defaults": rt_defaults,
             # the N > 1 `value` (literal step) at ONE rank: divide an N > 1 run's `value` by N times this, not by the N = 1 `value`
             "scaling_reference": scaling_reference, "scaling_reference_status": None if dp_ref is None else dp_ref.get("status"),
             "efficiency": efficiency,

@@ -181,13 +181,17 @@ class TrainStep:
         """The sampling and cloning rule of _uv_densify (model/fateavatar.py:610-672) without the mesh re-binding:
         `increase_num` rows drawn with probability proportional to xyz_gradient_accum (multinomial, with
         replacement), cloned with their scale multiplied by 0.75; appended rows start with zero Adam moments.
-        Data-parallel runs must pass identically seeded generators (or broadcast the returned indices).  Returns the
-        sampled row indices."""
+        Data-parallel: the statistics are per-view sums (model/fateavatar.py:734-737), so the draw is made on rank 0 from
+        the sum over all ranks and broadcast — every replica appends the same rows.  Returns the sampled row indices."""
         pc = self.pc
-        w = self.xyz_gradient_accum.reshape(-1)
-        if float(w.sum()) <= 0:
-            raise RuntimeError("no densification statistics accumulated yet")
-        idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+        acc, _ = self.reduce_densification_stats()
+        w = acc.reshape(-1)
+        idx = torch.zeros(increase_num, dtype=torch.int64, device=self.dev)
+        if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
+            if float(w.sum()) <= 0:
+                raise RuntimeError("no densification statistics accumulated yet")
+            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+        dp.broadcast_(idx)
         rows = [getattr(pc, name).detach()[idx].clone() for name, _ in pc.FIELDS]
         rows[3] = torch.log(torch.exp(rows[3]) * 0.75)   # _scaling
         old_rows = pc.P

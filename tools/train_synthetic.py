@@ -16,6 +16,7 @@ import sys
 import time
 
 import numpy as np
+os.environ.setdefault("FR_TUNE_RUNTIME", "1")   # (fateavatar_amd.tune_runtime() at import: the runtime switches the measurements are quoted under)
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
