@@ -945,7 +945,7 @@ def main():
             if n:
                 avg_s = ms / n * 1e-3
                 ach = sb["blend_bwd"] / avg_s / 1e9
-                traffic = valu = valu_meas = src = None
+                traffic = valu = valu4 = valu_meas = src = None
                 cpath = os.path.join(ROOT, "profiles", "blend_bwd_counters.json")
                 if os.path.exists(cpath):   # written by tools/pmc.sh + tools/pmcstats.py from rocprofv3 --pmc passes
                     try:
@@ -956,6 +956,10 @@ def main():
                                 # MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles on CDNA4's SIMD-32 ->
                                 # wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
                                 valu = round(cj["sq_insts_valu_per_launch"] * 2 / (1024 * 2.4e9 * avg_s), 4)
+                                # (the conservative reading — 4 cycles per wave64 op, SIMD-16 style — beside it: the in-repo
+                                # microbenchmark tools/diag/micro_issue.hip measures 2.5 - 2.9 cycles per wave-instruction
+                                # for this mix, i.e. between the two)
+                                valu4 = round(cj["sq_insts_valu_per_launch"] * 4 / (1024 * 2.4e9 * avg_s), 4)
                                 # ... and at the issue rate this kernel's instruction mix was MEASURED to sustain once 2-3
                                 # waves share a SIMD: 1.3 ns per wave-instruction (tools/diag/micro_issue.hip)
                                 valu_meas = round(cj["sq_insts_valu_per_launch"] * 1.3e-9 / (1024 * avg_s), 4)
@@ -963,7 +967,7 @@ def main():
                         pass
                 roof = {"bound": "hbm", "kernel": "k_unit_blend_bwd_sparse", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_frac": valu,
-                        "valu_frac_measured_issue": valu_meas,
+                        "valu_frac_at_4_cycles_per_op": valu4, "valu_frac_measured_issue": valu_meas,
                         "counters_source": src, "algorithmic_bytes": sb["blend_bwd"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": n,
                         "measured": "dispatch-tied HIP events around ISOLATED launches (eager no-wait frames of one view, queued "

@@ -156,8 +156,10 @@ class _BoundFrame:
 
 
 class _RawFrame:
-    """What render_bound_batch() reads: the RAW parameters of a frame whose binding the rasterizer evaluates itself."""
+    """What render_bound_batch() reads: the RAW parameters of a frame whose binding the rasterizer evaluates itself.  (Not a
+    holder for render(): it has no bound positions.)"""
     max_sh_degree = 0
+    fused_activations = True
 
     def __init__(self, pc: AvatarGaussians, stats):
         self._opacity, self._offset, self._rotation, self._scaling = pc._opacity, pc._offset, pc._rotation, pc._scaling
@@ -604,10 +606,11 @@ class AvatarBatchStep(AvatarStep):
                     if rasterizer.check_async_overflow(self.dev.index or 0):
                         self.overflows += 1
                         self.overflow_steps = getattr(self, "overflow_steps", []) + [self._step_no - 1]
-                        if self.overflows == 1:
-                            import warnings
-                            warnings.warn(f"AvatarBatchStep: the binning capacity overflowed inside the captured chain around step "
-                                          f"{self._step_no - 1} (view {L.k}); its gradient was lost, the chain is captured again")
+                        import warnings   # (every occurrence: each one is a step whose view contributed a zero gradient)
+                        warnings.warn(f"AvatarBatchStep: the binning capacity overflowed inside the captured chain around step "
+                                      f"{self._step_no - 1} (view {L.k}, occurrence {self.overflows}); that view back-propagated zeros "
+                                      "(Adam stepped on the other views' gradients and its momentum; with a data-parallel exchange "
+                                      "the zero was averaged in on every rank), the chain is captured again with a larger capacity")
                         self._drop_graphs()
                         captured = False
                         break

@@ -151,7 +151,10 @@ def render_bound_batch(viewpoint_cameras, pcs, posed_verts, binding: MeshBinding
     `pcs`: per view (or one for all) a holder with the raw parameters `_opacity` [N,1], `_offset` [N,1], `_rotation` [N,4],
     `_scaling` [N,3], the features `get_features` [N,M,3], `max_sh_degree` — and optionally `fused_densification_stats`;
     `posed_verts`: per view the posed mesh [V,3].  Returns the list of render() dicts; `out["bound"]` holds the
-    (xyz, rotation, scaling) the reference assigns to the Gaussians before render() (model/fateavatar.py:256-258)."""
+    (xyz, rotation, scaling) the reference assigns to the Gaussians before render() (model/fateavatar.py:256-258) as plain
+    kernel OUTPUTS, DETACHED from autograd: gradients reach offset / rotation / scaling / verts through the image only.  A
+    regulariser on the bound values themselves needs the differentiable stand-alone op (`binding.bind_gaussians`, what
+    `AvatarStep(fold_binding=False)` renders through)."""
     K = len(viewpoint_cameras)
     if not 1 <= K <= _lib.FR_MAX_BATCH:
         raise RuntimeError(f"render_bound_batch: 1 .. {_lib.FR_MAX_BATCH} views")
@@ -187,5 +190,5 @@ def render_bound_batch(viewpoint_cameras, pcs, posed_verts, binding: MeshBinding
     for k, sp in enumerate(points):
         image, radii = res[2 * k], res[2 * k + 1]
         out.append({"render": image, "viewspace_points": sp, "visibility_filter": radii._fr_visible, "radii": radii,
-                    "bound": radii._fr_bound})
+                    "bound": tuple(t.detach() for t in radii._fr_bound) if radii._fr_bound is not None else None})
     return out

@@ -646,7 +646,7 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
                                                    float dpb, float* __restrict__ accum, int lane, int vv, int own_u, int own_c)
 {
     for (int j = ((m + kGroup - 1) & ~(kGroup - 1)) - kGroup; j >= 0; j -= kGroup) {
-        float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup];
+        float araw[kGroup], cd[kGroup], dx[kGroup], dy[kGroup], gx[kGroup], gy[kGroup];
         bool ok[kGroup];
         bool any_ok = false;
 #pragma unroll
@@ -655,6 +655,9 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
             const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
             const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
             dx[k] = q0.x - fx, dy[k] = q0.y - fy;
+            // -log2(e) (a dx + b dy), -log2(e) (b dx + c dy): the pair's dG/d(centre) / G, from the pre-scaled conic
+            gx[k] = fmaf(2.f * q0.z, dx[k], q0.w * dy[k]);
+            gy[k] = fmaf(2.f * q1.x, dy[k], q0.w * dx[k]);
             const float power = pair_log2G(q0.z, q0.w, q1.x, dx[k], dy[k]);
             araw[k] = q1.y * __builtin_amdgcn_exp2f(power);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
             ok[k] = (j + k < lim) && !(power > 0.0f) && !(araw[k] < 1.0f / 255.0f);
@@ -682,8 +685,8 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
             const float q = dL_dalpha * ar_e;
             const float qdx = q * dx[k], qdy = q * dy[k];
             float* su = s + k * 9;
-            su[ACC_MX] = qdx;
-            su[ACC_MY] = qdy;
+            su[ACC_MX] = q * gx[k];   // combined with the conic per PIXEL, as backward.cu:540-546 does (see ACC_MX)
+            su[ACC_MY] = q * gy[k];
             su[ACC_CA] = qdx * dx[k];
             su[ACC_CB] = qdx * dy[k];
             su[ACC_CC] = qdy * dy[k];
@@ -1492,6 +1495,9 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         }
         S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
         const float rxl = rq0.x - (float)tx0, ryl = rq0.y - (float)ty0;           // own record centre, tile-local
+        // own record's pre-scaled conic (a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise): phase B combines a pair's
+        // (dx, dy) with it per PIXEL — -log2(e) (a dx + b dy, b dx + c dy) = dG/d(centre) / G — as backward.cu:540-546 does
+        const float ca2 = 2.f * rq0.z, cc2 = 2.f * rq1.x, cb1 = rq0.w;
 
         // ---- record ranges [lo, hi), from the back, each with at most kPairCap mask bits
         int hi = (int)m;
@@ -1589,7 +1595,10 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
                     const float4 dp = S.pix[p];
                     const v2f dd = {rxl - (float)(p & 7), ryl - (float)(p >> 3)};
                     const v2f qd = q * dd;
-                    s_m += qd;
+                    // q (2a' dx + b' dy), q (2c' dy + b' dx): the pixel's two products go into the sums one behind the other
+                    // (the running sum stays as small as the combined value: what matters for the rounding)
+                    s_m += (v2f){ca2, cc2} * qd;
+                    s_m += cb1 * (v2f){qd.y, qd.x};
                     s_ab += qd.x * dd;
                     s_cc += qd.y * dd.y;
                     s_op += q;

@@ -28,7 +28,10 @@ constexpr int kSortRegMax = 4096;    // longest list k_tile_sort_big sorts in re
 
 // accumulator slots (blend backward -> preprocess backward).  With q = dL/dG * G of a (pixel, Gaussian) pair
 // and d = splat centre - pixel, the slots hold the sums over pixels of:
-//   MX: q*dx   MY: q*dy   CA: q*dx*dx   CB: q*dx*dy   CC: q*dy*dy   OP: q   R,G,B: alpha*T*dL/dpixel
+//   MX: q*gx   MY: q*gy   CA: q*dx*dx   CB: q*dx*dy   CC: q*dy*dy   OP: q   R,G,B: alpha*T*dL/dpixel
+// with (gx, gy) = -log2(e) * (a dx + b dy, b dx + c dy) = (dG/d delx, dG/d dely) / G * log2(e): the pair's offset combined with
+// the conic PER PIXEL, as the reference does (backward.cu:540-546) — summing q*dx and q*dy and combining afterwards lets the
+// two products of an elongated splat cancel only after N pixels' worth of rounding.
 // k_preprocess_bwd turns them into the reference's dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.
 enum { ACC_MX = 0, ACC_MY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8 };
 

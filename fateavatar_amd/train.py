@@ -153,6 +153,9 @@ class TrainStep:
         if rasterizer.check_async_overflow(self.dev.index or 0):
             self.overflows += 1
             self._graph, self._eager_steps = None, 0
+            import warnings   # (every occurrence: the replays since the overflow stepped Adam on a zero gradient)
+            warnings.warn(f"{type(self).__name__}: the binning capacity overflowed inside the captured step (occurrence "
+                          f"{self.overflows}); the affected replays back-propagated zeros, the step runs eagerly and is captured again")
 
     # -- Gaussian maintenance (reference: train/iteration.py:62-86 -> model/fateavatar.py:610-731), generic-3DGS flavour:
     #    the FateAvatar versions additionally carry the mesh binding (face index, barycentrics) of every row

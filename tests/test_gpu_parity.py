@@ -92,6 +92,7 @@ def _flip_affected_gaussians(o, h):
 SKIPPED = {}   # scene -> (flip pixels, rows exempted from the tight test, fraction of the visible rows): printed with -rP
 
 
+SKIP_ROWS_BOUND = 1e-2   # aggregate rel-L2 the flip-exempt rows of a scene are still held to (per array)
 NOISE_K = 8.0   # the aggregate gradient bound is max(1e-4, NOISE_K x the float-order noise floor of the array)
 ACHIEVED = {}   # name -> {array: (rel-L2 of the kept rows, floor, rel-L2 of the flip-exempt rows)}
 
@@ -110,7 +111,9 @@ def _check_backward(o, h, dpix, name, max_skip_frac=0.02, agg_bound=1e-4):
     is max(agg_bound, NOISE_K x floor), where `floor` is MEASURED on this scene: the oracle's backward with float sums in
     seeded orders, and with nvcc-style contractions (two results the reference could produce), against its double sums.
     At every BASELINE configuration the floor is ~1e-7, the bound 1e-4, and the HIP path sits at 3e-7 .. 9e-7.
-    `agg_bound`: only scenes of IMAGE-SIZED splats state more than 1e-4 (3e-4; see test_fuzz_regression_image_sized_splats).
+    `agg_bound`: 1e-4 for every scene (round 4 let scenes of image-sized splats state 3e-4: the blend backward then summed a
+    Gaussian's q dx and q dy per tile and combined them with the conic afterwards; it combines per pixel now, as
+    backward.cu:540-546 does — test_fuzz_regression_image_sized_splats).
     `max_skip_frac`: the largest share of the VISIBLE Gaussians that threshold flips may exempt from the tight test
     (they are still held to rel-L2 0.2, and what they achieve is printed).  A flip in a 16x16 list of thousands of entries
     exempts thousands of rows, so dense stress scenes state a larger bound — but every scene states one, and it is asserted."""
@@ -156,9 +159,10 @@ def _check_backward(o, h, dpix, name, max_skip_frac=0.02, agg_bound=1e-4):
         # entry that is the small difference of large terms misses a 1e-4 relative test in fp32 either way)
         n_off = round((1.0 - fr) * got[keep].size)
         assert (fr >= 0.999 or n_off <= 3) and rl <= bound, (name, k, fr, rl, floor, bound, n_flips, int(skip.sum()))
-        # Gaussians that share a pixel with a threshold flip: same sign and size, not garbage
+        # Gaussians that share a pixel with a threshold flip (a flip changes the transmittance of every later entry of that
+        # ONE pixel; a row sums over all its pixels): within a few per cent in aggregate, not merely "same sign and size"
         if skip.any():
-            assert rl_skip <= 0.2, (name, k, "flip-affected rows", rl_skip)
+            assert rl_skip <= SKIP_ROWS_BOUND, (name, k, "flip-affected rows", rl_skip)
     # (last, so that a real mismatch is reported as such and not as a scene that exempts too much)
     assert frac <= max_skip_frac, (name, "threshold flips exempt too many rows from the tight gradient test", n_flips, int(skip.sum()), n_vis, frac)
 
@@ -192,18 +196,41 @@ def test_backward_without_exemptions_on_dense_scenes(name, gpu_device):
     _check_forward(o, h, name)
     H, W = s.camera.image_height, s.camera.image_width
     dpix = (np.random.default_rng(13).uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+    _check_backward_no_exemptions(o, h, dpix, name)
+
+
+class _Agree:
+    """A frame whose forward outputs are the oracle's: `_check_backward` then finds no flip pixel and exempts no row."""
+
+    def __init__(self, h, o):
+        import torch
+        self._h, self.color, self.final_T = h, torch.from_numpy(o.color.copy()), torch.from_numpy(o.final_T.copy())
+
+    def backward(self, d):
+        return self._h.backward(d)
+
+
+def _check_backward_no_exemptions(o, h, dpix, name):
+    """`_check_backward` with NO row exempt: dL/dpixel is zeroed at the pixels whose forward value flipped (such a pixel then
+    contributes nothing to any gradient, whatever its blend sequence was), and every Gaussian is held to the tight test."""
     bad = _flip_pixels(o, h)
+    dpix = dpix.copy()
     dpix[:, bad] = 0.0
     print(f"[no exemptions] {name}: {int(bad.sum())} flip pixel(s) masked out of dL/dpixel")
-    # (the same machinery with an empty exemption set: the forward outputs are made to agree before the comparison)
-    class _Agree:
-        def __init__(self, h, o):
-            self._h, self.color, self.final_T = h, __import__("torch").from_numpy(o.color.copy()), __import__("torch").from_numpy(o.final_T.copy())
-        def backward(self, d):
-            return self._h.backward(d)
-    _check_backward(o, _Agree(h, o), dpix, name + "-no-exemptions", max_skip_frac=0.0,
-                    agg_bound=3e-4 if name == "wide_offscreen" else 1e-4)
+    _check_backward(o, _Agree(h, o), dpix, name + "-no-exemptions", max_skip_frac=0.0)
     assert SKIPPED[name + "-no-exemptions"][1] == 0
+
+
+def _check_backward_capped(o, h, dpix, name, max_skip_frac):
+    """`_check_backward` when threshold flips exempt at most `max_skip_frac` of the visible rows — otherwise (scenes of
+    image-sized splats: one flip pixel's 16x16 list holds a third of the scene) the flips are masked out of dL/dpixel and
+    NO row is exempt.  Either way no scene hides more than `max_skip_frac` of its rows behind an exemption."""
+    skip, _ = _flip_affected_gaussians(o, h)
+    frac = float(skip.sum()) / max(1, int((o.radii > 0).sum()))
+    if frac <= max_skip_frac:
+        _check_backward(o, h, dpix, name, max_skip_frac=max_skip_frac)
+    else:
+        _check_backward_no_exemptions(o, h, dpix, name)
 
 
 def test_colors_precomp_and_cov3d_precomp(gpu_device):
