@@ -340,7 +340,10 @@ __device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t b
 // short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
 // image region land in different workgroups) and sorts it in registers if it has <= 256 keys.  Lists longer
 // than 1024 are left to k_tile_sort_big.
-constexpr uint32_t kMediumSorters = 512;  // workgroups that sort the medium lists while the others sort the short ones
+#ifndef FR_MEDIUM_SORTERS
+#define FR_MEDIUM_SORTERS 1024
+#endif
+constexpr uint32_t kMediumSorters = FR_MEDIUM_SORTERS;  // workgroups that sort the medium lists while the others sort the short ones
 
 struct SortArgs {
     ImageView v;
@@ -395,9 +398,12 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t nm = v.counts->medium_tiles;
+        SortXchgT<2>& sx2 = *reinterpret_cast<SortXchgT<2>*>(&sx);   // (lists up to 512: half the network)
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
-            sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], v.tile_total[tile], wave, lane, sx);
+            const uint32_t n = v.tile_total[tile];
+            if (n <= 512u) sort_tile_group<2>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx2);
+            else sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
         }
         // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
         // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
@@ -416,11 +422,16 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
     {
         const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
         if (blockIdx.x - kMediumSorters < Q && tile < T) {   // (a batched launch's grid is the largest view's)
-            if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
+            // (everything the tile's wave reads before its keys — list start and length, first unit, sub-list table — in ONE
+            // round trip, together with the frame's counts: none of it sits behind a branch on another load)
             const uint32_t start = v.tile_offset[tile];
             const uint32_t n = v.tile_total[tile];
+            const uint32_t u0 = v.unit_offset[tile];
+            const KeySrc ks = key_src(v, tile);
+            asm volatile("" ::"s"(ks.sub[1]), "s"(ks.sub[7]), "s"(start), "s"(n), "s"(u0));
+            if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
             // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
-            const uint32_t u0 = v.unit_offset[tile], nu = (n + kUnit - 1) / kUnit;
+            const uint32_t nu = (n + kUnit - 1) / kUnit;
             for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
                 if (u0 + k < unit_cap)   // (tile position, not tile index: the blend kernels need no division)
                     unit_tile[u0 + k] = make_uint4((tile / (uint32_t)v.tiles_x) << 16 | (tile % (uint32_t)v.tiles_x), k, start, n);
@@ -442,7 +453,6 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
                 }
             }
             if (n > 0 && n <= (uint32_t)kSortWaveMax) {
-                const KeySrc ks = key_src(v, tile);
                 if (n <= 64) sort_tile_regs<1>(ks, ids, start, n, lane);
                 else if (n <= 128) sort_tile_regs<2>(ks, ids, start, n, lane);
                 else sort_tile_regs<4>(ks, ids, start, n, lane);
@@ -544,23 +554,18 @@ struct UnitInfo {
     bool inside;
 };
 
-__device__ __forceinline__ UnitInfo unit_info(uint32_t u, const uint4* __restrict__ unit_tile,
-                                              const uint32_t* __restrict__ unit_offset,
-                                              const uint32_t* __restrict__ tile_offset, int W, int H, int tiles_x, int lane)
+// from the unit's descriptor (BinningView::unit_tile): (tile y << 16 | tile x, segment, list start, list length)
+__device__ __forceinline__ UnitInfo unit_info(const uint4 d, int W, int H, int lane)
 {
     UnitInfo i;
-    const uint4 d = unit_tile[u];  // one load: (tile y << 16 | tile x, segment, list start, list length)
     i.tx = d.x & 0xFFFFu, i.ty = d.x >> 16;
     i.seg = d.y;
     i.start = d.z;
     i.n = d.w;
-    (void)unit_offset;
-    (void)tile_offset;
     i.base = i.seg * kUnit;
     i.m = min((uint32_t)kUnit, i.n - i.base);
     i.px = (int)i.tx * kTile + (lane & 7);
     i.py = (int)i.ty * kTile + (lane >> 3);
-    (void)tiles_x;
     i.inside = i.px < W && i.py < H;
     return i;
 }
@@ -1150,6 +1155,7 @@ struct ChainArgs {
     BwdUnit* bwd_units;
     uint32_t* stripe_cursor;
     uint32_t heavy_pairs;
+    uint32_t unit_cap;
     int W, H, tiles_x;
     float* g_tseg;
     float* g_out;
@@ -1169,7 +1175,7 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     const uint4* __restrict__ unit_tile = a.unit_tile;
     const RecSrc recs = a.recs;
     uint2* __restrict__ masks = a.masks;
-    const int W = a.W, H = a.H, tiles_x = a.tiles_x, pair_hist = a.pair_hist;
+    const int W = a.W, H = a.H, pair_hist = a.pair_hist;
     float* g_tseg = a.g_tseg;
     float* g_out = a.g_out;
     const uint32_t dense_pairs = a.dense_pairs, chain_spins = a.chain_spins;
@@ -1188,11 +1194,15 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     // image then sits on one XCD.  Runs of 32 workgroups per XCD inside every 256: -2.6 MB, -0.3 us, still -1.5 % in
     // flight.  Measured, not kept.)
     const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
+    // (the unit's descriptor is requested together with the unit count, not behind it: one dependent round trip less in
+    // front of every wave's records; a.unit_cap descriptors exist whatever the frame holds)
+    const uint4 d_early = unit_tile[min(u, a.unit_cap - 1u)];
+    asm volatile("" ::"v"(d_early.x), "s"(nu_all));
     if (u >= nu_all) return;
     FW_STAMP(0);
     FW_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     const TransposeConsts tc = transpose_consts(lane);
-    const UnitInfo ui = unit_info(u, unit_tile, nullptr, nullptr, W, H, tiles_x, lane);
+    const UnitInfo ui = unit_info(d_early, W, H, lane);
     RecRegs rr = fetch_record(recs, (size_t)ui.start, ui.base + (uint32_t)lane, ui.n);
     asm volatile("" ::"v"(rr.q0.x), "v"(rr.q1.x), "v"(rr.q2.x));
     FW_STAMP(1);   // records in registers
@@ -1699,7 +1709,7 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H, a.stripe_cursor = b.stripe_cursor;
         ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].ids = b.ids;
         ChainArgs& c = ca[k];
-        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_pairs = h->heavy_pairs;
+        c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_pairs = h->heavy_pairs, c.unit_cap = (uint32_t)b.unit_cap;
         c.recs = RecSrc{b.ids, f[k].g.rec_tmpl};
         c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
         c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;
