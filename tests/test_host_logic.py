@@ -258,3 +258,26 @@ def test_backward_work_list_stripe_assignment_is_exact():
             counts[j] += 1
         want = [(nu - j + 63) // 64 for j in range(64)]        # slots j, j + 64, ... below nu
         assert counts == want, (nu, [(j, counts[j], want[j]) for j in range(64) if counts[j] != want[j]][:4])
+
+
+def test_runtime_switches_are_opt_in():
+    """Importing the package leaves the process environment alone; `tune_runtime()` (or FR_TUNE_RUNTIME=1 at import) sets the two
+    ROCm runtime switches unless the environment already holds a value; `runtime_env()` reports them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    keys = ("HIP_FORCE_DEV_KERNARG", "DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import fateavatar_amd as fa\n"
+            "print('A', [os.environ.get(k) for k in %r])\n"
+            "r = fa.tune_runtime()\n"
+            "print('B', [os.environ.get(k) for k in %r], r['late'], r['env'] == fa.runtime_env())\n" % (root, keys, keys))
+    base = {k: v for k, v in os.environ.items() if k not in keys and k != "FR_TUNE_RUNTIME"}
+    out = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=120).stdout
+    assert "A [None, None]" in out and "B ['1', '0'] False True" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(base, FR_TUNE_RUNTIME="1"), capture_output=True, text=True, timeout=120).stdout
+    assert "A ['1', '0']" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(base, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"), capture_output=True, text=True,
+                         timeout=120).stdout
+    assert "A [None, '1']" in out and "B ['1', '1'] False True" in out, out
