@@ -34,7 +34,7 @@ class fr_binding(C.Structure):
 class fr_aux(C.Structure):
     _fields_ = [("visible", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p),
                 ("binding", C.POINTER(fr_binding)), ("d_verts", C.c_void_p), ("d_offset", C.c_void_p),
-                ("d_rotation", C.c_void_p), ("d_scaling", C.c_void_p)]
+                ("d_rotation", C.c_void_p), ("d_scaling", C.c_void_p), ("overflow_out", C.c_void_p)]
 
 
 class fr_params(C.Structure):
@@ -54,7 +54,8 @@ class fr_adam_config(C.Structure):
     _fields_ = [("n_segments", C.c_int32), ("segment_end", C.c_uint64 * FR_ADAM_MAX_SEGMENTS),
                 ("segment_lr", C.c_float * FR_ADAM_MAX_SEGMENTS), ("segment_period", C.c_uint32 * FR_ADAM_MAX_SEGMENTS),
                 ("segment_split", C.c_uint32 * FR_ADAM_MAX_SEGMENTS), ("segment_lr2", C.c_float * FR_ADAM_MAX_SEGMENTS),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("grad_scale", C.c_float)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("grad_scale", C.c_float),
+                ("skip", C.c_void_p * FR_ADAM_MAX_GRADS), ("n_skip", C.c_int32)]
 
 
 class fr_inputs(C.Structure):

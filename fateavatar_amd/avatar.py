@@ -73,7 +73,10 @@ class AvatarGaussians(torch.nn.Module):
         dev = raw[0].device
         sizes = [P * w for _, w in self.FIELDS]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros_like(self.flat)
+        # (gradient buffer + the step's overflow word behind it: model.FlatGaussians._bind)
+        self._grad_store = torch.zeros(sum(sizes) + 4, dtype=torch.float32, device=dev)
+        self.flat_grad = self._grad_store[:sum(sizes)]
+        self.overflow_word = self._grad_store[sum(sizes):sum(sizes) + 1]
         off = 0
         for (name, w), n, r in zip(self.FIELDS, sizes, raw):
             shp = (P,) + self.SHAPES[name]
@@ -91,7 +94,9 @@ class AvatarGaussians(torch.nn.Module):
         o = AvatarGaussians.__new__(AvatarGaussians)
         torch.nn.Module.__init__(o)
         o.face_index, o.bary_coords, o.flat = self.face_index, self.bary_coords, self.flat
-        o.flat_grad = torch.zeros_like(self.flat)
+        o._grad_store = torch.zeros_like(self._grad_store)
+        o.flat_grad = o._grad_store[:self.flat.numel()]
+        o.overflow_word = o._grad_store[self.flat.numel():self.flat.numel() + 1]
         off = 0
         for name, w in self.FIELDS:
             n = self.P * w
@@ -105,6 +110,11 @@ class AvatarGaussians(torch.nn.Module):
     def begin_step(self):
         for name, _ in self.FIELDS:
             getattr(self, name).grad = None
+
+    def exchange_buffer(self) -> torch.Tensor:
+        """`collect_grads()` + the overflow word behind it: what a data-parallel step all-reduces (SUM)."""
+        self.collect_grads()
+        return self._grad_store
 
     def collect_grads(self) -> torch.Tensor:
         off = 0
@@ -215,6 +225,7 @@ class AvatarStep(TrainStep):
     def _make_adam(self):
         pc = self.pc
         self.adam = FusedAdam(pc.flat, pc.flat_grad, self.adam_segments(), grad_scale=1.0 / self.world)
+        self.adam.set_skip_words([pc.overflow_word])
 
     def _forward_backward(self):
         self._forward_backward_on(self)
@@ -226,12 +237,12 @@ class AvatarStep(TrainStep):
         pc.begin_step()                                             # zero_grad(set_to_none=True), iteration.py:48-49
         if self.fold_binding:
             from . import rasterizer
-            out = render_bound_batch([L.cam], [_RawFrame(pc, (L.xyz_gradient_accum, L.denom))], [L.verts], self._binding(pc),
+            out = render_bound_batch([L.cam], [_RawFrame(pc, (L.xyz_gradient_accum, L.denom, pc.overflow_word))], [L.verts], self._binding(pc),
                                      self.bg, slots=[rasterizer._slot])[0]
         else:
             xyz, rot, scl = bind_gaussians(L.verts, self.faces, pc.face_index, pc.bary_coords, self.face_scale_canonical,
                                            pc._offset, pc._rotation, pc._scaling, self.shell_len, self.resize_scale)
-            frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom))
+            frame = _BoundFrame(xyz, pc, rot, scl, (L.xyz_gradient_accum, L.denom, pc.overflow_word))
             out = render(L.cam, frame, self.bg)
         _, g = l1_loss_and_grad(out["render"], L.gt, loss_out=L.loss, grad_out=L._dimage, workspace=L._l1_ws)   # see TrainStep
         out["render"].backward(g)
@@ -265,6 +276,7 @@ class AvatarStep(TrainStep):
     def _rebind_optimizer(self, old_index, old_rows):
         pc = self.pc
         self.adam.remap_rows(pc.flat, pc.flat_grad, old_index, pc.widths(), old_rows)
+        self.adam.set_skip_words([pc.overflow_word])
         self._graph, self._eager_steps = None, 0   # buffers moved: the captured step is stale
 
     @torch.no_grad()
@@ -454,6 +466,8 @@ class AvatarBatchStep(AvatarStep):
         self._eager_steps = 0
         self._chain_graph = None           # (captured over the old lanes' buffers)
         self._ready = torch.cuda.Event()
+        # one overflowed view skips the whole step (its zero gradient would otherwise be averaged in)
+        self.adam.set_skip_words([L.pc.overflow_word for L in self.lanes])
 
     # ---- the step
     def _capture_lanes(self):
@@ -485,11 +499,11 @@ class AvatarBatchStep(AvatarStep):
         for L in self.lanes:
             L.pc.begin_step()
             if self.fold_binding:
-                frames.append(_RawFrame(L.pc, (L.xyz_gradient_accum, L.denom)))
+                frames.append(_RawFrame(L.pc, (L.xyz_gradient_accum, L.denom, L.pc.overflow_word)))
                 continue
             xyz, rot, scl = bind_gaussians(L.verts, self.faces, L.pc.face_index, L.pc.bary_coords, self.face_scale_canonical,
                                            L.pc._offset, L.pc._rotation, L.pc._scaling, self.shell_len, self.resize_scale)
-            frames.append(_BoundFrame(xyz, L.pc, rot, scl, (L.xyz_gradient_accum, L.denom)))
+            frames.append(_BoundFrame(xyz, L.pc, rot, scl, (L.xyz_gradient_accum, L.denom, L.pc.overflow_word)))
         if self.fold_binding:
             outs = render_bound_batch([L.cam for L in self.lanes], frames, [L.verts for L in self.lanes], self._binding(self.pc),
                                       self.bg, slots=[L.k for L in self.lanes])
@@ -504,6 +518,7 @@ class AvatarBatchStep(AvatarStep):
         torch.autograd.backward(images, grad_tensors=grads)
         flat = [L.pc.collect_grads() for L in self.lanes]
         if self.exchange:                          # sum of the local lanes, then the sum over the ranks; Adam scales
+            flat = [L.pc.exchange_buffer() for L in self.lanes]   # (gradients + overflow words: the words add up too)
             for g in flat[1:]:
                 flat[0].add_(g)
             if self.exchange_in_graph or not torch.cuda.is_current_stream_capturing():
@@ -579,6 +594,7 @@ class AvatarBatchStep(AvatarStep):
             main.wait_event(L.done)
         grads = [L.pc.flat_grad for L in self.lanes]
         if self.exchange:                          # sum of the local lanes, then the sum over the ranks; Adam scales
+            grads = [L.pc._grad_store for L in self.lanes]        # (gradients + overflow words: the words add up too)
             for g in grads[1:]:
                 grads[0].add_(g)
             dp.allreduce_sum_(grads[0])
@@ -597,8 +613,9 @@ class AvatarBatchStep(AvatarStep):
             captured = True
         # Every step polls the lanes' pinned count slots (a host read, no synchronisation): the counts are those of the
         # most recent replay that has FINISHED, so an overflow inside the captured chain is seen one or two steps late.
-        # Those replays back-propagated zeros for the overflowed view (Adam still stepped on its momentum): they are
-        # counted and named — `overflow_steps` — and the chain is captured again with the raised capacity.
+        # Those replays back-propagated zeros for the overflowed view — and their Adam launch SKIPPED the step on the device
+        # (the view's overflow word, FusedAdam.set_skip_words): nothing moved on a partly zero gradient.  They are counted
+        # and named — `overflow_steps` — and the chain is captured again with the raised capacity.
         self._step_no = getattr(self, "_step_no", 0) + 1
         if captured:
             for L in self.lanes:
@@ -608,9 +625,9 @@ class AvatarBatchStep(AvatarStep):
                         self.overflow_steps = getattr(self, "overflow_steps", []) + [self._step_no - 1]
                         import warnings   # (every occurrence: each one is a step whose view contributed a zero gradient)
                         warnings.warn(f"AvatarBatchStep: the binning capacity overflowed inside the captured chain around step "
-                                      f"{self._step_no - 1} (view {L.k}, occurrence {self.overflows}); that view back-propagated zeros "
-                                      "(Adam stepped on the other views' gradients and its momentum; with a data-parallel exchange "
-                                      "the zero was averaged in on every rank), the chain is captured again with a larger capacity")
+                                      f"{self._step_no - 1} (view {L.k}, occurrence {self.overflows}); that view back-propagated zeros and "
+                                      "the optimizer skipped the affected step(s) on every rank; the chain is captured again with a "
+                                      "larger capacity")
                         self._drop_graphs()
                         captured = False
                         break

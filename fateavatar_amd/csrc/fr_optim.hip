@@ -32,6 +32,8 @@ struct AdamArgs {
     unsigned seg_period[FR_ADAM_MAX_SEGMENTS], seg_split[FR_ADAM_MAX_SEGMENTS];
     float seg_lr2[FR_ADAM_MAX_SEGMENTS];
     float beta1, beta2, omb1, omb2, eps, grad_scale;  // omb = 1 - beta, rounded from double
+    int n_skip;                                        // fr_adam_config::skip: any non-zero word -> the step does nothing
+    const float* skip[FR_ADAM_MAX_GRADS];
 };
 
 // state = {step, 1 - beta1^step, 1 - beta2^step, -, ..., done-counters from word 32}: advanced on the device so that the host passes
@@ -74,6 +76,10 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a, float4* __restrict__ p
                                               float4* __restrict__ exp_avg, float4* __restrict__ exp_avg_sq,
                                               unsigned long long n, float* state)
 {
+    // a frame that feeds this step overflowed its binning capacity inside a replayed graph and back-propagated zeros
+    // (fr_aux::overflow_out): the whole step is skipped — every workgroup takes the same decision from the same words
+    for (int k = 0; k < a.n_skip; k++)
+        if (a.skip[k][0] != 0.0f) return;
     const float step_new = state[0] + 1.0f;
     const float bc1 = a.omb1 + a.beta1 * state[1], bc2 = a.omb2 + a.beta2 * state[2];
     const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -137,6 +143,8 @@ int launch_adam(const fr_adam_config& cfg, float* param, const float* const* gra
     }
     a.beta1 = (float)cfg.beta1, a.beta2 = (float)cfg.beta2, a.eps = (float)cfg.eps, a.grad_scale = cfg.grad_scale;
     a.omb1 = (float)(1.0 - cfg.beta1), a.omb2 = (float)(1.0 - cfg.beta2);
+    a.n_skip = cfg.n_skip < 0 ? 0 : (cfg.n_skip > FR_ADAM_MAX_GRADS ? FR_ADAM_MAX_GRADS : cfg.n_skip);
+    for (int k = 0; k < FR_ADAM_MAX_GRADS; k++) a.skip[k] = k < a.n_skip ? cfg.skip[k] : nullptr;
     const unsigned long long quads = (n + 3) / 4;
     unsigned long long blocks = (quads + 255) / 256;
     if (blocks > 2048) blocks = 2048;

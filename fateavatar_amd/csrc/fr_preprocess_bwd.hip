@@ -34,6 +34,7 @@ struct PreBwdArgs {
     fr_grads out;
     float* grad_accum;  // optional (fr_aux): += ||dL_dmeans2D[:, :2]|| of visible Gaussians
     float* denom;       // optional (fr_aux): += 1 for visible Gaussians
+    float* overflow_out;  // optional (fr_aux): 1.0f if the frame overflowed its binning capacity (all gradients zero), else 0.0f
     const DeviceCounts* counts;   // the frame's counts: an overflowed frame (nothing was blended) adds nothing to the statistics
     uint32_t acc;       // bit k: ADD into the k-th array of fr_grads instead of overwriting it (FR_FLAG_ACCUMULATE)
     int bound;          // fr_aux::binding: the gradients of mean / rotation / scale continue through `bind` into `bg`
@@ -414,6 +415,8 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a)
     if ((int)(blockIdx.x * blockDim.x) >= a.P) return;   // (a batched launch's grid is the largest view's)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (fr_aux::overflow_out: the step's optimizer kernel reads it — fr_adam_config::skip)
+    if (a.overflow_out && blockIdx.x == 0 && threadIdx.x == 0) *a.overflow_out = a.counts->overflow ? 1.0f : 0.0f;
     const int M3 = a.M * 3, stride = M3 | 1;
     const int wave_first = blockIdx.x * (64 * kPreBwdWaves) + wave * 64;
     const int rows = min(64, a.P - wave_first);
@@ -472,6 +475,7 @@ int launch_backward(int n, const BackwardCall* calls, hipStream_t s)
         a.radii = calls[k].radii, a.g = g[k], a.out = *calls[k].grads;
         a.grad_accum = prm.aux ? prm.aux->grad_accum : nullptr;
         a.denom = prm.aux ? prm.aux->denom : nullptr;
+        a.overflow_out = prm.aux ? prm.aux->overflow_out : nullptr;
         a.counts = v[k].counts;
         a.acc = ((uint32_t)prm.flags >> FR_FLAG_ACCUMULATE_SHIFT) & 0xFFu;
         a.bound = (prm.aux && prm.aux->binding) ? 1 : 0;

@@ -70,7 +70,12 @@ class FlatGaussians(torch.nn.Module):
         sizes = [P * w for w in self.widths()]
         shapes = [(P, 3), (P, self.M, 3), (P, 1), (P, 3), (P, 4)]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros_like(self.flat)
+        # the gradient buffer, and behind it (same allocation, so that ONE all-reduce carries both) the step's OVERFLOW WORD:
+        # the rasterizer's backward sets it to 1 when its frame overflowed the binning capacity inside a replayed graph (all
+        # its gradients are zero then), and the fused Adam skips a step whose word — summed over lanes and ranks — is not 0
+        self._grad_store = torch.zeros(sum(sizes) + 4, dtype=torch.float32, device=device)
+        self.flat_grad = self._grad_store[:sum(sizes)]
+        self.overflow_word = self._grad_store[sum(sizes):sum(sizes) + 1]
         self._grad_views = {}
         off = 0
         for (name, _), n, shp, r in zip(self.FIELDS, sizes, shapes, raw):
@@ -151,6 +156,11 @@ class FlatGaussians(torch.nn.Module):
             slot = getattr(getattr(self, name), "_fr_grad_out", None)
             if slot is not None:
                 slot.add_to_kept = bool(on)
+
+    def exchange_buffer(self) -> torch.Tensor:
+        """`collect_grads()` + the overflow word behind it: what a data-parallel step all-reduces (SUM)."""
+        self.collect_grads()
+        return self._grad_store
 
     def collect_grads(self) -> torch.Tensor:
         """After backward: make `flat_grad` hold every parameter's gradient (xyz / features are already there;

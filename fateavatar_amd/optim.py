@@ -96,6 +96,22 @@ class FusedAdam:
     def set_grad_scale(self, s: float) -> None:
         self.cfg.grad_scale = float(s)
 
+    def set_skip_words(self, words: Sequence[torch.Tensor]) -> None:
+        """Device floats (0 .. FR_ADAM_MAX_GRADS one-element tensors) that make a step a no-op when any of them is non-zero
+        — the overflow words the rasterizer's backward writes (fr_aux::overflow_out): a frame that overflowed its binning
+        capacity inside a replayed graph back-propagated zeros, and a step on such a gradient is skipped (parameters,
+        moments and step count untouched) instead of moving on momentum alone."""
+        words = list(words)
+        if len(words) > _lib.FR_ADAM_MAX_GRADS:
+            raise RuntimeError(f"at most {_lib.FR_ADAM_MAX_GRADS} skip words")
+        for w in words:
+            if not (w.is_cuda and w.dtype == torch.float32 and w.numel() >= 1):
+                raise RuntimeError("skip words are float32 device tensors")
+        self._skip_words = words      # (keeps them alive)
+        for k in range(_lib.FR_ADAM_MAX_GRADS):
+            self.cfg.skip[k] = words[k].data_ptr() if k < len(words) else None
+        self.cfg.n_skip = len(words)
+
     @torch.no_grad()
     def step(self, grads: Optional[Sequence[torch.Tensor]] = None) -> None:
         """One Adam step on `self.grad` — or, given `grads` (1 .. FR_ADAM_MAX_GRADS flat buffers laid out like the

@@ -126,16 +126,28 @@ def _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, prefiltered,
     return prm
 
 
-def _aux(visible=None, grad_accum=None, denom=None, binding=None, bind_grads=None):
+def _stats3(stats):
+    """(xyz_gradient_accum, denom[, overflow word]) -> the three of them (None where absent)."""
+    if stats is None:
+        return None, None, None
+    return stats[0], stats[1], (stats[2] if len(stats) > 2 else None)
+
+
+def _aux(visible=None, grad_accum=None, denom=None, binding=None, bind_grads=None, overflow_out=None):
     """fr_aux (optional fused side inputs / outputs) from torch tensors, or None if nothing is asked for.  `binding`: an
     `_lib.fr_binding` descriptor (the frame is rendered straight from its mesh binding); `bind_grads`: dict with the
     backward's d_verts / d_offset / d_rotation / d_scaling tensors (any may be None)."""
-    if visible is None and grad_accum is None and denom is None and binding is None:
+    if visible is None and grad_accum is None and denom is None and binding is None and overflow_out is None:
         return None
     for t, dt in ((visible, (torch.bool, torch.uint8)), (grad_accum, (torch.float32,)), (denom, (torch.float32,))):
         if t is not None and (t.dtype not in dt or not t.is_contiguous() or not t.is_cuda):
             raise RuntimeError("fused side outputs must be contiguous device tensors (bool/uint8 mask, float32 stats)")
     aux = _lib.fr_aux(*(t.data_ptr() if t is not None else None for t in (visible, grad_accum, denom)))
+    if overflow_out is not None:
+        if not (overflow_out.is_cuda and overflow_out.dtype == torch.float32 and overflow_out.numel() >= 1 and overflow_out.is_contiguous()):
+            raise RuntimeError("the overflow word must be a contiguous float32 device tensor")
+        aux._overflow_keepalive = overflow_out
+        aux.overflow_out = overflow_out.data_ptr()
     if binding is not None:
         aux._binding_keepalive = binding
         aux.binding = C.pointer(binding)
@@ -247,7 +259,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
     L = _lib.lib()
     h = _lib.handle(dev, _slot)
-    aux = _aux(grad_accum=_stats[0], denom=_stats[1]) if _stats is not None else None
+    aux = _aux(grad_accum=_stats3(_stats)[0], denom=_stats3(_stats)[1], overflow_out=_stats3(_stats)[2]) if _stats is not None else None
     prm = _params(P, degree, M, W, H, tan_fovx, tan_fovy, scale_modifier, False, debug, _raw, aux, acc_flags)
     inp = _inputs(background, means3D, sh, colors, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                   campos)
@@ -388,7 +400,7 @@ def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None,
         viewmatrix, projmatrix, campos = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
         dL_dout_color = _f32c(dL_dout_color)
         radii = radii.contiguous()
-        aux = _aux(grad_accum=stats[k][0] if stats[k] is not None else None, denom=stats[k][1] if stats[k] is not None else None,
+        aux = _aux(grad_accum=_stats3(stats[k])[0], denom=_stats3(stats[k])[1], overflow_out=_stats3(stats[k])[2],
                    binding=bindings[k], bind_grads=bind_grads[k])
         v = dict(g=g, keep=(background, means3D, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos,
                             dL_dout_color, radii, geomBuffer, binningBuffer, imageBuffer),

@@ -53,10 +53,13 @@ class TrainStep:
             (P * 3, lr["xyz"]),
             (P * M * 3, lr["feature_dc"], M * 3, 3, lr["feature_rest"]),
             (P, lr["opacity"]), (P * 3, lr["scaling"]), (P * 4, lr["rotation"])], grad_scale=1.0 / self.world)
+        # a replayed frame that overflowed its binning capacity back-propagates zeros: the rasterizer's backward says so in
+        # the word behind the gradient buffer (summed over ranks by the same all-reduce) and the update skips that step
+        self.adam.set_skip_words([pc.overflow_word])
         # _add_densification_stats accumulators (model/fateavatar.py:186-188,734-737), updated by the backward kernel
         self.xyz_gradient_accum = torch.zeros((P, 1), device=self.dev)
         self.denom = torch.zeros((P, 1), device=self.dev)
-        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom)
+        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom, pc.overflow_word)
         # static inputs of the captured step
         self.cam = camera
         self.gt = torch.zeros((3, camera.image_height, camera.image_width), device=self.dev)
@@ -82,7 +85,7 @@ class TrainStep:
         self.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
 
     def _exchange_and_update(self):
-        dp.allreduce_sum_(self.pc.collect_grads())  # Adam applies grad_scale = 1 / world
+        dp.allreduce_sum_(self.pc.exchange_buffer())  # gradients + overflow word; Adam applies grad_scale = 1 / world
         self.adam.step()
 
     def _body(self):
@@ -147,15 +150,17 @@ class TrainStep:
     def _poll_overflow(self):
         """The sort kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
         needs no synchronisation (they belong to the most recent frame that has got that far).  A replayed frame that
-        overflowed the capacity the graph was captured with produced no image and no gradients: raise the capacity,
-        drop the graph (the next steps run eagerly with the overflow check, then re-capture) and count the event."""
+        overflowed the capacity the graph was captured with produced no image and no gradients — and its Adam launch did
+        nothing (the overflow word the backward sets, FusedAdam.set_skip_words): raise the capacity, drop the graph (the
+        next steps run eagerly with the overflow check, then re-capture) and count the event."""
         from . import rasterizer
         if rasterizer.check_async_overflow(self.dev.index or 0):
             self.overflows += 1
             self._graph, self._eager_steps = None, 0
             import warnings   # (every occurrence: the replays since the overflow stepped Adam on a zero gradient)
             warnings.warn(f"{type(self).__name__}: the binning capacity overflowed inside the captured step (occurrence "
-                          f"{self.overflows}); the affected replays back-propagated zeros, the step runs eagerly and is captured again")
+                          f"{self.overflows}); the affected replays back-propagated zeros and their optimizer launch skipped the "
+                          "step (overflow word), the step runs eagerly and is captured again")
 
     # -- Gaussian maintenance (reference: train/iteration.py:62-86 -> model/fateavatar.py:610-731), generic-3DGS flavour:
     #    the FateAvatar versions additionally carry the mesh binding (face index, barycentrics) of every row
@@ -166,7 +171,8 @@ class TrainStep:
         # statistics restart from zero after a change of the point set (model/fateavatar.py:667-672)
         self.xyz_gradient_accum = torch.zeros((pc.P, 1), device=self.dev)
         self.denom = torch.zeros((pc.P, 1), device=self.dev)
-        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom)
+        pc.fused_densification_stats = (self.xyz_gradient_accum, self.denom, pc.overflow_word)
+        self.adam.set_skip_words([pc.overflow_word])
         self._graph, self._eager_steps = None, 0   # buffers moved: the captured step is stale
 
     @torch.no_grad()

@@ -99,6 +99,11 @@ typedef struct fr_aux {
     float* d_offset;
     float* d_rotation;
     float* d_scaling;
+    /* fr_backward out [1] (device float, or NULL): 1.0f if the frame this backward belongs to overflowed its binning capacity
+     * — nothing was blended, every gradient of the call is zero —, else 0.0f.  A step replayed from a hipGraph cannot react on
+     * the host before its optimizer kernel runs; fr_adam_config::skip points the update at these words instead (a step
+     * whose gradient is partly zeros for that reason is skipped, moments and step count included). */
+    float* overflow_out;
 } fr_aux;
 
 /* Frame parameters: the scalar arguments of Rasterizer::forward/backward. */
@@ -251,6 +256,12 @@ typedef struct fr_adam_config {
     float segment_lr2[FR_ADAM_MAX_SEGMENTS];
     double beta1, beta2, eps; /* doubles, like torch's hyper-parameters: 1 - beta is rounded to float from here */
     float grad_scale;
+    /* optional: n_skip (0 .. FR_ADAM_MAX_GRADS) device floats; if ANY of them is non-zero when the kernel runs the step does
+     * nothing — no parameter, no moment, no step count changes.  Point them at the fr_aux::overflow_out words of the frames
+     * whose gradients feed this step; in a data-parallel step keep those words behind the gradients in the exchanged buffer,
+     * so that the all-reduce sums them and every rank skips the same steps. */
+    const float* skip[4 /* FR_ADAM_MAX_GRADS */];
+    int32_t n_skip;
 } fr_adam_config;
 int fr_adam_step(const fr_adam_config* cfg, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                  uint64_t n, float* state, void* hip_stream);

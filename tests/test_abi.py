@@ -36,6 +36,7 @@ int main(void){
  printf("%zu %zu %zu %zu\n", sizeof(fr_params), sizeof(fr_inputs), sizeof(fr_grads), sizeof(fr_counts));
  printf("%zu %zu %zu\n", offsetof(fr_params, tan_fovx), offsetof(fr_params, debug), offsetof(fr_inputs, campos));
  printf("%zu %zu %zu %zu\n", sizeof(fr_aux), sizeof(fr_binding), offsetof(fr_aux, binding), offsetof(fr_aux, d_scaling));
+ printf("%zu %zu %zu %zu\n", offsetof(fr_aux, overflow_out), sizeof(fr_adam_config), offsetof(fr_adam_config, skip), offsetof(fr_adam_config, n_skip));
  return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
@@ -49,6 +50,8 @@ int main(void){
     assert sizes[5] == _lib.fr_params.debug.offset
     assert sizes[6] == _lib.fr_inputs.campos.offset
     assert sizes[7:11] == [C.sizeof(_lib.fr_aux), C.sizeof(_lib.fr_binding), _lib.fr_aux.binding.offset, _lib.fr_aux.d_scaling.offset]
+    assert sizes[11:15] == [_lib.fr_aux.overflow_out.offset, C.sizeof(_lib.fr_adam_config), _lib.fr_adam_config.skip.offset,
+                            _lib.fr_adam_config.n_skip.offset]
 
 
 def test_scratch_size_queries_are_sane_without_a_gpu():

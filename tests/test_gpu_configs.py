@@ -391,3 +391,61 @@ def test_bench_exchange_machinery_on_one_gpu_accumulates_rounds_in_place(gpu_dev
     # (amortised: the mean over rounds x 2 views; literal: view 0 alone — each the same whatever the number of rounds)
     assert sums[1][0] > 0 and abs(sums[3][0] - sums[1][0]) <= 2e-6 * sums[1][0], sums
     assert sums[1][1] > 0 and abs(sums[3][1] - sums[1][1]) <= 2e-6 * sums[1][1], sums
+
+
+def test_overflow_inside_the_captured_step_skips_the_update(gpu_device):
+    """A replayed step whose frame outgrows the binning capacity the graph was captured with back-propagates zeros, and the
+    host only learns of it a step later.  The rasterizer's backward says so on the device (fr_aux::overflow_out, the word
+    behind the flat gradient buffer) and the fused Adam skips that step — parameters, moments and the step count stay as
+    they were — instead of moving on momentum alone; the next step sees the counts, runs eagerly with a larger capacity and
+    is a normal step again.  (AvatarStep / AvatarBatchStep hand the same words to the same kernel: one per lane, one
+    overflowed view skips the whole step.)  In a subprocess: a fresh handle and capacity hint."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, math, warnings; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from fateavatar_amd import scenes, rasterizer\n"
+        "from fateavatar_amd.model import FlatGaussians, TorchCamera\n"
+        "from fateavatar_amd.render import render\n"
+        "from fateavatar_amd.train import TrainStep\n"
+        "dev = torch.device('cuda:0')\n"
+        "truth = scenes.head_scene(P=1500, res=256, sh_degree=1, seed=4, opacity=0.5)\n"
+        "cam = TorchCamera(truth.camera, dev)\n"
+        "bg = torch.from_numpy(truth.bg).to(dev)\n"
+        "mk = lambda k: FlatGaussians(truth.means3D, truth.shs * k, truth.opacities, truth.scales, truth.rotations, 1, dev, fused_activations=True)\n"
+        "with torch.no_grad():\n"
+        "    gt = render(cam, mk(1.0), bg)['render'].clone()\n"
+        "pc = mk(0.5)\n"
+        "ts = TrainStep(pc, cam, bg, use_graph=True)\n"
+        "for _ in range(5):\n"
+        "    ts.step(cam, gt)\n"
+        "torch.cuda.synchronize()\n"
+        "assert ts._graph is not None and ts.overflows == 0 and ts.adam.step_count == 5\n"
+        "assert float(pc.overflow_word) == 0.0\n"
+        "cap_now = rasterizer._capacity_hint[0]\n"
+        "with torch.no_grad():\n"
+        "    pc._scaling.data.add_(math.log(40.0))     # the splats grow under the captured graph\n"
+        "torch.cuda.synchronize()\n"
+        "flat0, m0, v0 = pc.flat.clone(), ts.adam.exp_avg.clone(), ts.adam.exp_avg_sq.clone()\n"
+        "ts.step(cam, gt)                              # replayed: overflows the captured capacity\n"
+        "torch.cuda.synchronize()\n"
+        "c = rasterizer.read_counts(0)\n"
+        "assert c.overflow and c.num_instances > cap_now, (c.overflow, c.num_instances, cap_now)\n"
+        "assert float(pc.overflow_word) == 1.0\n"
+        "assert torch.equal(pc.flat, flat0) and torch.equal(ts.adam.exp_avg, m0) and torch.equal(ts.adam.exp_avg_sq, v0)\n"
+        "assert ts.adam.step_count == 5\n"
+        "with warnings.catch_warnings(record=True) as w:\n"
+        "    warnings.simplefilter('always')\n"
+        "    ts.step(cam, gt)                          # the host sees the counts: eager, larger capacity, a normal step\n"
+        "torch.cuda.synchronize()\n"
+        "assert ts.overflows == 1 and any('overflowed' in str(x.message) for x in w)\n"
+        "assert ts.adam.step_count == 6 and float(pc.overflow_word) == 0.0 and not torch.equal(pc.flat, flat0)\n"
+        "for _ in range(4):\n"
+        "    ts.step(cam, gt)\n"
+        "torch.cuda.synchronize(); ts.check()\n"
+        "assert ts.adam.step_count == 10 and ts._graph is not None and ts.overflows == 1\n"
+        "print('gated-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert "gated-ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
