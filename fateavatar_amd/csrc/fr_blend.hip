@@ -179,14 +179,14 @@ __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
 
 // Which of the 64 pixels of tile (tile_x0, tile_y0) can pass the blend's alpha >= 1/255 test for this splat: a
 // conservative SUPERSET (bit 8*row + column), one x-interval per pixel row from the roots of
-//   a' dx^2 + (b' dy) dx + c' dy^2 >= -log2(255 opacity) - slack       (pre-scaled conic: the left side is log2 G).
+//   a' dx^2 + (b' dy) dx + c' dy^2 >= -ln(255 opacity) - slack       (the record's conic (-0.5 a, -b, -0.5 c): the left side is ln G).
 // The blend kernels walk only these pairs and apply the exact tests to each, so a bit too many costs one wasted
 // evaluation and a missing bit would change the image: the slack covers the fp32 evaluation error of log2 G in the
 // blend loops, and anything not plainly an ellipse (a' >= 0, NaN) selects the whole row.
 __device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, float b2, float c2, float opacity,
                                                 float tile_x0, float tile_y0)
 {
-    const float L = __builtin_amdgcn_logf(255.0f * opacity);   // v_log_f32 = log2; alpha >= 1/255 <=> log2 G >= -L
+    const float L = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opacity);   // ln (v_log_f32 is log2); alpha >= 1/255 <=> ln G >= -L
     // |terms| of log2 G near the footprint edge are O(L + 1); ill-conditioned conics cancel larger terms
     const float far_x = fmaxf(fabsf(x0 - tile_x0), fabsf(x0 - (tile_x0 + 7.f)));
     const float far_y = fmaxf(fabsf(y0 - tile_y0), fabsf(y0 - (tile_y0 + 7.f)));
@@ -512,9 +512,12 @@ constexpr uint32_t kUnitGrid = 8192;  // most workgroups (of 4 waves) of the ble
                                       // (config 5, ~30 k units: 8192 workgroups 70.6 us, 2048: 73.4, 1024: 75.4 — the dispatcher balances better than the stride)
 constexpr int kGroup = 4;
 
-// log2 of the Gaussian falloff of one (pixel, record) pair from the record's pre-scaled conic (write_record):
-// the reference's power = -0.5 (a dx^2 + c dy^2) - b dx dy (forward.cu:340), times log2(e)
-__device__ __forceinline__ float pair_log2G(float a2, float b2, float c2, float dx, float dy)
+// The exponent of the Gaussian falloff of one (pixel, record) pair from the record's conic — the reference's
+// power = -0.5 (a dx^2 + c dy^2) - b dx dy (forward.cu:340) — with the conic stored as (-0.5 a, -b, -0.5 c): scalings by powers of
+// two, so the record holds the reference's conic EXACTLY (the blend backward combines it with (dx, dy) per pixel, where an
+// extra rounding of a against b would be amplified by the cancellation of the two products).  G = exp2(power * log2(e)).
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float pair_power(float a2, float b2, float c2, float dx, float dy)
 {
     float p = (a2 * dx) * dx;
     p = fmaf(c2 * dy, dy, p);
@@ -660,11 +663,11 @@ __device__ __forceinline__ void bwd_unit_all_pairs(const float4* __restrict__ s_
             const float4 q1 = s_rec[(j + k) * kRecQuads + 1];
             const float q2x = s_rec[(j + k) * kRecQuads + 2].x;
             dx[k] = q0.x - fx, dy[k] = q0.y - fy;
-            // -log2(e) (a dx + b dy), -log2(e) (b dx + c dy): the pair's dG/d(centre) / G, from the pre-scaled conic
+            // -(a dx + b dy), -(b dx + c dy): the pair's dG/d(centre) / G, from the record's conic (-0.5 a, -b, -0.5 c)
             gx[k] = fmaf(2.f * q0.z, dx[k], q0.w * dy[k]);
             gy[k] = fmaf(2.f * q1.x, dy[k], q0.w * dx[k]);
-            const float power = pair_log2G(q0.z, q0.w, q1.x, dx[k], dy[k]);
-            araw[k] = q1.y * __builtin_amdgcn_exp2f(power);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
+            const float power = pair_power(q0.z, q0.w, q1.x, dx[k], dy[k]);
+            araw[k] = q1.y * __builtin_amdgcn_exp2f(power * kLog2e);  // opacity * G: alpha before the 0.99 clamp (1/255 < 0.99: same test)
             ok[k] = (j + k < lim) && !(power > 0.0f) && !(araw[k] < 1.0f / 255.0f);
             any_ok = any_ok || ok[k];
             cd[k] = (q1.z * dpr + q1.w * dpg) + q2x * dpb;  // colour . dL_dpixel
@@ -851,8 +854,8 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
             const float4 q1 = rec[j[k] * kRecQuads + 1];
             const float q2x = rec[j[k] * kRecQuads + 2].x;
             const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+            const float power = pair_power(q0.z, q0.w, q1.x, dx, dy);
+            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power * kLog2e));
             ok[k] = act[k] && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
             cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
         }
@@ -900,8 +903,8 @@ __device__ __forceinline__ WalkOut blend_unit_dense_local(const float4* __restri
             const float4 q1 = rec[(j + k) * kRecQuads + 1];
             const float q2x = rec[(j + k) * kRecQuads + 2].x;
             const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+            const float power = pair_power(q0.z, q0.w, q1.x, dx, dy);
+            alpha[k] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power * kLog2e));
             ok[k] = inside && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
             cr[k] = q1.z, cg[k] = q1.w, cb[k] = q2x;
         }
@@ -949,70 +952,73 @@ __device__ __forceinline__ void gather_tile(const ImageView& v, uint32_t tile, u
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, Tf = 1.0f;
     uint32_t ncon = 0;
-    uint32_t k_end = nu;   // units [k_end, nu) are dead for every pixel: the backward never reads their state
-    for (uint32_t base = 0; base < nu; base += R) {
+    if (nu <= (uint32_t)R) {   // short tile: one round of loads, the image front to back, the suffix pass on the registers
         float cr[R], cg[R], cb[R], To[R];
         uint32_t lw[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
+            const uint32_t kk = (uint32_t)k < nu ? (uint32_t)k : 0u;   // (clamped: the loads stay unconditional)
             const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
             cr[k] = load_row<COHERENT>(o), cg[k] = load_row<COHERENT>(o + kUnit), cb[k] = load_row<COHERENT>(o + 2 * kUnit);
             To[k] = load_row<COHERENT>(o + 3 * kUnit);
             lw[k] = __float_as_uint(load_row<COHERENT>(o + 4 * kUnit));
         }
-        bool all_dead = false;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            if (base + (uint32_t)k < nu) {
+            if ((uint32_t)k < nu) {
                 const bool dead = (lw[k] & kDeadBit) != 0u;
                 Cr += cr[k], Cg += cg[k], Cb += cb[k];   // (a dead pixel's contribution is stored as 0)
                 if (!dead) {
                     Tf = To[k];
                     if (lw[k] & ~kDeadBit) ncon = lw[k] & ~kDeadBit;
                 }
-                all_dead = __all(dead);
             }
         }
-        if (nu <= (uint32_t)R) {   // short tile: the suffix pass runs on the registers
-            float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-#pragma unroll
-            for (int k = R - 1; k >= 0; k--) {
-                if ((uint32_t)k < nu) {
-                    const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // (dead on entry: T may have underflowed)
-                    // (the tile's LAST unit has nothing behind it and leaves with final_T: the backward builds that state itself)
-                    if ((uint32_t)k + 1u < nu)
-                        unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
-                    Sr += cr[k], Sg += cg[k], Sb += cb[k];
-                }
-            }
-        } else if (all_dead) {
-            k_end = min(nu, base + (uint32_t)R);
-            break;
-        }
-    }
-    if (nu > (uint32_t)R) {
         float Sr = 0.f, Sg = 0.f, Sb = 0.f;
-        for (uint32_t base = (k_end - 1u) & ~(uint32_t)(R - 1);; base -= R) {
+#pragma unroll
+        for (int k = R - 1; k >= 0; k--) {
+            if ((uint32_t)k < nu) {
+                const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;   // (dead on entry: T may have underflowed)
+                // (the tile's LAST unit has nothing behind it and leaves with final_T: the backward builds that state itself)
+                if ((uint32_t)k + 1u < nu)
+                    unit_state[(size_t)(u0 + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
+                Sr += cr[k], Sg += cg[k], Sb += cb[k];
+            }
+        }
+    } else {
+        // long tile: ONE pass over the rows, back to front, eight units per round of loads — a unit's entry state is the sum
+        // of the rows behind it, the image the sum of all of them (in this order), the final transmittance and contributor
+        // count come from the last unit that was alive for the pixel.  (Units whose every pixel is dead get no state: the
+        // backward never reads it.)
+        float Sr = 0.f, Sg = 0.f, Sb = 0.f;
+        bool have_T = false, have_n = false;
+        for (uint32_t base = (nu - 1u) & ~(uint32_t)(R - 1);; base -= R) {
             float cr[R], cg[R], cb[R], To[R];
+            uint32_t lw[R];
 #pragma unroll
             for (int k = 0; k < R; k++) {
-                const uint32_t kk = base + (uint32_t)k < k_end ? base + (uint32_t)k : base;
+                const uint32_t kk = base + (uint32_t)k < nu ? base + (uint32_t)k : base;   // (clamped: the loads stay unconditional)
                 const float* o = g_out + (size_t)(u0 + kk) * 5 * kUnit + lane;
                 cr[k] = load_row<COHERENT>(o), cg[k] = load_row<COHERENT>(o + kUnit), cb[k] = load_row<COHERENT>(o + 2 * kUnit);
                 To[k] = load_row<COHERENT>(o + 3 * kUnit);
+                lw[k] = __float_as_uint(load_row<COHERENT>(o + 4 * kUnit));
             }
 #pragma unroll
             for (int k = R - 1; k >= 0; k--) {
-                if (base + (uint32_t)k < k_end) {
+                if (base + (uint32_t)k < nu) {
+                    const bool dead = (lw[k] & kDeadBit) != 0u;
+                    const uint32_t last = lw[k] & ~kDeadBit;
+                    if (!dead && !have_T) Tf = To[k], have_T = true;
+                    if (!dead && !have_n && last) ncon = last, have_n = true;
                     const float inv = (To[k] >= 0.0001f) ? __builtin_amdgcn_rcpf(To[k]) : 0.f;
-                    if (base + (uint32_t)k + 1u < nu)
+                    if (base + (uint32_t)k + 1u < nu && !__all(dead))
                         unit_state[(size_t)(u0 + base + (uint32_t)k) * kUnit + lane] = make_float4(Sr * inv, Sg * inv, Sb * inv, To[k]);
                     Sr += cr[k], Sg += cg[k], Sb += cb[k];
                 }
             }
             if (base == 0) break;
         }
+        Cr = Sr, Cg = Sg, Cb = Sb;
     }
     if (inside) {
         v.final_T[pix] = Tf;
@@ -1060,8 +1066,8 @@ __device__ __forceinline__ void pair_alpha_from_memory(const float4* __restrict_
 {
     const float4 q0 = r[0], q1 = r[1];
     const float dx = q0.x - fx, dy = q0.y - fy;
-    const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-    alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+    const float power = pair_power(q0.z, q0.w, q1.x, dx, dy);
+    alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power * kLog2e));
     ok = inside && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
     c0 = q1.z, c1 = q1.w, c2 = r[2].x;
 }
@@ -1505,8 +1511,8 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
         }
         S.pix[lane] = make_float4(dpr, dpg, dpb, 0.f);
         const float rxl = rq0.x - (float)tx0, ryl = rq0.y - (float)ty0;           // own record centre, tile-local
-        // own record's pre-scaled conic (a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise): phase B combines a pair's
-        // (dx, dy) with it per PIXEL — -log2(e) (a dx + b dy, b dx + c dy) = dG/d(centre) / G — as backward.cu:540-546 does
+        // own record's conic as stored, (a', b', c') = (-0.5 a, -b, -0.5 c) EXACTLY: phase B combines a pair's (dx, dy) with it
+        // per PIXEL — (2 a' dx + b' dy, b' dx + 2 c' dy) = -(a dx + b dy, b dx + c dy) = dG/d(centre) / G — as backward.cu:540-546 does
         const float ca2 = 2.f * rq0.z, cc2 = 2.f * rq1.x, cb1 = rq0.w;
 
         // ---- record ranges [lo, hi), from the back, each with at most kPairCap mask bits
@@ -1561,8 +1567,8 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
                     const float4 q1 = S.rec[j[k] * kRecQuads + 1];
                     const float4 q2 = S.rec[j[k] * kRecQuads + 2];
                     const float dx = q0.x - fx, dy = q0.y - fy;
-                    const float power = pair_log2G(q0.z, q0.w, q1.x, dx, dy);
-                    const float araw = q1.y * __builtin_amdgcn_exp2f(power);   // opacity * G (alpha before the 0.99 clamp)
+                    const float power = pair_power(q0.z, q0.w, q1.x, dx, dy);
+                    const float araw = q1.y * __builtin_amdgcn_exp2f(power * kLog2e);   // opacity * G (alpha before the 0.99 clamp)
                     const bool ok = act[k] && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
                     cd[k] = (q1.z * dpr + q1.w * dpg) + q2.x * dpb;              // colour . dL_dpixel
                     ar_e[k] = ok ? araw : 0.f;                                  // failed pair: alpha = 0, every update is the identity

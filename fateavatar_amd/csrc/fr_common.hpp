@@ -29,9 +29,10 @@ constexpr int kSortRegMax = 4096;    // longest list k_tile_sort_big sorts in re
 // accumulator slots (blend backward -> preprocess backward).  With q = dL/dG * G of a (pixel, Gaussian) pair
 // and d = splat centre - pixel, the slots hold the sums over pixels of:
 //   MX: q*gx   MY: q*gy   CA: q*dx*dx   CB: q*dx*dy   CC: q*dy*dy   OP: q   R,G,B: alpha*T*dL/dpixel
-// with (gx, gy) = -log2(e) * (a dx + b dy, b dx + c dy) = (dG/d delx, dG/d dely) / G * log2(e): the pair's offset combined with
-// the conic PER PIXEL, as the reference does (backward.cu:540-546) — summing q*dx and q*dy and combining afterwards lets the
-// two products of an elongated splat cancel only after N pixels' worth of rounding.
+// with (gx, gy) = -(a dx + b dy, b dx + c dy) = (dG/d delx, dG/d dely) / G: the pair's offset combined with the conic PER PIXEL,
+// as the reference does (backward.cu:540-546), and with the reference's conic itself (the record stores it scaled by powers
+// of two only) — summing q*dx and q*dy and combining afterwards lets the two products of an elongated splat cancel only after
+// N pixels' worth of rounding, and a conic whose entries were rounded independently puts its rounding into that cancellation.
 // k_preprocess_bwd turns them into the reference's dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.
 enum { ACC_MX = 0, ACC_MY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8 };
 
@@ -62,7 +63,7 @@ __host__ __device__ static inline T* carve(char*& p, size_t count)
 struct GeomView {
     float4* rec_tmpl;       // [P*3] the 48-byte splat RECORD the blend kernels gather for every (tile, Gaussian) instance:
                             // (x, y, a', b'), (c', opacity, r, g), (b, id, depth, 0) with the pixel-space centre, the
-                            // conic pre-scaled for v_exp_f32 (fr_blend.hip) and the colour fed to the blend (SH result or
+                            // conic as (a', b', c') = (-0.5 a, -b, -0.5 c) (fr_blend.hip: pair_power) and the colour fed to the blend (SH result or
                             // colors_precomp) — ONE 48-byte gather per instance, not three
     float* opacity_act;     // [P] the activated opacity (the backward's API does not take the opacities; the conic is NOT stored:
                             // k_preprocess_bwd computes the 2D covariance again anyway and inverts it with the forward's expressions)

@@ -325,12 +325,12 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
             key_depth = p_view.z;
             a.g.opacity_act[idx] = opacity;
             {
-                // the blend record (GeomView::rec_tmpl): the conic pre-scaled so that the blend loops get
-                // log2(G) = a'dx^2 + c'dy^2 + b'dxdy straight into v_exp_f32: a' = -0.5 log2(e) a, b' = -log2(e) b, c' likewise
-                constexpr float kLog2e = 1.4426950408889634f;
+                // the blend record (GeomView::rec_tmpl): the conic as (-0.5 a, -b, -0.5 c) — exact scalings — so that the blend
+                // loops get the reference's power = a'dx^2 + c'dy^2 + b'dxdy (forward.cu:340) in three multiply-adds, and the
+                // blend backward the reference's conic itself
                 float4* t = a.g.rec_tmpl + (size_t)idx * 3;
-                t[0] = make_float4(pix_x, pix_y, conic_a * (-0.5f * kLog2e), conic_b * (-kLog2e));
-                t[1] = make_float4(conic_c * (-0.5f * kLog2e), opacity, col[0], col[1]);
+                t[0] = make_float4(pix_x, pix_y, conic_a * -0.5f, -conic_b);
+                t[1] = make_float4(conic_c * -0.5f, opacity, col[0], col[1]);
                 t[2] = make_float4(col[2], __uint_as_float((uint32_t)idx), p_view.z, 0.f);   // (.z: view-space depth, for diagnostics)
             }
             a.g.clamped[idx] = clamp_bits;

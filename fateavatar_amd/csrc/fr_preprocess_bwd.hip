@@ -158,10 +158,9 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreBwdArgs& a, const Ca
     // forward's expressions (forward.cu:74-113, 207-219) — the same bits; only the activated opacity comes from the state.
     const float det_inv = 1.f / denom;
     const float4 co = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, a.g.opacity_act[idx]);
-    // (ACC_MX / ACC_MY arrive combined with the conic per pixel, scaled by -log2(e): fr_common.hpp)
-    constexpr float kInvLog2e = 0.6931471805599453f;
-    const float g2x = (acc[ACC_MX] * kInvLog2e) * (0.5f * a.W);
-    const float g2y = (acc[ACC_MY] * kInvLog2e) * (0.5f * a.H);
+    // (ACC_MX / ACC_MY arrive combined with the conic per pixel: sum of q * dG/d(centre) / G, fr_common.hpp)
+    const float g2x = acc[ACC_MX] * (0.5f * a.W);
+    const float g2y = acc[ACC_MY] * (0.5f * a.H);
     const float dcx = -0.5f * acc[ACC_CA], dcy = -0.5f * acc[ACC_CB], dcz = -0.5f * acc[ACC_CC];
     const float dop = (co.w != 0.f) ? acc[ACC_OP] / co.w : 0.f;
     float dcol[3] = {acc[ACC_R], acc[ACC_G], acc[ACC_B]};

@@ -45,12 +45,10 @@ def _check_forward(o, h, name):
     m2 = h.geometry(0, 2)
     np.testing.assert_array_equal(m2[vis], o.means2D[vis])
     np.testing.assert_array_equal(h.geometry(1, 1)[vis, 0], o.depths[vis])
-    # conic + opacity: kept only inside the 48-byte blend record, the conic pre-scaled for v_exp_f32 (a' = -0.5 log2(e) a,
-    # b' = -log2(e) b, c' = -0.5 log2(e) c: one float32 multiplication each, repeated here)
+    # conic + opacity: kept only inside the 48-byte blend record, the conic as (-0.5 a, -b, -0.5 c): exact scalings
     rec = h.geometry(8, 12)
-    k = np.float32(1.4426950408889634)
     co = o.conic_opacity.astype(np.float32)
-    want = np.stack([co[:, 0] * (np.float32(-0.5) * k), co[:, 1] * (-k), co[:, 2] * (np.float32(-0.5) * k), co[:, 3]], axis=1)
+    want = np.stack([co[:, 0] * np.float32(-0.5), -co[:, 1], co[:, 2] * np.float32(-0.5), co[:, 3]], axis=1)
     np.testing.assert_array_equal(rec[vis, 2:6], want[vis])
     np.testing.assert_array_equal(h.geometry(3, 4)[vis, :3], o.rgb[vis] if o._inputs["colors_precomp"] is None
                                   else o._inputs["colors_precomp"][vis])
