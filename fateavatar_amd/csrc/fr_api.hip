@@ -312,7 +312,7 @@ const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t fie
     switch (field) {
         case 0: return nullptr;   // (pixel-space centres: columns 0-1 of field 8)
         case 1: return nullptr;   // (view-space depth: column 10 of field 8)
-        case 2: return nullptr;   // (conic + opacity: columns 2-5 of field 8 hold them pre-scaled; the conic itself is not stored)
+        case 2: return nullptr;   // (conic + opacity: columns 2-5 of field 8 hold (-0.5 a, -b, -0.5 c, opacity))
         case 3: return nullptr;   // (colours: columns 6-8 of field 8)
         case 4: return nullptr;   // (Sigma3D is not stored any more: both per-Gaussian kernels compute it)
         case 5: return nullptr;   // (the 8x8-tile rectangle is no longer stored)

@@ -181,13 +181,13 @@ __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
 // conservative SUPERSET (bit 8*row + column), one x-interval per pixel row from the roots of
 //   a' dx^2 + (b' dy) dx + c' dy^2 >= -ln(255 opacity) - slack       (the record's conic (-0.5 a, -b, -0.5 c): the left side is ln G).
 // The blend kernels walk only these pairs and apply the exact tests to each, so a bit too many costs one wasted
-// evaluation and a missing bit would change the image: the slack covers the fp32 evaluation error of log2 G in the
+// evaluation and a missing bit would change the image: the slack covers the fp32 evaluation error of ln G in the
 // blend loops, and anything not plainly an ellipse (a' >= 0, NaN) selects the whole row.
 __device__ __forceinline__ uint2 footprint_mask(float x0, float y0, float a2, float b2, float c2, float opacity,
                                                 float tile_x0, float tile_y0)
 {
     const float L = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opacity);   // ln (v_log_f32 is log2); alpha >= 1/255 <=> ln G >= -L
-    // |terms| of log2 G near the footprint edge are O(L + 1); ill-conditioned conics cancel larger terms
+    // |terms| of ln G near the footprint edge are O(L + 1); ill-conditioned conics cancel larger terms
     const float far_x = fmaxf(fabsf(x0 - tile_x0), fabsf(x0 - (tile_x0 + 7.f)));
     const float far_y = fmaxf(fabsf(y0 - tile_y0), fabsf(y0 - (tile_y0 + 7.f)));
     const float mag = fabsf(a2) * far_x * far_x + fabsf(c2) * far_y * far_y + fabsf(b2) * far_x * far_y;

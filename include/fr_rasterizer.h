@@ -337,7 +337,7 @@ const uint32_t* fr_image_n_contrib(const void* image, int32_t W, int32_t H);
  * fr_forward.  field: 6 clamped (uint8 bitmask), 8 the blend-record
  * template (12 floats: x, y, a', b', c', opacity, r, g, b, id bits, depth, 0 — the pixel-space centre, the view-space
  * depth and the colour that fields 0, 1 and 3 used to hold are its columns 0-1, 10 and 6-8; 2 was conic_opacity (the
- * pre-scaled conic and the opacity are columns 2-5; the backward inverts its own 2D covariance), 4 was cov3D, which is no
+ * conic as (-0.5 a, -b, -0.5 c) and the opacity are columns 2-5; the backward inverts its own 2D covariance), 4 was cov3D, which is no
  * longer stored (both per-Gaussian kernels compute it); 5 was the tile rectangle, 7 the gradient accumulators: they
  * live in the handle now).  NULL for any other field. */
 const void* fr_debug_geometry_field(const void* geometry, int32_t P, int32_t field);
