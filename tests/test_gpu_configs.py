@@ -139,31 +139,47 @@ def test_fuzz_regression_image_sized_splats(gpu_device):
     elongated splat the two products nearly cancel, and the rounding error of a SUM over N pixels that is combined
     afterwards grows like N instead of sqrt(N) — visible only when N is 1e4 .. 1e5 pixels per splat.  The kernel combines
     per pixel now (ACC_MX / ACC_MY, fr_common.hpp): held to 1e-4 in aggregate like every scene, with no row exempt."""
-    kw = dict(sh_degree=1, seed=94317314, spread=1.134029611696778, scale_lo=0.02388334673519118, scale_hi=0.1873148655148575,
-              opacity_lo=0.2519240224445132, opacity_hi=0.3490066171734876, behind_fraction=0.1, M=16,
-              bg=(0.5623222519413001, 0.9073807768081659, 0.760648176186418))
-    s = scenes.random_scene(29994, 502, 715, **kw)
+    _, P, H, W, kw, dpix, _ = util.fuzz_case(991, 61, big=True)
+    assert (P, H, W, kw["seed"]) == (29994, 502, 715, 94317314)
+    s = scenes.random_scene(P, H, W, **kw)
     o = util.oracle_forward(s)
     h = util.HipFrame(s, gpu_device)
     _check_forward(o, h, "fuzz991-61")
-    dpix = _fuzz991_dpix(61)
     _check_backward_capped(o, h, dpix, "fuzz991-61", max_skip_frac=0.05)
 
 
-def _fuzz991_dpix(k):
-    """dL/dpixel of iteration k of `tools/fuzz_parity.py 80 991 big`: the tool's stream of draws, replayed."""
-    rng = np.random.default_rng(991)
-    for it in range(k + 1):
-        P = int(rng.integers(1, 60000))
-        H, W = int(rng.integers(8, 900)), int(rng.integers(8, 900))
-        deg = int(rng.integers(0, 4))
-        slo = float(10 ** rng.uniform(-3.5, -1.5)); _ = slo * float(rng.uniform(1, 20))
-        olo = float(rng.uniform(0.001, 0.5)); _ = float(rng.uniform(olo, 1.0))
-        _ = float(rng.uniform(0.05, 1.5))
-        _ = (int(rng.integers(1 << 30)), float(rng.choice([0.0, 0.1])), int(rng.choice([(deg + 1) ** 2, 16])), tuple(rng.uniform(0, 1, 3)))
-        d = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
-    assert (P, H, W) == (29994, 502, 715), (P, H, W)
-    return d
+def test_fuzz_regression_conic_rounding(gpu_device):
+    """`tools/fuzz_parity.py 5000 9001`, iteration 4055 (round 5): 2 979 Gaussians up to 0.21 of the scene wide in a 79 x 122
+    image — radii of several hundred pixels.  dL/dmeans2D came out at rel-L2 2.18e-4 (floor 1e-6) while the blend record held the
+    conic pre-scaled for v_exp_f32 (-0.5 log2(e) a, -log2(e) b, ...): each entry carried its own rounding, and the per-pixel
+    combination a dx + b dy of an elongated splat cancels, which amplified it.  The record holds (-0.5 a, -b, -0.5 c) now —
+    exact — and the case sits at 1.8e-6."""
+    _, P, H, W, kw, dpix, name = util.fuzz_case(9001, 4055)
+    assert (P, H, W) == (2979, 79, 122)
+    s = scenes.random_scene(P, H, W, **kw)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "fuzz9001-4055")
+    _check_backward_capped(o, h, dpix, "fuzz9001-4055", max_skip_frac=0.05)
+    from tests.test_gpu_parity import ACHIEVED
+    got = ACHIEVED.get("fuzz9001-4055", ACHIEVED.get("fuzz9001-4055-no-exemptions"))
+    assert got["dL_dmeans2D"][0] <= 2e-5, got["dL_dmeans2D"]
+
+
+def test_fuzz_regression_termination_flip_below_the_forward_tolerance(gpu_device):
+    """`tools/fuzz_parity.py 1000 9002 big`, iteration 918 (round 5): 30 188 splats up to 0.08 of the scene wide, 423 x 728.  One
+    pixel (40, 379) ends at T = 1.0004e-4 in the oracle after 190 entries and at 1.0044e-4 here after 96: a termination flip
+    (T (1 - alpha) < 1e-4 decided within 0.8 % of the rounding margin) that moves the pixel's colour by 4.5e-5 — INSIDE the
+    forward tolerance, so the pixel was not recognised as a flip — and yet carried 0.2 % of dL/dcov3D of a splat 637 pixels in
+    radius (rel-L2 2.7e-4 of the whole array with every other pixel at 1e-6).  util.flip_pixels finds such pixels by their
+    RELATIVE change of T_final (any flip moves it by >= 0.39 %)."""
+    _, P, H, W, kw, dpix, name = util.fuzz_case(9002, 918, big=True)
+    assert (P, H, W) == (30188, 423, 728)
+    s = scenes.random_scene(P, H, W, **kw)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, "fuzz9002-918")
+    _check_backward_capped(o, h, dpix, "fuzz9002-918", max_skip_frac=0.05)
 
 
 def test_dead_pixel_next_to_live_pixels_gives_finite_gradients(gpu_device):

@@ -176,3 +176,34 @@ def assert_same_trajectory(a, b, what="", tight=5e-3, lr_max=0.05):
     frac = float((d < tight).double().mean())
     n_out = int((d >= tight).sum())
     assert rl <= 1e-3 and frac >= 0.9999 and n_out <= 64 and float(d.max()) <= 2 * lr_max, (what, rl, frac, n_out, float(d.max()))
+
+
+def fuzz_stream(seed, big=False):
+    """The configurations of `tools/fuzz_parity.py N SEED [big]`, in order: yields (k, P, H, W, kw, dL_dpixel, name) with
+    `scenes.random_scene(P, H, W, **kw)` the scene of iteration k.  One stream of draws, so that a campaign's case k can be
+    replayed (tools/diag/fuzz_replay.py, fuzz_bisect.py) and pinned as a regression test (tests/test_gpu_configs.py)."""
+    rng = np.random.default_rng(seed)
+    k = 0
+    while True:
+        P = int(rng.integers(1, 60000 if big else 6000))
+        H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
+        deg = int(rng.integers(0, 4))
+        slo = float(10 ** rng.uniform(-3.5, -1.5))
+        shi = slo * float(rng.uniform(1, 20))
+        olo = float(rng.uniform(0.001, 0.5))
+        ohi = float(rng.uniform(olo, 1.0))
+        spread = float(rng.uniform(0.05, 1.5))
+        kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
+                  opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
+                  bg=tuple(rng.uniform(0, 1, 3)))
+        dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+        name = f"fuzz{k}: P={P} {H}x{W} deg={deg} scale=[{slo:.4f},{shi:.4f}] op=[{olo:.3f},{ohi:.3f}] spread={spread:.2f}"
+        yield k, P, H, W, kw, dpix, name
+        k += 1
+
+
+def fuzz_case(seed, k, big=False):
+    """Iteration k of fuzz_stream(seed, big)."""
+    for c in fuzz_stream(seed, big):
+        if c[0] == k:
+            return c

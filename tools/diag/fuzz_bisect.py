@@ -16,18 +16,7 @@ from tests.test_gpu_parity import _flip_pixels  # noqa: E402
 
 K, seed, big = int(sys.argv[1]), int(sys.argv[2]), len(sys.argv) > 3
 key = os.environ.get("FUZZ_BWD", "dL_dcov3D")
-rng = np.random.default_rng(seed)
-for it in range(K + 1):
-    P = int(rng.integers(1, 60000 if big else 6000))
-    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
-    deg = int(rng.integers(0, 4))
-    slo = float(10 ** rng.uniform(-3.5, -1.5)); shi = slo * float(rng.uniform(1, 20))
-    olo = float(rng.uniform(0.001, 0.5)); ohi = float(rng.uniform(olo, 1.0))
-    spread = float(rng.uniform(0.05, 1.5))
-    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
-              opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
-              bg=tuple(rng.uniform(0, 1, 3)))
-    dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
+_, P, H, W, kw, dpix, _ = util.fuzz_case(seed, K, big)
 print(P, H, W, kw)
 s = scenes.random_scene(P, H, W, **kw)
 o = util.oracle_forward(s)

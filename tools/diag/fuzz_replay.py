@@ -11,19 +11,7 @@ from fateavatar_amd import scenes  # noqa: E402
 from tests import util  # noqa: E402
 
 K, seed, big = int(sys.argv[1]), int(sys.argv[2]), len(sys.argv) > 3
-rng = np.random.default_rng(seed)
-for it in range(K + 1):
-    P = int(rng.integers(1, 60000 if big else 6000))
-    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
-    deg = int(rng.integers(0, 4))
-    slo = float(10 ** rng.uniform(-3.5, -1.5)); shi = slo * float(rng.uniform(1, 20))
-    olo = float(rng.uniform(0.001, 0.5)); ohi = float(rng.uniform(olo, 1.0))
-    spread = float(rng.uniform(0.05, 1.5))
-    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
-              opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
-              bg=tuple(rng.uniform(0, 1, 3)))
-    if it < K:
-        rng.uniform(-1, 1, (3, H, W))   # (the dL/dpixel draw of fuzz_parity.py)
+_, P, H, W, kw, dpix, _ = util.fuzz_case(seed, K, big)
 print(P, H, W, kw)
 s = scenes.random_scene(P, H, W, **kw)
 o = util.oracle_forward(s)
@@ -38,13 +26,6 @@ for y, x in list(zip(*np.nonzero(bad)))[:12]:
           f"T hip {fT[y, x]:.6e} oracle {o.final_T[y, x]:.6e}  n_contrib hip {nc[y, x]} oracle {o.n_contrib[y, x]}")
 if os.environ.get("FUZZ_BWD"):
     from oracle import oracle
-    rng2 = np.random.default_rng(seed)
-    for it in range(K + 1):   # (replay fuzz_parity's stream once more for this case's dL/dpixel)
-        P_ = int(rng2.integers(1, 60000 if big else 6000))
-        H_, W_ = int(rng2.integers(8, 900 if big else 300)), int(rng2.integers(8, 900 if big else 300))
-        rng2.integers(0, 4); rng2.uniform(-3.5, -1.5); rng2.uniform(1, 20); o1 = rng2.uniform(0.001, 0.5); rng2.uniform(o1, 1.0)
-        rng2.uniform(0.05, 1.5); rng2.integers(1 << 30); rng2.choice([0.0, 0.1]); rng2.choice([1, 16]); rng2.uniform(0, 1, 3)
-        dpix = (rng2.uniform(-1, 1, (3, H_, W_)) / (H_ * W_)).astype(np.float32)
     ob, hb = oracle.backward(o, dpix), h.backward(dpix)
     k = os.environ["FUZZ_BWD"]
     ref, got = getattr(ob, k).reshape(P, -1), hb[k].reshape(P, -1)

@@ -1,31 +1,27 @@
-"""One-off fuzz: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box."""
-import sys, os, traceback
-import numpy as np, torch
+"""Fuzz campaign: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box.
+    python tools/fuzz_parity.py N SEED [big]        (FR_FUZZ_ONLY=k: only iteration k)
+The configurations come from tests/util.fuzz_stream; a failing iteration k is replayed with tools/diag/fuzz_replay.py /
+fuzz_bisect.py and pinned in tests/test_gpu_configs.py (test_fuzz_regression_*)."""
+import itertools
+import os
+import sys
+import traceback
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fateavatar_amd import scenes
-from tests import util
-from tests.test_gpu_parity import _check_forward, _check_backward_capped
-from oracle import oracle
+from fateavatar_amd import scenes  # noqa: E402
+from tests import util  # noqa: E402
+from tests.test_gpu_parity import _check_backward_capped, _check_forward  # noqa: E402
 
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
+big = len(sys.argv) > 3
 bad = 0
 kinds = {}
-for it in range(n):
-    big = len(sys.argv) > 3
-    P = int(rng.integers(1, 60000 if big else 6000))
-    H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
-    deg = int(rng.integers(0, 4))
-    slo = float(10 ** rng.uniform(-3.5, -1.5)); shi = slo * float(rng.uniform(1, 20))
-    olo = float(rng.uniform(0.001, 0.5)); ohi = float(rng.uniform(olo, 1.0))
-    spread = float(rng.uniform(0.05, 1.5))
-    kw = dict(sh_degree=deg, seed=int(rng.integers(1 << 30)), spread=spread, scale_lo=slo, scale_hi=shi, opacity_lo=olo,
-              opacity_hi=ohi, behind_fraction=float(rng.choice([0.0, 0.1])), M=int(rng.choice([(deg + 1) ** 2, 16])),
-              bg=tuple(rng.uniform(0, 1, 3)))
-    name = f"fuzz{it}: P={P} {H}x{W} deg={deg} scale=[{slo:.4f},{shi:.4f}] op=[{olo:.3f},{ohi:.3f}] spread={spread:.2f}"
+for it, P, H, W, kw, dpix, name in itertools.islice(util.fuzz_stream(seed, big), n):
     if os.environ.get("FR_FUZZ_ONLY") and it != int(os.environ["FR_FUZZ_ONLY"]):
-        rng.uniform(-1, 1, (3, H, W))   # (keeps the stream of draws of the full run)
         continue
     if os.environ.get("FR_FUZZ_PRINT_KW"):
         print("kw", it, dict(P=P, H=H, W=W, **kw), flush=True)
@@ -34,7 +30,6 @@ for it in range(n):
         o = util.oracle_forward(s)
         h = util.HipFrame(s, dev)
         _check_forward(o, h, name)
-        dpix = (rng.uniform(-1, 1, (3, H, W)) / (H * W)).astype(np.float32)
         # (as tests/test_gpu_configs.py: at most 5 % of the rows exempt by threshold flips, else the flips are masked out of
         # dL/dpixel and no row is exempt; aggregate bound 1e-4 for every scene)
         _check_backward_capped(o, h, dpix, name, max_skip_frac=0.05)
