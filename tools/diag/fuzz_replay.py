@@ -33,10 +33,20 @@ if os.environ.get("FUZZ_BWD"):
     err = np.abs(got - ref)
     bad = err > 1e-4 * np.abs(ref) + 1e-6 * scale
     print(k, "entries off:", int(bad.sum()), "of", bad.size, "scale", scale)
+    # what the reference's own float order does to the same entries (the oracle with seeded summation orders / nvcc-style
+    # contraction against its double sums: the floors of tests/test_gpu_parity.py::_check_backward)
+    alts = []
+    for sd, contract in ((1, False), (2, True), (3, False), (4, True)):
+        oracle.set_bwd_float_order(sd); oracle.set_bwd_contract(contract)
+        try:
+            alts.append(getattr(oracle.backward(o, dpix), k).reshape(P, -1))
+        finally:
+            oracle.set_bwd_float_order(0); oracle.set_bwd_contract(False)
     for i in np.argwhere(bad)[:10]:
         i = tuple(i)
         print("  id", i, "ref", ref[i], "got", got[i], "err/|ref|", err[i] / abs(ref[i]), "err/scale", err[i] / scale,
-              "radius", o.radii[i[0]], "opacity", o.conic_opacity[i[0], 3])
+              "radius", o.radii[i[0]], "opacity", o.conic_opacity[i[0], 3],
+              "| oracle float orders err/|ref|:", [float(abs(a[i] - ref[i]) / abs(ref[i])) for a in alts])
     # which rows carry the L2 error (flip-affected rows are excluded from the test's rel_l2)
     from tests.test_gpu_parity import _flip_affected_gaussians
     skip, n_flips = _flip_affected_gaussians(o, h)
