@@ -517,6 +517,29 @@ constexpr int kGroup = 4;
 // two, so the record holds the reference's conic EXACTLY (the blend backward combines it with (dx, dy) per pixel, where an
 // extra rounding of a against b would be amplified by the cancellation of the two products).  G = exp2(power * log2(e)).
 constexpr float kLog2e = 1.4426950408889634f;
+
+// Index of the lowest / highest set bit of a 64-bit mask — and SOME index in 0 .. 63 for an empty mask, without a select: v_ffbl_b32 /
+// v_ffbh_u32 return -1 for 0, so the unsigned minimum over the two halves (the other half's count + 32, which wraps to 31) stays in
+// range.  The walks below let an idle lane read a valid record or pixel and mask what it does with it (__builtin_ctzll(0) is
+// undefined, and the guarded form costs a v_cndmask per pair).
+__device__ __forceinline__ int low_bit_or_any(u64 m)
+{
+    uint32_t a, b;
+    asm("v_ffbl_b32 %0, %1" : "=v"(a) : "v"((uint32_t)m));
+    asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"((uint32_t)(m >> 32)));
+    const uint32_t r = min(a, b + 32u);
+    __builtin_assume(r < 64u);
+    return (int)r;
+}
+__device__ __forceinline__ int high_bit_or_any(u64 m)
+{
+    uint32_t a, b;
+    asm("v_ffbh_u32 %0, %1" : "=v"(a) : "v"((uint32_t)(m >> 32)));
+    asm("v_ffbh_u32 %0, %1" : "=v"(b) : "v"((uint32_t)m));
+    const uint32_t r = min(a, b + 32u);
+    __builtin_assume(r < 64u);
+    return 63 - (int)r;
+}
 __device__ __forceinline__ float pair_power(float a2, float b2, float c2, float dx, float dy)
 {
     float p = (a2 * dx) * dx;
@@ -843,7 +866,7 @@ __device__ __forceinline__ WalkOut walk_unit_fwd(const float4* __restrict__ rec,
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             act[k] = Bg != 0ull;
-            j[k] = act[k] ? (int)__builtin_ctzll(Bg) : 0;
+            j[k] = low_bit_or_any(Bg);
             Bg &= Bg - 1ull;
         }
         float alpha[2], cr[2], cg[2], cb[2];
@@ -1556,7 +1579,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
 #pragma unroll
                 for (int k = 0; k < kARecs; k++) {
                     act[k] = Bg != 0ull;
-                    j[k] = act[k] ? 63 - (int)__builtin_clzll(Bg) : 0;
+                    j[k] = high_bit_or_any(Bg);
                     Bg &= ~(1ull << j[k]);       // (no bits set: stays 0)
                 }
                 float ar_e[kARecs], cd[kARecs];
@@ -1603,7 +1626,7 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const bool act = Mg != 0ull;
-                    const int p = act ? (int)__builtin_ctzll(Mg) : 0;
+                    const int p = low_bit_or_any(Mg);
                     Mg &= Mg - 1ull;
                     float2 qw = S.pair[act ? slot : (uint32_t)kPairCap + (uint32_t)lane];
                     const float q = act ? qw.x : 0.f, wgt = act ? qw.y : 0.f;
