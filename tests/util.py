@@ -184,12 +184,17 @@ def fuzz_stream(seed, big=False):
     replayed (tools/diag/fuzz_replay.py, fuzz_bisect.py) and pinned as a regression test (tests/test_gpu_configs.py)."""
     rng = np.random.default_rng(seed)
     k = 0
+    huge = big == "huge"   # config-5-sized scenes: lists beyond 1 024 entries (k_tile_sort_big), regrown buffers; small splats only
     while True:
-        P = int(rng.integers(1, 60000 if big else 6000))
-        H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
+        if huge:
+            P = int(rng.integers(60000, 400000))
+            H, W = int(rng.integers(512, 1400)), int(rng.integers(512, 1400))
+        else:
+            P = int(rng.integers(1, 60000 if big else 6000))
+            H, W = int(rng.integers(8, 900 if big else 300)), int(rng.integers(8, 900 if big else 300))
         deg = int(rng.integers(0, 4))
-        slo = float(10 ** rng.uniform(-3.5, -1.5))
-        shi = slo * float(rng.uniform(1, 20))
+        slo = float(10 ** (rng.uniform(-3.5, -2.7) if huge else rng.uniform(-3.5, -1.5)))
+        shi = slo * float(rng.uniform(1, 6) if huge else rng.uniform(1, 20))
         olo = float(rng.uniform(0.001, 0.5))
         ohi = float(rng.uniform(olo, 1.0))
         spread = float(rng.uniform(0.05, 1.5))

@@ -1,5 +1,5 @@
 """Fuzz campaign: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box.
-    python tools/fuzz_parity.py N SEED [big]        (FR_FUZZ_ONLY=k: only iteration k)
+    python tools/fuzz_parity.py N SEED [big|huge]   (FR_FUZZ_ONLY=k: only iteration k; huge: 60 k - 400 k Gaussians, 512 - 1400 pixels a side)
 The configurations come from tests/util.fuzz_stream; a failing iteration k is replayed with tools/diag/fuzz_replay.py /
 fuzz_bisect.py and pinned in tests/test_gpu_configs.py (test_fuzz_regression_*)."""
 import itertools
@@ -17,7 +17,7 @@ from tests.test_gpu_parity import _check_backward_capped, _check_forward  # noqa
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
-big = len(sys.argv) > 3
+big = ("huge" if sys.argv[3] == "huge" else True) if len(sys.argv) > 3 else False
 bad = 0
 kinds = {}
 for it, P, H, W, kw, dpix, name in itertools.islice(util.fuzz_stream(seed, big), n):
