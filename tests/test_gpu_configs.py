@@ -130,6 +130,20 @@ def test_fuzz_random_configurations(seed, big, gpu_device):
     _check_backward_capped(o, h, _dpix(H, W, seed), name, max_skip_frac=0.05)
 
 
+@pytest.mark.parametrize("seed,k,big", [(9401, 0, False), (9401, 1, False), (9401, 2, False), (9401, 3, False), (9402, 0, True), (9402, 1, True)])
+def test_fuzz_random_cameras(seed, k, big, gpu_device):
+    """Fuzz configurations under a random look-at camera (util.fuzz_camera: general view / projection matrices, any roll,
+    tan(fov / 2) 0.1 .. 0.7, Gaussians beside and behind the camera) instead of random_scene's identity view — the first cases of
+    `FR_FUZZ_CAMERA=1 tools/fuzz_parity.py 1500 9401` / `300 9402 big` (round 5: no failure in 1 800)."""
+    _, P, H, W, kw, dpix, name = util.fuzz_case(seed, k, big)
+    s = scenes.random_scene(P, H, W, **kw)
+    s.camera = util.fuzz_camera(seed, k, H, W)
+    o = util.oracle_forward(s)
+    h = util.HipFrame(s, gpu_device)
+    _check_forward(o, h, name + "-camera")
+    _check_backward_capped(o, h, dpix, name + "-camera", max_skip_frac=0.05)
+
+
 def test_fuzz_regression_image_sized_splats(gpu_device):
     """The one configuration of 1 300 fuzz runs that ever missed an aggregate gradient bound (`tools/fuzz_parity.py 80 991 big`,
     iteration 61; round 3 saw 2.7e-4 on dL_dscales, round 4 1.35e-4 on dL_dmeans2D, every ENTRY within the elementwise

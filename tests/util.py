@@ -212,3 +212,20 @@ def fuzz_case(seed, k, big=False):
     for c in fuzz_stream(seed, big):
         if c[0] == k:
             return c
+
+
+def fuzz_camera(seed, k, H, W):
+    """A random look-at camera for case k of a fuzz stream (its own generator: the stream's draws are untouched): eye 0.5 .. 1.6 from
+    the centre of random_scene's cube, looking at a point near it, any roll, tan(fov_x / 2) 0.1 .. 0.7 — general view and
+    projection matrices, Gaussians beside and behind the camera, the 1.3 x tan(fov) clamp of the covariance Jacobian."""
+    import math
+    from fateavatar_amd import scenes
+    rng = np.random.default_rng([seed, k, 77])
+    d = rng.normal(size=3)
+    eye = np.array([0.0, 0.0, 1.0]) + d / np.linalg.norm(d) * rng.uniform(0.5, 1.6)
+    target = np.array([0.0, 0.0, 1.0]) + rng.uniform(-0.15, 0.15, 3)
+    up = rng.normal(size=3)
+    tanfov = float(rng.uniform(0.1, 0.7))
+    fov = 2 * math.atan(tanfov)
+    fovy = 2 * math.atan(tanfov * H / W)
+    return scenes.look_at_camera(eye, target, up, fov, fovy, H, W)

@@ -1,5 +1,5 @@
 """Fuzz campaign: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box.
-    python tools/fuzz_parity.py N SEED [big|huge]   (FR_FUZZ_ONLY=k: only iteration k; huge: 60 k - 400 k Gaussians, 512 - 1400 pixels a side)
+    python tools/fuzz_parity.py N SEED [big|huge]   (FR_FUZZ_ONLY=k: only iteration k; FR_FUZZ_CAMERA=1: random look-at cameras; huge: 60 k - 400 k Gaussians, 512 - 1400 pixels a side)
 The configurations come from tests/util.fuzz_stream; a failing iteration k is replayed with tools/diag/fuzz_replay.py /
 fuzz_bisect.py and pinned in tests/test_gpu_configs.py (test_fuzz_regression_*)."""
 import itertools
@@ -27,6 +27,8 @@ for it, P, H, W, kw, dpix, name in itertools.islice(util.fuzz_stream(seed, big),
         print("kw", it, dict(P=P, H=H, W=W, **kw), flush=True)
     try:
         s = scenes.random_scene(P, H, W, **kw)
+        if os.environ.get("FR_FUZZ_CAMERA"):   # a random look-at camera instead of the identity view (util.fuzz_camera)
+            s.camera = util.fuzz_camera(seed, it, H, W)
         o = util.oracle_forward(s)
         h = util.HipFrame(s, dev)
         _check_forward(o, h, name)
