@@ -1,5 +1,5 @@
 """Fuzz campaign: random scene configurations, HIP vs oracle (forward state, image, gradients).  GPU box.
-    python tools/fuzz_parity.py N SEED [big|huge]   (FR_FUZZ_ONLY=k: only iteration k; FR_FUZZ_CAMERA=1: random look-at cameras; huge: 60 k - 400 k Gaussians, 512 - 1400 pixels a side)
+    python tools/fuzz_parity.py N SEED [big|huge]   (FR_FUZZ_ONLY=k: only iteration k; FR_FUZZ_CAMERA=1: random look-at cameras; FR_FUZZ_INPUTS=1: colors_precomp / cov3D_precomp / scale_modifier drawn per case; huge: 60 k - 400 k Gaussians, 512 - 1400 pixels a side)
 The configurations come from tests/util.fuzz_stream; a failing iteration k is replayed with tools/diag/fuzz_replay.py /
 fuzz_bisect.py and pinned in tests/test_gpu_configs.py (test_fuzz_regression_*)."""
 import itertools
@@ -29,8 +29,19 @@ for it, P, H, W, kw, dpix, name in itertools.islice(util.fuzz_stream(seed, big),
         s = scenes.random_scene(P, H, W, **kw)
         if os.environ.get("FR_FUZZ_CAMERA"):   # a random look-at camera instead of the identity view (util.fuzz_camera)
             s.camera = util.fuzz_camera(seed, it, H, W)
-        o = util.oracle_forward(s)
-        h = util.HipFrame(s, dev)
+        extra = {}
+        if os.environ.get("FR_FUZZ_INPUTS"):   # the API's optional inputs, drawn per case (their own generator)
+            import numpy as np
+            r2 = np.random.default_rng([seed, it, 78])
+            if r2.random() < 0.35:
+                extra["colors_precomp"] = r2.uniform(0, 1, (P, 3)).astype(np.float32)
+            if r2.random() < 0.35:   # (a valid covariance: the scene's own, from a first oracle pass)
+                extra["cov3D_precomp"] = util.oracle_forward(s).cov3D.copy()
+            if r2.random() < 0.5:
+                extra["scale_modifier"] = float(r2.uniform(0.4, 1.6))
+            name += " inputs=" + ",".join(sorted(extra)) if extra else ""
+        o = util.oracle_forward(s, **extra)
+        h = util.HipFrame(s, dev, **extra)
         _check_forward(o, h, name)
         # (as tests/test_gpu_configs.py: at most 5 % of the rows exempt by threshold flips, else the flips are masked out of
         # dL/dpixel and no row is exempt; aggregate bound 1e-4 for every scene)
