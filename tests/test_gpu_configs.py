@@ -144,6 +144,22 @@ def test_fuzz_random_cameras(seed, k, big, gpu_device):
     _check_backward_capped(o, h, dpix, name + "-camera", max_skip_frac=0.05)
 
 
+@pytest.mark.parametrize("k", [1, 6, 9, 16, 23, 25, 28])   # every combination of the three inputs
+def test_fuzz_optional_inputs(k, gpu_device):
+    """Fuzz configurations with the API's optional inputs drawn per case (util.fuzz_inputs: colors_precomp, cov3D_precomp,
+    scale_modifier) under a random camera — cases of `FR_FUZZ_INPUTS=1 FR_FUZZ_CAMERA=1 tools/fuzz_parity.py 800 9501` (round 5: no
+    failure in 800)."""
+    _, P, H, W, kw, dpix, name = util.fuzz_case(9501, k)
+    s = scenes.random_scene(P, H, W, **kw)
+    s.camera = util.fuzz_camera(9501, k, H, W)
+    extra = util.fuzz_inputs(9501, k, s)
+    o = util.oracle_forward(s, **extra)
+    h = util.HipFrame(s, gpu_device, **extra)
+    name += " inputs=" + ",".join(sorted(extra))
+    _check_forward(o, h, name)
+    _check_backward_capped(o, h, dpix, name, max_skip_frac=0.05)
+
+
 def test_fuzz_regression_image_sized_splats(gpu_device):
     """The one configuration of 1 300 fuzz runs that ever missed an aggregate gradient bound (`tools/fuzz_parity.py 80 991 big`,
     iteration 61; round 3 saw 2.7e-4 on dL_dscales, round 4 1.35e-4 on dL_dmeans2D, every ENTRY within the elementwise

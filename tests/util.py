@@ -229,3 +229,18 @@ def fuzz_camera(seed, k, H, W):
     fov = 2 * math.atan(tanfov)
     fovy = 2 * math.atan(tanfov * H / W)
     return scenes.look_at_camera(eye, target, up, fov, fovy, H, W)
+
+
+def fuzz_inputs(seed, k, s):
+    """The API's optional inputs for case k of a fuzz stream, drawn per case (their own generator): colors_precomp instead of
+    the SH coefficients (35 %), cov3D_precomp — the scene's own covariance, from a first oracle pass — (35 %), scale_modifier
+    0.4 .. 1.6 (50 %).  Keyword arguments of oracle_forward / HipFrame."""
+    r = np.random.default_rng([seed, k, 78])
+    extra = {}
+    if r.random() < 0.35:
+        extra["colors_precomp"] = r.uniform(0, 1, (s.P, 3)).astype(np.float32)
+    if r.random() < 0.35:
+        extra["cov3D_precomp"] = oracle_forward(s).cov3D.copy()
+    if r.random() < 0.5:
+        extra["scale_modifier"] = float(r.uniform(0.4, 1.6))
+    return extra

@@ -29,17 +29,8 @@ for it, P, H, W, kw, dpix, name in itertools.islice(util.fuzz_stream(seed, big),
         s = scenes.random_scene(P, H, W, **kw)
         if os.environ.get("FR_FUZZ_CAMERA"):   # a random look-at camera instead of the identity view (util.fuzz_camera)
             s.camera = util.fuzz_camera(seed, it, H, W)
-        extra = {}
-        if os.environ.get("FR_FUZZ_INPUTS"):   # the API's optional inputs, drawn per case (their own generator)
-            import numpy as np
-            r2 = np.random.default_rng([seed, it, 78])
-            if r2.random() < 0.35:
-                extra["colors_precomp"] = r2.uniform(0, 1, (P, 3)).astype(np.float32)
-            if r2.random() < 0.35:   # (a valid covariance: the scene's own, from a first oracle pass)
-                extra["cov3D_precomp"] = util.oracle_forward(s).cov3D.copy()
-            if r2.random() < 0.5:
-                extra["scale_modifier"] = float(r2.uniform(0.4, 1.6))
-            name += " inputs=" + ",".join(sorted(extra)) if extra else ""
+        extra = util.fuzz_inputs(seed, it, s) if os.environ.get("FR_FUZZ_INPUTS") else {}   # the API's optional inputs, drawn per case
+        name += (" inputs=" + ",".join(sorted(extra))) if extra else ""
         o = util.oracle_forward(s, **extra)
         h = util.HipFrame(s, dev, **extra)
         _check_forward(o, h, name)
