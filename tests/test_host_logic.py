@@ -281,3 +281,17 @@ def test_runtime_switches_are_opt_in():
     out = subprocess.run([sys.executable, "-c", code], env=dict(base, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"), capture_output=True, text=True,
                          timeout=120).stdout
     assert "A [None, '1']" in out and "B ['1', '1'] False True" in out, out
+
+
+def test_fuzz_stream_is_pinned():
+    """The fuzz campaigns' configurations are a seeded stream (tests/util.fuzz_stream); the regression tests of
+    tests/test_gpu_configs.py name cases of it by (seed, iteration).  The stream must not drift."""
+    from tests import util
+    _, P, H, W, kw, dpix, name = util.fuzz_case(991, 61, big=True)
+    assert (P, H, W, kw["seed"], kw["sh_degree"]) == (29994, 502, 715, 94317314, 1) and dpix.shape == (3, 502, 715)
+    assert name.startswith("fuzz61: P=29994 502x715 deg=1 scale=[0.0239,0.1873]")
+    _, P, H, W, kw, dpix, _ = util.fuzz_case(9001, 4055)
+    assert (P, H, W, kw["seed"], kw["M"]) == (2979, 79, 122, 896468609, 1)
+    a, b = util.fuzz_camera(9401, 3, 100, 80), util.fuzz_camera(9401, 3, 100, 80)
+    import numpy as np
+    assert np.array_equal(a.world_view_transform, b.world_view_transform) and a.image_height == 100
