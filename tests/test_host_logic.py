@@ -295,3 +295,27 @@ def test_fuzz_stream_is_pinned():
     a, b = util.fuzz_camera(9401, 3, 100, 80), util.fuzz_camera(9401, 3, 100, 80)
     import numpy as np
     assert np.array_equal(a.world_view_transform, b.world_view_transform) and a.image_height == 100
+
+
+def test_flip_pixels_finds_sub_tolerance_transmittance_changes():
+    """util.flip_pixels (what the GPU parity tests treat as a threshold flip): outside the forward tolerance, OR T_final off by
+    more than 0.1 % relative — a pixel near T = 1e-4 that blends one entry of alpha = 1/255 more changes by 4e-7 absolute, far
+    inside 1e-5 + 1e-4 |T|, and must still be found; fp32 noise of a long product (1e-5 relative) must not."""
+    import numpy as np
+    from types import SimpleNamespace
+    from tests import util
+    rng = np.random.default_rng(0)
+    col = rng.uniform(0, 1, (3, 8, 8)).astype(np.float32)
+    T = np.full((8, 8), 1.0e-4, np.float32)
+    T[0, :] = 0.5
+    o = SimpleNamespace(color=col, final_T=T)
+    got_T = T.copy()
+    got_T[3, 3] *= np.float32(1.0 - 1.0 / 255.0)      # one more entry at the alpha threshold: 0.39 %
+    got_T[4, 4] *= np.float32(1.0 + 1e-5)             # rounding noise
+    got_T[0, 2] *= np.float32(1.0 - 1.0 / 255.0)      # the same flip at T = 0.5: also outside the plain tolerance
+    bad = util.flip_pixels(o, col.copy(), got_T)
+    assert bad[3, 3] and bad[0, 2] and not bad[4, 4] and int(bad.sum()) == 2
+    assert not (np.abs(got_T[3, 3] - T[3, 3]) > 1e-5 + 1e-4 * T[3, 3])   # (the plain tolerance does not see the first one)
+    col2 = col.copy()
+    col2[1, 5, 5] += np.float32(1e-3)
+    assert util.flip_pixels(o, col2, T.copy())[5, 5]
