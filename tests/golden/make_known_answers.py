@@ -29,6 +29,10 @@ with its image, transmittance, radii and contributor counts, and finite-differen
 Gaussians.  They are evaluated by a pixel-vectorised copy of the same forward (forward64v), which this script first
 checks against the scalar one on every small scene.
 
+Six more ("random_camera_k", round 5) are drawn at random under general cameras — a rotated, translated view, images that are no
+multiple of a tile, 70 - 110 anisotropic Gaussians from sub-pixel to a quarter of the image, SH degree 0 .. 3, Gaussians behind the
+camera and off screen — with finite-difference gradients of twelve Gaussians each.
+
 Every scene is checked to sit far from the discrete decisions (power > 0, alpha < 1/255, T < 1e-4, radius ceil, tile
 rectangle, depth order), so that an fp32 implementation takes the same ones.  Output: tests/golden/known_answers.npz
 (inputs + expected outputs; data only).
@@ -554,7 +558,72 @@ def scenes():
                            410 + rng.choice(25, 5, replace=False), 435 + rng.choice(15, 5, replace=False)])
     s["sample"] = sorted(int(v) for v in pick)
     out.append(s)
+
+    # I: a family of random scenes under GENERAL cameras (their own generators: the draws above are untouched): a rotated and
+    #    translated view, images that are no multiple of a tile, 70 - 110 anisotropic Gaussians of every size from sub-pixel to a
+    #    quarter of the image, opacities 0.03 .. 0.95, SH degree 0 .. 3 with 16 stored coefficients or exactly (D + 1)^2, a few
+    #    Gaussians behind the camera and far off screen; finite-difference gradients of a sample of twelve each.
+    for k, (W, H) in enumerate([(40, 28), (33, 47), (56, 24), (48, 40), (27, 27), (64, 36)]):
+        out.append(random_camera_scene(k, W, H, base, sh))
     return out
+
+
+def rotation_matrix(axis, deg):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    t = math.radians(deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(t) * K + (1 - math.cos(t)) * (K @ K)
+
+
+def random_camera_scene(k, W, H, base, sh):
+    r = np.random.default_rng([20260929, k])
+    f32 = np.float32
+    R = rotation_matrix(r.standard_normal(3), float(r.uniform(10, 70)))
+    T = r.uniform(-0.3, 0.3, 3)
+    tan = float(r.uniform(0.2, 0.6))
+    s = base(f"random_camera_{k}", W, H, tan, R=R, T=T, bg=tuple(r.uniform(0, 1, 3)))
+    s["dL_dpix"] = (r.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32)
+    P = int(r.integers(70, 111))
+    D = k % 4
+    M = 16 if k % 2 == 0 else (D + 1) ** 2
+    zs = 1.0 + 0.02 * r.permutation(P) + r.uniform(0.0, 0.005, P)          # distinct view depths, gaps > 1e-2
+
+    def draw(i):
+        zz = zs[i]
+        kind = i % 10
+        if kind == 0 and i < 30:     # behind the camera / far off screen
+            cam = np.array([r.uniform(-0.2, 0.2), r.uniform(-0.2, 0.2), -r.uniform(0.3, 2.0)]) if i % 20 == 0 else \
+                np.array([zz * tan * r.uniform(4, 6), 0.1, zz])
+            sig = 1.5
+        else:
+            cx, cy = r.uniform(-3, W + 3), r.uniform(-3, H + 3)
+            sig = float(np.exp(r.uniform(np.log(0.5), np.log(0.25 * max(W, H)))))
+            cam = np.array([((2 * cx + 1) / W - 1) * s["tanfovx"] * zz, ((2 * cy + 1) / H - 1) * s["tanfovy"] * zz, zz])
+        world = R @ (cam - T)                                                    # x_view = R^T x_world + T (getWorld2View2)
+        pxw = 2.0 * s["tanfovx"] * zz / W
+        sc3 = sig * pxw * r.uniform(0.5, 1.5, 3)
+        return world.astype(f32), sc3.astype(f32), quat(r.standard_normal(3), float(r.uniform(0, 180))), f32(r.uniform(0.03, 0.95))
+
+    m3, sc3, rot, opa = np.zeros((P, 3), f32), np.zeros((P, 3), f32), np.zeros((P, 4), f32), np.zeros(P, f32)
+    for i in range(P):
+        m3[i], sc3[i], rot[i], opa[i] = draw(i)
+    shs = np.zeros((P, M, 3), f32)
+    shs[:, :(D + 1) ** 2] = r.uniform(-0.6, 0.9, (P, (D + 1) ** 2, 3))
+    s.update(means3D=m3, scales=sc3, rotations=rot, opacities=opa, shs=shs, D=D, big=True)
+    need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
+    for attempt in range(400):
+        margins = []
+        forward64v(s, margins=margins)
+        bad = sorted({int(mm[2]) for mm in margins if mm[1] <= 2.0 * need[mm[0]]})
+        if not bad:
+            break
+        for i in bad:
+            s["means3D"][i], s["scales"][i], s["rotations"][i], s["opacities"][i] = draw(i)
+    else:
+        raise AssertionError(s["name"] + ": could not move every pair off the decisions")
+    s["sample"] = sorted(int(v) for v in r.choice(P, 12, replace=False))
+    return s
 
 
 def main():

@@ -11,7 +11,10 @@ centre pixels terminate at T < 1e-4; alpha clamped at 0.99 (forward only, and â€
 through the clamp, backward.cu:499-534 â€” with gradients of the frozen-offset model); and "big_lists": 450 Gaussians on
 3 x 3 reference tiles with lists of hundreds of entries per tile (cross-tile key order, lists longer than one 64-record
 blend unit and than the 256-key register sort, pixels that terminate hundreds of entries deep), its image / transmittance /
-radii / contributor counts and the finite-difference gradients of a sample of 36 of its Gaussians."""
+radii / contributor counts and the finite-difference gradients of a sample of 36 of its Gaussians; and six "random_camera_k"
+scenes (round 5): 70 - 110 anisotropic Gaussians from sub-pixel to a quarter of the image under a ROTATED, translated camera,
+images that are no multiple of a tile (40 x 28 ... 64 x 36), SH degree 0 .. 3, Gaussians behind the camera and off screen, lists
+of 40 - 70 entries, with the finite-difference gradients of twelve Gaussians each."""
 import os
 
 import numpy as np
@@ -92,6 +95,16 @@ def test_known_answers_cover_the_branches():
     assert int((o["final_T"] < 2e-4).sum()) > 0                                              # pixels terminated deep in the list
     deep = o["n_contrib"][o["final_T"] < 2e-4]
     assert int(deep.min()) > 128, deep.min()
+    degrees = set()
+    for k in range(6):
+        i, o = _scene(f"random_camera_{k}")
+        rot = i["viewmatrix"][:3, :3].astype(np.float64)
+        assert np.abs(rot - np.eye(3)).max() > 0.1 and abs(np.linalg.det(rot) - 1.0) < 1e-5        # a genuinely rotated view
+        assert 70 <= i["means3D"].shape[0] <= 110 and len(o["sample"]) == 12 and int(o["n_contrib"].max()) >= 40
+        assert int((o["radii"] == 0).sum()) >= 2                                                    # culled / off-screen Gaussians
+        assert (int(i["W"]) % 16, int(i["H"]) % 16) != (0, 0)
+        degrees.add(int(i["D"]))
+    assert degrees == {0, 1, 2, 3}
 
 
 @pytest.mark.parametrize("name", NAMES)
