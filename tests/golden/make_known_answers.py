@@ -17,6 +17,10 @@ blend / binning / backward arithmetic has no reference-held pin.  This script is
       - guard-band clamp (backward.cu:168-176,262-264): the clamped t.x / t.y are constants (stop-gradient);
       - dL_dmeans2D is the derivative w.r.t. the NDC-scaled pixel centre in the blend only (backward.cu:460-461,545-546):
         obtained by perturbing the 2D centres with everything else fixed, times 0.5 W / 0.5 H.
+      - dL_dscales is the derivative with respect to scale_modifier * scale (backward.cu:295,322-325: the chain rule's factor
+        `mod` is not applied): the finite difference divided by the modifier (scenes "random_inputs_*", the only ones with a
+        modifier other than 1 — found BY those scenes: the oracle, which restates backward.cu, disagreed with the plain finite
+        difference by exactly the modifier).
       - the 0.99 alpha clamp (forward.cu:343) whose gradient the reference passes straight through (backward.cu:499-534:
         dL_dalpha goes on to opacity and G as if alpha = opacity * G): a pair clamped at the base point is evaluated as
         alpha = 0.99 + (opacity * G - (opacity * G at the base point)) — the clamped VALUE, the unclamped DERIVATIVE
@@ -326,9 +330,16 @@ def known_answer_big(sc, sample, clamp_model=False):
     res["sample"] = np.asarray(sample, np.int32)
     res["dL_dmeans3D"] = fd_rows("means3D")
     res["dL_dopacity"] = fd_rows("opacities").reshape(len(sample), 1)
-    res["dL_dsh"] = fd_rows("shs")
-    res["dL_dscales"] = fd_rows("scales")
-    res["dL_drotations"] = fd_rows("rotations")
+    if sc.get("colors_precomp") is not None:
+        res["dL_dcolors"] = fd_rows("colors_precomp")
+    else:
+        res["dL_dsh"] = fd_rows("shs")
+    if sc.get("cov3D_precomp") is not None:
+        res["dL_dcov3D"] = fd_rows("cov3D_precomp")   # NB: the 6 stored floats; off-diagonals enter the matrix twice
+    else:
+        # (the reference differentiates with respect to the MODIFIED scale: see known_answer below)
+        res["dL_dscales"] = fd_rows("scales") / float(sc["scale_modifier"])
+        res["dL_drotations"] = fd_rows("rotations")
     d2 = np.zeros((len(sample), 3))
     for r, i in enumerate(sample):
         for k, half in ((0, 0.5 * sc["W"]), (1, 0.5 * sc["H"])):
@@ -399,7 +410,11 @@ def known_answer(sc, grads=True):
     if sc.get("cov3D_precomp") is not None:
         res["dL_dcov3D"] = fd("cov3D_precomp")   # NB: the 6 stored floats; off-diagonals enter the matrix twice
     else:
-        res["dL_dscales"] = fd("scales")
+        # A third place where the reference's backward is not the derivative of its forward: Sigma is built from s = mod * scale
+        # (backward.cu:295) and dL_dscale is dot(Rt[i], dL_dMt[i]) (backward.cu:322-325) — the derivative with respect to s, the
+        # factor `mod` of the chain rule is not applied.  With scale_modifier = 1 (every call of FateAvatar's render path) the two are
+        # the same; the expected value here is the finite difference divided by the modifier.
+        res["dL_dscales"] = fd("scales") / float(sc["scale_modifier"])
         res["dL_drotations"] = fd("rotations")
     d2 = np.zeros((P, 3))
     for i in range(P):
@@ -565,6 +580,12 @@ def scenes():
     #    Gaussians behind the camera and far off screen; finite-difference gradients of a sample of twelve each.
     for k, (W, H) in enumerate([(40, 28), (33, 47), (56, 24), (48, 40), (27, 27), (64, 36)]):
         out.append(random_camera_scene(k, W, H, base, sh))
+    # J: the same family through the API's optional inputs: colors_precomp, cov3D_precomp (valid covariances, of random scales and
+    #    rotations), both, and scale_modifier != 1 with near-opaque Gaussians (pixels that terminate inside the list)
+    out.append(random_camera_scene(10, 44, 30, base, sh, name="random_inputs_colors", colors=True, mod=0.6))
+    out.append(random_camera_scene(11, 36, 42, base, sh, name="random_inputs_cov3d", cov=True))
+    out.append(random_camera_scene(12, 50, 26, base, sh, name="random_inputs_both", colors=True, cov=True))
+    out.append(random_camera_scene(13, 38, 38, base, sh, name="random_inputs_modifier_opaque", mod=1.5, opa=(0.5, 0.97)))
     return out
 
 
@@ -576,13 +597,14 @@ def rotation_matrix(axis, deg):
     return np.eye(3) + math.sin(t) * K + (1 - math.cos(t)) * (K @ K)
 
 
-def random_camera_scene(k, W, H, base, sh):
+def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, mod=1.0, opa=(0.03, 0.95)):
     r = np.random.default_rng([20260929, k])
     f32 = np.float32
     R = rotation_matrix(r.standard_normal(3), float(r.uniform(10, 70)))
     T = r.uniform(-0.3, 0.3, 3)
     tan = float(r.uniform(0.2, 0.6))
-    s = base(f"random_camera_{k}", W, H, tan, R=R, T=T, bg=tuple(r.uniform(0, 1, 3)))
+    s = base(name or f"random_camera_{k}", W, H, tan, R=R, T=T, bg=tuple(r.uniform(0, 1, 3)))
+    s["scale_modifier"] = mod
     s["dL_dpix"] = (r.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32)
     P = int(r.integers(70, 111))
     D = k % 4
@@ -602,17 +624,35 @@ def random_camera_scene(k, W, H, base, sh):
             cam = np.array([((2 * cx + 1) / W - 1) * s["tanfovx"] * zz, ((2 * cy + 1) / H - 1) * s["tanfovy"] * zz, zz])
         world = R @ (cam - T)                                                    # x_view = R^T x_world + T (getWorld2View2)
         pxw = 2.0 * s["tanfovx"] * zz / W
-        sc3 = sig * pxw * r.uniform(0.5, 1.5, 3)
-        return world.astype(f32), sc3.astype(f32), quat(r.standard_normal(3), float(r.uniform(0, 180))), f32(r.uniform(0.03, 0.95))
+        sc3 = sig * pxw * r.uniform(0.5, 1.5, 3) / (1.0 if cov else mod)
+        return world.astype(f32), sc3.astype(f32), quat(r.standard_normal(3), float(r.uniform(0, 180))), f32(r.uniform(*opa))
 
-    m3, sc3, rot, opa = np.zeros((P, 3), f32), np.zeros((P, 3), f32), np.zeros((P, 4), f32), np.zeros(P, f32)
+    m3, sc3, rot, opa_v = np.zeros((P, 3), f32), np.zeros((P, 3), f32), np.zeros((P, 4), f32), np.zeros(P, f32)
     for i in range(P):
-        m3[i], sc3[i], rot[i], opa[i] = draw(i)
+        m3[i], sc3[i], rot[i], opa_v[i] = draw(i)
     shs = np.zeros((P, M, 3), f32)
     shs[:, :(D + 1) ** 2] = r.uniform(-0.6, 0.9, (P, (D + 1) ** 2, 3))
-    s.update(means3D=m3, scales=sc3, rotations=rot, opacities=opa, shs=shs, D=D, big=True)
+    opa_arr = opa_v
+    s.update(means3D=m3, scales=sc3, rotations=rot, opacities=opa_arr, shs=shs, D=D, big=True)
+    if colors:
+        s.update(colors_precomp=r.uniform(0, 1, (P, 3)).astype(f32), shs=None, D=0)
+
+    def covariances():
+        c = np.zeros((P, 6), f32)
+        for i in range(P):
+            q0, x, y, z = s["rotations"][i].astype(np.float64)
+            Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - q0 * z), 2 * (x * z + q0 * y)],
+                           [2 * (x * y + q0 * z), 1 - 2 * (x * x + z * z), 2 * (y * z - q0 * x)],
+                           [2 * (x * z - q0 * y), 2 * (y * z + q0 * x), 1 - 2 * (x * x + y * y)]])
+            Mm = Rm @ np.diag(s["scales"][i].astype(np.float64))
+            S = Mm @ Mm.T
+            c[i] = (S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2])
+        return c
+
     need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
     for attempt in range(400):
+        if cov:
+            s["cov3D_precomp"] = covariances()
         margins = []
         forward64v(s, margins=margins)
         bad = sorted({int(mm[2]) for mm in margins if mm[1] <= 2.0 * need[mm[0]]})
@@ -622,6 +662,8 @@ def random_camera_scene(k, W, H, base, sh):
             s["means3D"][i], s["scales"][i], s["rotations"][i], s["opacities"][i] = draw(i)
     else:
         raise AssertionError(s["name"] + ": could not move every pair off the decisions")
+    if cov:
+        s.update(scales=None, rotations=None)
     s["sample"] = sorted(int(v) for v in r.choice(P, 12, replace=False))
     return s
 

@@ -14,7 +14,12 @@ blend unit and than the 256-key register sort, pixels that terminate hundreds of
 radii / contributor counts and the finite-difference gradients of a sample of 36 of its Gaussians; and six "random_camera_k"
 scenes (round 5): 70 - 110 anisotropic Gaussians from sub-pixel to a quarter of the image under a ROTATED, translated camera,
 images that are no multiple of a tile (40 x 28 ... 64 x 36), SH degree 0 .. 3, Gaussians behind the camera and off screen, lists
-of 40 - 70 entries, with the finite-difference gradients of twelve Gaussians each."""
+of 40 - 70 entries, with the finite-difference gradients of twelve Gaussians each; and four "random_inputs_*" scenes of the same
+family through the API's optional inputs: colors_precomp (scale_modifier 0.6), cov3D_precomp, both, and scale_modifier 1.5 with
+near-opaque Gaussians (69 pixels terminate inside their list).  The modifier scenes found a third place where the reference's
+backward is not the derivative of its forward: dL_dscales is the derivative with respect to scale_modifier * scale
+(backward.cu:295,322-325) — the oracle, which restates backward.cu, and the plain finite difference differed by exactly the
+modifier; the expected value is the finite difference divided by it."""
 import os
 
 import numpy as np
@@ -105,6 +110,14 @@ def test_known_answers_cover_the_branches():
         assert (int(i["W"]) % 16, int(i["H"]) % 16) != (0, 0)
         degrees.add(int(i["D"]))
     assert degrees == {0, 1, 2, 3}
+    i, o = _scene("random_inputs_colors")
+    assert "shs" not in i and "dL_dcolors" in o and "dL_dsh" not in o and float(i["scale_modifier"]) == pytest.approx(0.6)
+    i, o = _scene("random_inputs_cov3d")
+    assert "scales" not in i and "dL_dcov3D" in o and "dL_dscales" not in o
+    i, o = _scene("random_inputs_both")
+    assert "shs" not in i and "scales" not in i and {"dL_dcolors", "dL_dcov3D"} <= set(o)
+    i, o = _scene("random_inputs_modifier_opaque")
+    assert float(i["scale_modifier"]) == pytest.approx(1.5) and int((o["final_T"] < 1e-3).sum()) > 50 and np.abs(o["dL_dscales"]).max() > 0
 
 
 @pytest.mark.parametrize("name", NAMES)
