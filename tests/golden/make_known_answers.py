@@ -35,7 +35,9 @@ checks against the scalar one on every small scene.
 
 Six more ("random_camera_k", round 5) are drawn at random under general cameras — a rotated, translated view, images that are no
 multiple of a tile, 70 - 110 anisotropic Gaussians from sub-pixel to a quarter of the image, SH degree 0 .. 3, Gaussians behind the
-camera and off screen — with finite-difference gradients of twelve Gaussians each.
+camera and off screen — with finite-difference gradients of twelve Gaussians each; four of the same family go through the
+API's optional inputs (colors_precomp, cov3D_precomp, both, scale_modifier 0.6 / 1.5), three sit at the edges of the tiling
+(7 x 5, 16 x 16, 17 x 33) and "random_big_600" puts 600 Gaussians on 64 x 64 (lists of hundreds of entries per tile).
 
 Every scene is checked to sit far from the discrete decisions (power > 0, alpha < 1/255, T < 1e-4, radius ceil, tile
 rectangle, depth order), so that an fp32 implementation takes the same ones.  Output: tests/golden/known_answers.npz
@@ -586,6 +588,13 @@ def scenes():
     out.append(random_camera_scene(11, 36, 42, base, sh, name="random_inputs_cov3d", cov=True))
     out.append(random_camera_scene(12, 50, 26, base, sh, name="random_inputs_both", colors=True, cov=True))
     out.append(random_camera_scene(13, 38, 38, base, sh, name="random_inputs_modifier_opaque", mod=1.5, opa=(0.5, 0.97)))
+    # K: image shapes at the edges of the tiling — smaller than a tile, exactly one reference tile, one pixel past a tile in both
+    #    directions — and one scene at the scale of "big_lists" under a general camera (600 Gaussians on 64 x 64: lists of hundreds
+    #    of entries in every tile, pixels that terminate deep inside them)
+    out.append(random_camera_scene(20, 7, 5, base, sh, name="random_tiny_7x5", P=12))
+    out.append(random_camera_scene(21, 16, 16, base, sh, name="random_one_tile_16x16", P=24))
+    out.append(random_camera_scene(22, 17, 33, base, sh, name="random_past_a_tile_17x33", P=40))
+    out.append(random_camera_scene(23, 64, 64, base, sh, name="random_big_600", P=600, n_sample=16))
     return out
 
 
@@ -597,7 +606,7 @@ def rotation_matrix(axis, deg):
     return np.eye(3) + math.sin(t) * K + (1 - math.cos(t)) * (K @ K)
 
 
-def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, mod=1.0, opa=(0.03, 0.95)):
+def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, mod=1.0, opa=(0.03, 0.95), P=None, n_sample=12):
     r = np.random.default_rng([20260929, k])
     f32 = np.float32
     R = rotation_matrix(r.standard_normal(3), float(r.uniform(10, 70)))
@@ -606,7 +615,7 @@ def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, m
     s = base(name or f"random_camera_{k}", W, H, tan, R=R, T=T, bg=tuple(r.uniform(0, 1, 3)))
     s["scale_modifier"] = mod
     s["dL_dpix"] = (r.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32)
-    P = int(r.integers(70, 111))
+    P = int(r.integers(70, 111)) if P is None else P
     D = k % 4
     M = 16 if k % 2 == 0 else (D + 1) ** 2
     zs = 1.0 + 0.02 * r.permutation(P) + r.uniform(0.0, 0.005, P)          # distinct view depths, gaps > 1e-2
@@ -664,7 +673,7 @@ def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, m
         raise AssertionError(s["name"] + ": could not move every pair off the decisions")
     if cov:
         s.update(scales=None, rotations=None)
-    s["sample"] = sorted(int(v) for v in r.choice(P, 12, replace=False))
+    s["sample"] = sorted(int(v) for v in r.choice(P, min(P, n_sample), replace=False))
     return s
 
 
