@@ -37,7 +37,8 @@ Six more ("random_camera_k", round 5) are drawn at random under general cameras 
 multiple of a tile, 70 - 110 anisotropic Gaussians from sub-pixel to a quarter of the image, SH degree 0 .. 3, Gaussians behind the
 camera and off screen — with finite-difference gradients of twelve Gaussians each; four of the same family go through the
 API's optional inputs (colors_precomp, cov3D_precomp, both, scale_modifier 0.6 / 1.5), three sit at the edges of the tiling
-(7 x 5, 16 x 16, 17 x 33) and "random_big_600" puts 600 Gaussians on 64 x 64 (lists of hundreds of entries per tile).
+(7 x 5, 16 x 16, 17 x 33), "random_big_600" puts 600 Gaussians on 64 x 64 (lists of hundreds of entries per tile) and
+"head_like_1500" is the regime of BASELINE config 2 in small (this one takes 25 minutes of finite differences).
 
 Every scene is checked to sit far from the discrete decisions (power > 0, alpha < 1/255, T < 1e-4, radius ceil, tile
 rectangle, depth order), so that an fp32 implementation takes the same ones.  Output: tests/golden/known_answers.npz
@@ -595,7 +596,51 @@ def scenes():
     out.append(random_camera_scene(21, 16, 16, base, sh, name="random_one_tile_16x16", P=24))
     out.append(random_camera_scene(22, 17, 33, base, sh, name="random_past_a_tile_17x33", P=40))
     out.append(random_camera_scene(23, 64, 64, base, sh, name="random_big_600", P=600, n_sample=16))
+    # L: the regime of BASELINE config 2 in small: 1 500 identical isotropic splats of opacity 0.1 on an ellipsoid with the head
+    #    template's bounding box, the benchmark's camera (R = diag(1, -1, -1), T = (0, 1.47, 0.98), tan(fov / 2) = 0.2), SH degree 3
+    #    with DC = 0 and a small rest, white background, 96 x 96 pixels: every footprint carries its alpha = 1/255 ring INSIDE the
+    #    3-sigma rectangle, front and back surface overlap, ~25 splats per pixel
+    out.append(head_like_scene(base))
     return out
+
+
+def head_like_scene(base):
+    r = np.random.default_rng([20260929, 99])
+    f32 = np.float32
+    W = H = 96
+    s = base("head_like_1500", W, H, 0.2, R=np.diag([1.0, -1.0, -1.0]), T=(0.0, 1.47, 0.98), bg=(1.0, 1.0, 1.0))
+    s["dL_dpix"] = (r.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32)
+    P = 1500
+    scale = 6.085e-4 * math.sqrt(100_000 / P)          # mean nearest-neighbour spacing at 100 k, scaled
+
+    def draw(i):
+        u, v = math.acos(r.uniform(-1, 1)), r.uniform(0, 2 * math.pi)
+        return np.asarray([0.1036 * math.sin(u) * math.cos(v), 1.470 + 0.157 * math.cos(u), -0.021 + 0.111 * math.sin(u) * math.sin(v)], f32)
+
+    m3 = np.stack([draw(i) for i in range(P)])
+    shs = np.zeros((P, 16, 3), f32)
+    shs[:, 1:] = 0.1 * r.uniform(-1, 1, (P, 15, 3))
+    s.update(means3D=m3, scales=np.full((P, 3), scale, f32), rotations=np.tile(np.asarray([1, 0, 0, 0], f32), (P, 1)),
+             opacities=np.full(P, 0.1, f32), shs=shs, D=3, big=True)
+    need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
+    for attempt in range(400):
+        margins = []
+        base0 = forward64v(s, margins=margins)
+        dep = np.sort(base0["g"]["depth"][base0["g"]["radii"] > 0])
+        close = set()
+        if len(dep) > 1 and np.diff(dep).min() <= 2e-5:          # distinct depths: the order must not hinge on fp32 rounding
+            d_all = base0["g"]["depth"]
+            for a in np.nonzero(np.diff(dep) <= 2e-5)[0]:
+                close.update(int(j) for j in np.nonzero(d_all == dep[a])[0])
+        bad = sorted({int(mm[2]) for mm in margins if mm[1] <= 2.0 * need[mm[0]]} | close)
+        if not bad:
+            break
+        for i in bad:
+            s["means3D"][i] = draw(i)
+    else:
+        raise AssertionError("head_like_1500: could not move every pair off the decisions")
+    s["sample"] = sorted(int(v) for v in r.choice(P, 12, replace=False))
+    return s
 
 
 def rotation_matrix(axis, deg):

@@ -18,7 +18,8 @@ of 40 - 70 entries, with the finite-difference gradients of twelve Gaussians eac
 family through the API's optional inputs: colors_precomp (scale_modifier 0.6), cov3D_precomp, both, and scale_modifier 1.5 with
 near-opaque Gaussians (69 pixels terminate inside their list); three at the edges of the tiling (7 x 5, 16 x 16, 17 x 33) and
 "random_big_600": 600 Gaussians on 64 x 64 under a general camera, lists of hundreds of entries in every tile, 4 031 of the 4 096
-pixels terminating inside them.  The modifier scenes found a third place where the reference's
+pixels terminating inside them; and "head_like_1500", the regime of BASELINE config 2 in small: 1 500 identical isotropic splats of
+opacity 0.1 on an ellipsoid with the head template's bounding box under the benchmark's camera, 96 x 96, ~25 splats per pixel.  The modifier scenes found a third place where the reference's
 backward is not the derivative of its forward: dL_dscales is the derivative with respect to scale_modifier * scale
 (backward.cu:295,322-325) — the oracle, which restates backward.cu, and the plain finite difference differed by exactly the
 modifier; the expected value is the finite difference divided by it."""
@@ -118,6 +119,9 @@ def test_known_answers_cover_the_branches():
     for n, wh in (("random_tiny_7x5", (7, 5)), ("random_one_tile_16x16", (16, 16)), ("random_past_a_tile_17x33", (17, 33))):
         i, o = _scene(n)
         assert (int(i["W"]), int(i["H"])) == wh and int((o["radii"] > 0).sum()) >= 6
+    i, o = _scene("head_like_1500")
+    assert i["means3D"].shape[0] == 1500 and float(i["opacities"].max()) == pytest.approx(0.1) and int((o["radii"] > 0).sum()) == 1500
+    assert np.allclose(i["viewmatrix"][:3, :3], np.diag([1.0, -1.0, -1.0])) and int(o["n_contrib"].max()) > 200   # the benchmark's camera
     i, o = _scene("random_inputs_colors")
     assert "shs" not in i and "dL_dcolors" in o and "dL_dsh" not in o and float(i["scale_modifier"]) == pytest.approx(0.6)
     i, o = _scene("random_inputs_cov3d")
