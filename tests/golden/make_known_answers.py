@@ -601,16 +601,18 @@ def scenes():
     #    with DC = 0 and a small rest, white background, 96 x 96 pixels: every footprint carries its alpha = 1/255 ring INSIDE the
     #    3-sigma rectangle, front and back surface overlap, ~25 splats per pixel
     out.append(head_like_scene(base))
+    # ... and where training takes it (config/fateavatar.yaml: opacities driven towards 1): the same surface with 700 splats of
+    #    opacity 0.9 on 64 x 64 — pixels terminate after a handful of entries, most of every list is never blended
+    out.append(head_like_scene(base, name="head_like_opaque_700", P=700, res=64, opacity=0.9, tag=98))
     return out
 
 
-def head_like_scene(base):
-    r = np.random.default_rng([20260929, 99])
+def head_like_scene(base, name="head_like_1500", P=1500, res=96, opacity=0.1, tag=99):
+    r = np.random.default_rng([20260929, tag])
     f32 = np.float32
-    W = H = 96
-    s = base("head_like_1500", W, H, 0.2, R=np.diag([1.0, -1.0, -1.0]), T=(0.0, 1.47, 0.98), bg=(1.0, 1.0, 1.0))
+    W = H = res
+    s = base(name, W, H, 0.2, R=np.diag([1.0, -1.0, -1.0]), T=(0.0, 1.47, 0.98), bg=(1.0, 1.0, 1.0))
     s["dL_dpix"] = (r.uniform(-1, 1, (3, H, W)) / (H * W)).astype(f32)
-    P = 1500
     scale = 6.085e-4 * math.sqrt(100_000 / P)          # mean nearest-neighbour spacing at 100 k, scaled
 
     def draw(i):
@@ -621,7 +623,7 @@ def head_like_scene(base):
     shs = np.zeros((P, 16, 3), f32)
     shs[:, 1:] = 0.1 * r.uniform(-1, 1, (P, 15, 3))
     s.update(means3D=m3, scales=np.full((P, 3), scale, f32), rotations=np.tile(np.asarray([1, 0, 0, 0], f32), (P, 1)),
-             opacities=np.full(P, 0.1, f32), shs=shs, D=3, big=True)
+             opacities=np.full(P, opacity, f32), shs=shs, D=3, big=True)
     need = dict(power=1e-4, alpha=1e-4, T=1e-4, radius=2e-3, rect=2e-4)
     for attempt in range(400):
         margins = []
@@ -638,7 +640,7 @@ def head_like_scene(base):
         for i in bad:
             s["means3D"][i] = draw(i)
     else:
-        raise AssertionError("head_like_1500: could not move every pair off the decisions")
+        raise AssertionError(name + ": could not move every pair off the decisions")
     s["sample"] = sorted(int(v) for v in r.choice(P, 12, replace=False))
     return s
 
@@ -725,8 +727,21 @@ def random_camera_scene(k, W, H, base, sh, name=None, colors=False, cov=False, m
 def main():
     blob = {}
     names = []
+    # KA_REUSE=1: a scene whose inputs are byte-identical to those in the existing file keeps its expected outputs (the finite
+    # differences of the large scenes take half an hour); without it everything is recomputed
+    old = np.load(os.path.join(OUT, "known_answers.npz")) if os.environ.get("KA_REUSE") and os.path.exists(os.path.join(OUT, "known_answers.npz")) else None
     for sc in scenes():
         n = sc["name"]
+        ins = {k: np.asarray(v) for k, v in sc.items() if k not in ("name", "forward_only", "big", "clamp_model", "sample") and v is not None}
+        if old is not None and n in [str(x) for x in old["names"]]:
+            old_in = {k.split("/", 2)[2]: old[k] for k in old.files if k.startswith(n + "/in/")}
+            if set(old_in) == set(ins) and all(old_in[k].dtype == ins[k].dtype and np.array_equal(old_in[k], ins[k]) for k in ins):
+                names.append(n)
+                for k in old.files:
+                    if k.startswith(n + "/"):
+                        blob[k] = old[k]
+                print(n, "(inputs unchanged: expected outputs kept)", flush=True)
+                continue
         if sc.get("big"):
             ka, base = known_answer_big(sc, sc.get("sample"), clamp_model=sc.get("clamp_model", False))
             if sc.get("clamp_model"):
