@@ -461,8 +461,8 @@ class HipEngine:
                     "steps_per_s": round(args.steps / dt, 2), "allreduce_payload_bytes": 12 * args.P * 4,
                     "exchange_in_graph": bool(getattr(st, "exchange_in_graph", False)), "sh_degree": 0,
                     "binding": "inside the per-Gaussian kernels (fr_aux::binding)",
-                    "storage_order": "coherent (grid cells of the sampled points: stands in for the reference's UV-raster "
-                                     "initialisation, model/fateavatar.py:131-135; tools/train_synthetic.py --random-order is the A/B)",
+                    "storage_order": "the reference's UV-raster initialisation (uniform_sampling_barycoords on the template's UV "
+                                     "layout, model/fateavatar.py:128-133; tools/train_synthetic.py --random-order is the A/B)",
                     "step": "bind + render + L1 + backward + all-reduce(AVG) of the 'gs' group + densification statistics + Adam"}
         except Exception as e:   # (the headline modes must not be lost to this one)
             return {"status": "failed: " + repr(e)[:300]}

@@ -61,6 +61,35 @@ class AvatarGaussians(torch.nn.Module):
         self.bary_coords = torch.as_tensor(np.asarray(bary_coords), dtype=torch.float32, device=device).contiguous()
         self._bind([op, z(P, 1), z(P, 1, 3), rot, torch.full((P, 3), float(scale_init), dtype=torch.float32, device=device)])
 
+    @classmethod
+    def from_template(cls, device, uv_resolution: int = 256, num_points: Optional[int] = None, sampling: str = "uv",
+                      rng: Optional[np.random.Generator] = None) -> "AvatarGaussians":
+        """The reference's own initialisation on the head template: `_register_template_mesh` + `_register_init_gaussian`
+        (model/fateavatar.py:120-190, 597-608).  `sampling="uv"` (the reference): binding points = the texel centres the
+        template's UV layout covers at `uv_resolution` x `uv_resolution` (config/fateavatar.yaml:28 `tex_size: 256`), in
+        row-major texel order, padded to uv_resolution^2 rows with random points on sampled faces
+        (volume_rendering/mesh_sampling.py:86-138); `num_points` (default uv_resolution^2) asks for another row count the way
+        the reference's `num_points` argument does (raster side int(sqrt(num_points))).  `sampling="random"`: the
+        area-weighted draw the reference keeps commented out (model/fateavatar.py:135-137, mesh_sampling.py:140-169).
+        scale_init = the reference's knn estimate on the canonical template points."""
+        from . import mesh_sampling, scenes
+        from .knn import init_scale_by_knn
+        n = int(num_points) if num_points is not None else int(uv_resolution) * int(uv_resolution)
+        rng = rng or np.random.default_rng(0)
+        verts, faces, _ = scenes.head_geometry()
+        if sampling == "uv":
+            uv = scenes.head_uv()
+            if uv is None:
+                raise RuntimeError("the head template's UV layout is not in fateavatar_amd/data/head_template_geom.npz")
+            fi, bc = mesh_sampling.uniform_sampling_barycoords(n, uv[0], uv[1], rng=rng)
+        elif sampling == "random":
+            fi, bc = mesh_sampling.random_sampling_barycoords(n, verts, faces, rng)
+        else:
+            raise ValueError(f"sampling must be 'uv' or 'random', not {sampling!r}")
+        pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)      # reweight_verts_by_barycoords
+        scale_init = float(init_scale_by_knn(torch.from_numpy(pts).to(device))[2])
+        return cls(fi, bc, scale_init, device)
+
     @property
     def P(self):
         return int(self.face_index.shape[0])

@@ -163,6 +163,17 @@ def head_geometry():
     return v, f, "procedural_ellipsoid"
 
 
+def head_uv():
+    """UV layout of the head template: (verts_uvs [5150,2] float32, faces_uvs [10006,3] int32) — `aux.verts_uvs` and
+    `faces.textures_idx` of the reference's load_obj call (model/fateavatar.py:120-127), the inputs of its UV-raster
+    initialisation.  None when only the procedural stand-in geometry is available."""
+    if os.path.exists(HEAD_GEOM):
+        z = np.load(HEAD_GEOM)
+        if "verts_uvs" in z.files:
+            return z["verts_uvs"].astype(np.float32), z["faces_uvs"].astype(np.int32)
+    return None
+
+
 def sample_mesh(verts, faces, n: int, seed: int = 0) -> np.ndarray:
     """Area-weighted face choice + barycentric = rand(3)/sum (mesh_sampling.py:166-167 style)."""
     rng = np.random.default_rng(seed)

@@ -12,10 +12,12 @@ its rasterizer is CUDA and cannot be built in this image):
                      Sigma = (R S)(R S)^T from (scale, unit quaternion r,x,y,z), 6 upper-tri floats
   golden_camera.npz  volume_rendering/camera_3dgs.py:22-72, tools/gs_utils/graphics_utils.py:51-84
                      world_view_transform / projection / full_proj_transform / camera_center
+  golden_proj.npz    tools/gs_utils/graphics_utils.py:22-29 geom_transform_points: NDC / view-space coordinates of points
+                     in front of the golden cameras (the 1 / (w + 1e-7) projection of forward.cu:196-200)
   golden_misc.npz    tools/gs_utils/general_utils.py:18-19 inverse_sigmoid
   golden_binding.npz volume_rendering/mesh_compute.py:27-59 compute_face_orientation (+ scale) / compute_face_normals
-  ../../fateavatar_amd/data/head_template_geom.npz  vertices + triangle indices of weights/head_template_mouth_close.obj
-                     (input geometry of BASELINE.json configs 2 and 5; data, not code)
+  ../../fateavatar_amd/data/head_template_geom.npz  vertices, triangle indices, UV coordinates (`vt`) and per-corner UV indices of
+                     weights/head_template_mouth_close.obj (input geometry of BASELINE.json configs 2, 3 and 5; data, not code)
 """
 import math
 import os
@@ -106,6 +108,30 @@ def gen_camera():
     np.savez_compressed(os.path.join(OUT, "golden_camera.npz"), **cams)
 
 
+def gen_proj():
+    """tools/gs_utils/graphics_utils.py:22-29 geom_transform_points — the reference's own Python statement of the projection the
+    rasterizer starts with (forward.cu:196-200: p_hom = transformPoint4x4(p, projmatrix), p_proj = p_hom / (p_hom.w + 1e-7)) —
+    on points in front of every golden camera: NDC through full_proj_transform, view space through world_view_transform."""
+    from tools.gs_utils.graphics_utils import geom_transform_points
+    z = np.load(os.path.join(OUT, "golden_camera.npz"))
+    g = torch.Generator().manual_seed(11)
+    out = {"names": z["names"]}
+    for name in z["names"]:
+        R, T = torch.from_numpy(z[f"{name}_R"]), torch.from_numpy(z[f"{name}_T"])
+        fx, fy = (float(v) for v in z[f"{name}_fov"])
+        n = 256
+        vz = 0.3 + 4.7 * torch.rand(n, generator=g)
+        vx = (2 * torch.rand(n, generator=g) - 1) * 0.9 * math.tan(fx / 2) * vz
+        vy = (2 * torch.rand(n, generator=g) - 1) * 0.9 * math.tan(fy / 2) * vz
+        view = torch.stack([vx, vy, vz], 1)
+        pts = (view - T[None]) @ R.T.float()            # view = R^T x + T  (getWorld2View2)  ->  x = R (view - T)
+        pts = pts.float().contiguous()
+        out[f"{name}_points"] = pts.numpy()
+        out[f"{name}_ndc"] = geom_transform_points(pts, torch.from_numpy(z[f"{name}_full"])).numpy()
+        out[f"{name}_view"] = geom_transform_points(pts, torch.from_numpy(z[f"{name}_wvt"])).numpy()
+    np.savez_compressed(os.path.join(OUT, "golden_proj.npz"), **out)
+
+
 def gen_misc():
     """inverse_sigmoid, RGB2SH / SH2RGB (sh_utils.py:114-118), get_expon_lr_func (general_utils.py:29-62) and the numpy
     getWorld2View2 with scene translate / scale (graphics_utils.py:38-49)."""
@@ -131,15 +157,16 @@ def gen_misc():
 
 
 def gen_head():
-    verts, faces = [], []
-    with open(os.path.join(REF, "weights", "head_template_mouth_close.obj")) as f:
-        for line in f:
-            if line.startswith("v "):
-                verts.append([float(t) for t in line.split()[1:4]])
-            elif line.startswith("f "):
-                faces.append([int(t.split("/")[0]) - 1 for t in line.split()[1:4]])
-    np.savez_compressed(os.path.join(OUT, "..", "..", "fateavatar_amd", "data", "head_template_geom.npz"), verts=np.asarray(verts, np.float32),
-                        faces=np.asarray(faces, np.int32))
+    """Geometry AND UV layout of the head template: what the reference reads with pytorch3d's load_obj
+    (model/fateavatar.py:120-127: verts, faces.verts_idx, aux.verts_uvs, faces.textures_idx).  Parsed with the repository's
+    own OBJ reader; numeric arrays only."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from fateavatar_amd.obj import load_obj
+    m = load_obj(os.path.join(REF, "weights", "head_template_mouth_close.obj"))
+    assert m["verts"].shape == (5023, 3) and m["faces"].shape == (10006, 3)
+    assert m["verts_uvs"].shape == (5150, 2) and m["faces_uvs"].shape == (10006, 3) and m["faces_uvs"].min() >= 0
+    np.savez_compressed(os.path.join(OUT, "..", "..", "fateavatar_amd", "data", "head_template_geom.npz"), verts=m["verts"],
+                        faces=m["faces"], verts_uvs=m["verts_uvs"], faces_uvs=m["faces_uvs"])
 
 
 def gen_binding():
@@ -162,6 +189,7 @@ if __name__ == "__main__":
     gen_sh()
     gen_cov3d()
     gen_camera()
+    gen_proj()
     gen_misc()
     gen_head()
     print("golden fixtures written to", OUT)

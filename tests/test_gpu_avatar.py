@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, P, res, n_frames, seed=0):
+def _setup(dev, P, res, n_frames, seed=0, order="random"):
     import torch
     from fateavatar_amd import insta, mesh_sampling, scenes
     from fateavatar_amd.avatar import AvatarGaussians
@@ -18,7 +18,11 @@ def _setup(dev, P, res, n_frames, seed=0):
     from fateavatar_amd.model import TorchCamera
     transform, posed, faces = insta.synthetic_sequence(n_frames, res, seed)
     verts, _, _ = scenes.head_geometry()
-    fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, np.random.default_rng(seed))
+    if order == "uv":     # the reference's own initialisation (model/fateavatar.py:128-133)
+        uv, fuv = scenes.head_uv()
+        fi, bc = mesh_sampling.uniform_sampling_barycoords(P, uv, fuv, rng=np.random.default_rng(seed))
+    else:
+        fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, np.random.default_rng(seed))
     pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)
     _, _, scale_init = init_scale_by_knn(torch.from_numpy(pts).to(dev))      # model/fateavatar.py:597-608
     cams = [TorchCamera(c, dev) for c in insta.camera_arrays(transform)]
@@ -99,6 +103,53 @@ def test_config3_fateavatar_loop_100k_512(gpu_device):
     assert FATE_LRS == dict(opacity=0.05, offset=0.0016, color=0.0025, rotation=0.001, scaling=0.005)
     from tests import util as _u
     _u.assert_same_trajectory(pc_g.flat, pc_e.flat, "graph vs eager", tight=2e-2)
+
+
+def test_config3_loop_on_the_reference_uv_raster_initialisation(gpu_device):
+    """Row H on the reference's OWN initialisation (model/fateavatar.py:120-190, config/fateavatar.yaml:28 tex_size 256):
+    65 536 Gaussians bound to the texel centres of the template's UV layout in row-major texel order, padded with random
+    points on sampled faces.  The set renders (the head covers the image's centre), the step trains on it (loss falls),
+    the captured step follows the eager one, nothing overflows — and `AvatarGaussians.from_template` builds that set."""
+    import torch
+    from fateavatar_amd.avatar import AvatarGaussians, AvatarStep, _BoundFrame
+    from fateavatar_amd.binding import bind_gaussians
+    from fateavatar_amd.render import render
+    dev = gpu_device
+    P, res, n_frames, steps = 256 * 256, 512, 8, 40
+    S = _setup(dev, P, res, n_frames, order="uv")
+    pc_t = AvatarGaussians.from_template(dev, uv_resolution=256)
+    assert pc_t.P == P and np.array_equal(pc_t.face_index.cpu().numpy(), S["fi"]) and np.array_equal(pc_t.bary_coords.cpu().numpy(), S["bc"])
+    assert abs(float(pc_t._scaling[0, 0]) - S["scale_init"]) < 1e-6
+    # the first 59 099 rows are texels (a face per covered texel centre, strictly inside it), the rest padding on sampled faces
+    assert (S["bc"][:59_099] > 0).all() and np.isin(S["fi"][59_099:], S["fi"][:59_099]).all()
+    bg = torch.ones(3, device=dev)
+    gts = _targets(S, dev, bg)
+    # it renders: the initial (grey, opacity 0.1) set leaves a head-shaped footprint in the middle of the image
+    st0 = AvatarStep(S["make"](), S["faces"], S["canon"], S["cams"][0], bg, use_graph=False)
+    with torch.no_grad():
+        pc0 = st0.pc
+        xyz, rot, scl = bind_gaussians(S["posed"][0], st0.faces, pc0.face_index, pc0.bary_coords, st0.face_scale_canonical, pc0._offset,
+                                       pc0._rotation, pc0._scaling, st0.shell_len, True)
+        out = render(S["cams"][0], _BoundFrame(xyz, pc0, rot, scl, None), bg)
+    img = out["render"]
+    covered = (img.mean(0) < 0.999)
+    assert 0.05 < float(covered.float().mean()) < 0.6 and bool(covered[res // 2, res // 2])
+    assert int((out["radii"] > 0).sum()) > 0.9 * P
+
+    def run(use_graph):
+        pc = S["make"]()
+        st = AvatarStep(pc, S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=use_graph)
+        losses = [st.step(S["cams"][it % n_frames], S["posed"][it % n_frames], gts[it % n_frames]).clone() for it in range(steps)]
+        torch.cuda.synchronize()
+        st.check()
+        return pc, [float(x) for x in losses], st
+
+    pc_e, loss_e, st_e = run(False)
+    pc_g, loss_g, st_g = run(True)
+    assert st_g._graph is not None and st_g.overflows == 0 and st_g.adam.step_count == steps
+    assert np.mean(loss_e[-8:]) < 0.9 * np.mean(loss_e[:8]), (loss_e[:4], loss_e[-4:])
+    assert np.allclose(loss_g[:16], loss_e[:16], rtol=5e-3), (loss_g[:16], loss_e[:16])
+    assert torch.equal(st_g.denom, st_e.denom) and float(st_e.denom.max()) > 0
 
 
 def test_binding_gradients_match_autograd_of_the_torch_ops(gpu_device):

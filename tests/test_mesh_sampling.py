@@ -111,3 +111,44 @@ def test_head_template_uv_sampling():
     order = np.linalg.norm(np.diff(pos, axis=0), axis=1).mean()
     shuffled = np.linalg.norm(np.diff(pos[np.random.default_rng(0).permutation(len(pos))], axis=0), axis=1).mean()
     assert order < 0.2 * shuffled
+
+
+def test_reference_initialisation_on_the_committed_template():
+    """The reference's `_register_template_mesh` call (model/fateavatar.py:128-133: uniform_sampling_barycoords(tex_size^2, uvcoords,
+    uvfaces), config/fateavatar.yaml:28 tex_size 256) on the template data the repository ships (vt / per-corner vt indices of
+    weights/head_template_mouth_close.obj, exported by tests/golden/make_golden.py:gen_head).  Pins the covered-texel count and
+    the first rows, and checks every texel sample INDEPENDENTLY of the rasterizer: its barycentrics must reproduce the texel
+    centre it stands for, the texels must come in row-major order, and no sample may lie on a culled (clockwise) face."""
+    from fateavatar_amd import scenes
+    got = scenes.head_uv()
+    assert got is not None
+    uv, fuv = got
+    assert uv.shape == (5150, 2) and fuv.shape == (10006, 3) and fuv.min() >= 0 and fuv.max() == 5149
+    S = 256
+    fi, bc = ms.uniform_sampling_barycoords(S * S, uv, fuv, rng=np.random.default_rng(0))
+    assert fi.shape == (S * S,) and bc.shape == (S * S, 3) and bc.dtype == np.float32
+    n_tex = 59_099                                            # texel centres the UV layout covers at 256 x 256 (90.2 %)
+    p2f, _ = ms.rasterize_uv(uv, fuv, S)
+    assert int((p2f >= 0).sum()) == n_tex
+    assert fi[:6].tolist() == [9990, 9990, 9990, 10000, 9993, 9993]
+    assert np.allclose(bc[:2], [[0.7098801, 0.28616953, 0.00394932], [0.8041375, 0.18685095, 0.00901049]], atol=2e-6)
+    # every texel sample: barycentrics (strictly positive) x the face's UV corners = a texel CENTRE, centres row-major
+    # (pytorch3d divides the edge functions by area + 1e-8: the barycentrics of a face of NDC area A sum to A / (A + 1e-8),
+    # 0.994 on the template's smallest faces — the reference uses them as they come, so does the restatement)
+    t = uv.astype(np.float64)[fuv]
+    A = (t[:, 1, 0] - t[:, 0, 0]) * (t[:, 2, 1] - t[:, 0, 1]) - (t[:, 2, 0] - t[:, 0, 0]) * (t[:, 1, 1] - t[:, 0, 1])
+    sums = bc[:n_tex].sum(-1).astype(np.float64)
+    assert np.allclose(sums, 4 * A[fi[:n_tex]] / (4 * A[fi[:n_tex]] + 1e-8), atol=2e-6)
+    rec = (bc[:n_tex, :, None].astype(np.float64) * uv[fuv[fi[:n_tex]]]).sum(1) / sums[:, None]
+    xi = rec[:, 0] * S - 0.5
+    yi = (1.0 - rec[:, 1]) * S - 0.5
+    assert np.abs(xi - np.round(xi)).max() < 1e-4 and np.abs(yi - np.round(yi)).max() < 1e-4
+    lin = np.round(yi).astype(np.int64) * S + np.round(xi).astype(np.int64)
+    assert (np.diff(lin) > 0).all() and lin.min() >= 0 and lin.max() < S * S
+    assert (bc[:n_tex] > 0).all() and np.allclose(bc[n_tex:].sum(-1), 1.0, atol=1e-5)
+    assert (A < 0).sum() == 5 and not np.isin(fi, np.nonzero(A < 0)[0]).any()
+    # the padding (strict=True: mesh_sampling.py:123-131): random points on faces that already carry a texel
+    assert np.isin(fi[n_tex:], fi[:n_tex]).all()
+    # another row count goes through the same call (raster side int(sqrt(n))): BASELINE config 3's 100 000
+    fi2, _ = ms.uniform_sampling_barycoords(100_000, uv, fuv, rng=np.random.default_rng(0))
+    assert fi2.shape == (100_000,) and int((ms.rasterize_uv(uv, fuv, 316)[0] >= 0).sum()) == 90_611

@@ -46,6 +46,36 @@ def test_camera_matches_reference_camera():
                                    rtol=1e-6, atol=1e-7)
 
 
+def test_projection_matches_reference_geom_transform_points():
+    """The oracle's projection (forward.cu:196-200 restated: p_hom = P x, p_proj = p_hom / (p_hom.w + 1e-7), ndc2Pix) and its
+    view-space depth against the reference's own Python projection, tools/gs_utils/graphics_utils.py:22-29
+    `geom_transform_points`, on 256 points in front of each of the five golden cameras."""
+    z = np.load(os.path.join(G, "golden_proj.npz"))
+    c = np.load(os.path.join(G, "golden_camera.npz"))
+    checked = 0
+    for name in z["names"]:
+        pts, ndc, view = z[f"{name}_points"], z[f"{name}_ndc"], z[f"{name}_view"]
+        H, W = (int(v) for v in c[f"{name}_res"])
+        fx, fy = (float(v) for v in c[f"{name}_fov"])
+        P = pts.shape[0]
+        rot = np.zeros((P, 4), np.float32)
+        rot[:, 0] = 1
+        f = oracle.forward(bg=np.zeros(3, np.float32), means3D=pts, opacities=np.full((P, 1), 0.5, np.float32),
+                           viewmatrix=c[f"{name}_wvt"], projmatrix=c[f"{name}_full"], campos=c[f"{name}_center"],
+                           tanfovx=np.tan(fx / 2), tanfovy=np.tan(fy / 2), H=H, W=W, colors_precomp=np.full((P, 3), 0.5, np.float32),
+                           scales=np.full((P, 3), 0.02, np.float32), rotations=rot)
+        vis = f.radii > 0
+        assert vis.sum() > 0.9 * P          # (points sit inside 0.9 of the frustum, 0.3 .. 5 in front of the camera)
+        want_x = ((ndc[:, 0].astype(np.float64) + 1.0) * W - 1.0) * 0.5        # ndc2Pix, auxiliary.h:41-44
+        want_y = ((ndc[:, 1].astype(np.float64) + 1.0) * H - 1.0) * 0.5
+        # float32 matmul of the reference vs the rasterizer's left-to-right sums: a few ulp of the homogeneous coordinates (measured: <= 2.5e-4 pixel)
+        assert np.abs(f.means2D[vis, 0] - want_x[vis]).max() < 5e-4
+        assert np.abs(f.means2D[vis, 1] - want_y[vis]).max() < 5e-4
+        np.testing.assert_allclose(f.depths[vis], view[vis, 2], rtol=1e-6, atol=0)
+        checked += int(vis.sum())
+    assert checked > 1100
+
+
 def test_inverse_sigmoid_round_trip():
     z = np.load(os.path.join(G, "golden_misc.npz"))
     x = z["x"].astype(np.float64)

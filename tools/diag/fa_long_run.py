@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("ts", os.path.join(os.environ.get(
 ts = importlib.util.module_from_spec(spec); spec.loader.exec_module(ts)
 dev = torch.device("cuda:0")
 for K in (1, 4):
-    su = ts.fateavatar_setup(100_000, 512, dev, views=8, views_per_step=K)
+    su = ts.fateavatar_setup(100_000, 512, dev, views=8, views_per_step=K, keep_coherent=True)
     st, cams, posed, gts, nf = su["st"], su["cams"], su["posed"], su["gts"], su["n_frames"]
     cfg = dict(densify_interval=700, increase_num=5000, prune_interval=900, opacity_reset_interval=1500, max_points_num=140_000)
     t0 = time.time(); did_all = {}; losses = []

@@ -38,7 +38,11 @@ def main():
                     help="--views-per-step K: K lanes on K streams (a graph per frame) instead of ONE launch chain on one "
                          "stream (render_batch: the default)")
     ap.add_argument("--random-order", action="store_true",
-                    help="FateAvatar step: the Gaussians stored as drawn instead of in a coherent (UV-raster-like) order")
+                    help="FateAvatar step: area-weighted random binding points, stored as drawn, instead of the reference's "
+                         "UV-raster initialisation (model/fateavatar.py:128-133)")
+    ap.add_argument("--keep-coherent", action="store_true",
+                    help="FateAvatar step: re-store the rows in a spatially coherent order after every densification (an "
+                         "extension; the reference appends)")
     ap.add_argument("--binding-op", action="store_true",
                     help="FateAvatar step: the stand-alone binding kernels instead of the binding inside the rasterizer's kernels")
     ap.add_argument("--views-per-step", type=int, default=1,
@@ -93,26 +97,22 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, chain=True, fold_binding=True, coherent=True):
+def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, chain=True, fold_binding=True, order="uv",
+                     keep_coherent=False):
     """FateAvatar's optimisation step on the synthetic INSTA-layout sequence: the mesh-bound Gaussian
     set, its step object (AvatarStep, or AvatarBatchStep for K > 1 frames per step), cameras, posed meshes and targets
-    rendered from a hidden ground-truth set.  Used by this script and by bench.py's `avatar` mode."""
-    from fateavatar_amd import insta, mesh_sampling
+    rendered from a hidden ground-truth set.  Used by this script and by bench.py's `avatar` mode.
+    `order="uv"`: the reference's own initialisation — `uniform_sampling_barycoords(P, ...)` on the template's UV raster
+    (model/fateavatar.py:128-133), rows in row-major texel order; `order="random"`: the area-weighted draw as drawn (the A/B)."""
+    from fateavatar_amd import insta
     from fateavatar_amd.avatar import AvatarGaussians, AvatarStep, _BoundFrame
     from fateavatar_amd.binding import bind_gaussians
-    from fateavatar_amd.knn import init_scale_by_knn
     n_frames = max(views, 8)
     transform, posed, faces = insta.synthetic_sequence(n_frames, res, seed=0)
     verts, _, _ = scenes.head_geometry()
-    fi, bc = mesh_sampling.random_sampling_barycoords(P, verts, faces, np.random.default_rng(0))
-    pts = (verts[faces[fi]] * bc[:, :, None]).sum(1).astype(np.float32)
-    if coherent:
-        # the reference samples its Gaussians on the UV raster (model/fateavatar.py:131-135, mesh_sampling.py:86-138):
-        # neighbours in storage are neighbours on the mesh.  The template here has no UV map; a grid-cell order of the
-        # sampled points stands in for the raster order (`--random-order`: the samples as drawn)
-        order = scenes.spatial_order(pts)
-        fi, bc, pts = fi[order], bc[order], pts[order]
-    scale_init = float(init_scale_by_knn(torch.from_numpy(pts).to(dev))[2])
+    pc = AvatarGaussians.from_template(dev, num_points=P, sampling=order, rng=np.random.default_rng(0))
+    fi, bc = pc.face_index.cpu().numpy(), pc.bary_coords.cpu().numpy()
+    scale_init = float(pc._scaling[0, 0])
     cams = [TorchCamera(c, dev) for c in insta.camera_arrays(transform)]
     posed_t, faces_t, canon = torch.from_numpy(posed).to(dev), torch.from_numpy(faces).to(dev), torch.from_numpy(verts).to(dev)
     bg = torch.ones(3, device=dev)
@@ -130,21 +130,20 @@ def fateavatar_setup(P, res, dev, views=8, views_per_step=1, use_graph=True, cha
             xyz, rot, scl = bind_gaussians(posed_t[f], ref.faces, gt.face_index, gt.bary_coords, ref.face_scale_canonical, gt._offset,
                                            gt._rotation, gt._scaling, ref.shell_len, True)
             gts.append(render(cams[f], _BoundFrame(xyz, gt, rot, scl, None), bg)["render"].clone())
-    pc = AvatarGaussians(fi, bc, scale_init, dev)
     K = max(1, views_per_step)
     cam0 = TorchCamera(insta.camera_arrays(transform)[0], dev)
     if K == 1:
-        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=use_graph, fold_binding=fold_binding, keep_coherent=coherent)
+        st = AvatarStep(pc, faces_t, canon, cam0, bg, use_graph=use_graph, fold_binding=fold_binding, keep_coherent=keep_coherent)
     else:   # the reference's batch of K frames per step (model/fateavatar.py:251-276), in flight together
         from fateavatar_amd.avatar import AvatarBatchStep
         st = AvatarBatchStep(pc, faces_t, canon, cam0, bg, views_per_step=K, use_graph=use_graph, chain=chain,
-                             fold_binding=fold_binding, keep_coherent=coherent)
+                             fold_binding=fold_binding, keep_coherent=keep_coherent)
     return dict(st=st, cams=cams, posed=posed_t, gts=gts, n_frames=n_frames, K=K)
 
 
 def main_fateavatar(a, rank, world, dev):
     su = fateavatar_setup(a.P, a.res, dev, views=a.views, views_per_step=a.views_per_step, use_graph=not a.no_graph, chain=a.chain,
-                           fold_binding=not a.binding_op, coherent=not a.random_order)
+                           fold_binding=not a.binding_op, order="random" if a.random_order else "uv", keep_coherent=a.keep_coherent)
     st, cams, posed_t, gts, n_frames, K = su["st"], su["cams"], su["posed"], su["gts"], su["n_frames"], su["K"]
 
     def one_step(it, keep=True):
@@ -178,7 +177,7 @@ def main_fateavatar(a, rank, world, dev):
         l = [float(x) for x in losses]
         print(json.dumps({"host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4),
                           "metric": "FateAvatar optimisation steps/s (bind + render + L1 + backward + stats + Adam)",
-                          "storage_order": "random" if a.random_order else "coherent (grid cells; stands in for the reference's UV raster)",
+                          "storage_order": "random (area-weighted draw)" if a.random_order else "the reference's UV-raster initialisation (row-major texels)",
                           "binding": "stand-alone kernels" if a.binding_op else "inside the per-Gaussian kernels (fr_aux::binding)",
                           "value": round(a.steps / dt, 1), "frames_per_s": round(world * K * a.steps / dt, 1), "n_gpus": world,
                           "views_per_step": K, "launch_chain": bool(a.chain) if K > 1 else None,
