@@ -317,10 +317,10 @@ class AvatarStep(TrainStep):
         w = acc.reshape(-1)
         idx = torch.zeros(increase_num, dtype=torch.int64, device=self.dev)
         uvw = torch.zeros((increase_num, 3), dtype=torch.float32, device=self.dev)
+        if float(w.sum()) <= 0:       # (the summed statistics are identical on every rank: all of them raise, none is left
+            raise RuntimeError("no densification statistics accumulated yet")   # waiting in the broadcast below)
         if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
-            if float(w.sum()) <= 0:
-                raise RuntimeError("no densification statistics accumulated yet")
-            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)   # (`generator`: rank 0's only)
             uvw = torch.rand((increase_num, 3), device=self.dev, generator=generator)
         dp.broadcast_(idx)
         dp.broadcast_(uvw)
@@ -429,6 +429,7 @@ class AvatarStep(TrainStep):
             self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
             self.adam.state.zero_()
             self.adam.state[:4].copy_(opt["state"][:4])
+        self.host_steps = self.adam.step_count          # (skipped_steps counts from the restored state on)
         if dens is not None:
             self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])
             self.denom.copy_(dens["denom"])
@@ -545,7 +546,6 @@ class AvatarBatchStep(AvatarStep):
         for L, out in zip(self.lanes, outs):
             L.out = {"render": out["render"].detach(), "radii": out["radii"], "visibility_filter": out["visibility_filter"]}
         torch.autograd.backward(images, grad_tensors=grads)
-        flat = [L.pc.collect_grads() for L in self.lanes]
         if self.exchange:                          # sum of the local lanes, then the sum over the ranks; Adam scales
             flat = [L.pc.exchange_buffer() for L in self.lanes]   # (gradients + overflow words: the words add up too)
             for g in flat[1:]:
@@ -554,7 +554,7 @@ class AvatarBatchStep(AvatarStep):
                 dp.allreduce_sum_(flat[0])
             self.adam.step()
         else:
-            self.adam.step(flat)
+            self.adam.step([L.pc.collect_grads() for L in self.lanes])
 
     def _capture_chain(self):
         from . import rasterizer
@@ -577,6 +577,7 @@ class AvatarBatchStep(AvatarStep):
         from .loss import multi_copy
         if not (len(cameras) == len(posed_verts) == len(gt_images) == self.K):
             raise ValueError(f"AvatarBatchStep.step needs {self.K} cameras, vertex sets and images")
+        self.host_steps += 1
         main = torch.cuda.current_stream(self.dev)
         pairs = []
         for L, cam, verts, gt in zip(self.lanes, cameras, posed_verts, gt_images):

@@ -409,6 +409,12 @@ def rasterize_gaussians_backward_batch(views, slots=None, raw=False, wants=None,
                  grads=_lib.fr_grads(*[_ptr(g[n]) for n in names]),
                  radii=radii, geom=geomBuffer, img=imageBuffer, binning=binningBuffer, dpix=dL_dout_color)
         st.append(v)
+    # fr_aux::overflow_out is OVERWRITTEN (0 or 1) by every backward: views of one launch that shared a word would race, and a
+    # view that did not overflow could clear the flag of one that did (the optimizer would step on a partly zero gradient)
+    words = [int(_stats3(stats[k])[2].data_ptr()) for k in range(K) if _stats3(stats[k])[2] is not None]
+    if len(set(words)) != len(words):
+        raise RuntimeError("rasterize_gaussians_backward_batch: the views of a batch need ONE overflow word EACH "
+                           "(fused_densification_stats[2]); give every view its own statistics tuple")
     handles = (C.c_void_p * K)(*[_lib.handle(dev, sl) for sl in slots])
     prm_p = (C.POINTER(_lib.fr_params) * K)(*[C.pointer(v["prm"]) for v in st])
     inp_p = (C.POINTER(_lib.fr_inputs) * K)(*[C.pointer(v["inp"]) for v in st])

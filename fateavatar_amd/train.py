@@ -71,6 +71,7 @@ class TrainStep:
         self._graph = None       # render .. backward (.. Adam when world == 1)
         self._eager_steps = 0
         self.overflows = 0       # replayed frames that overflowed the captured binning capacity (see _poll_overflow)
+        self.host_steps = 0      # step() calls; the device's own count of APPLIED updates is adam.step_count (skipped_steps)
 
     # -- the step body: everything between zero_grad and the gradient exchange
     def _forward_backward(self):
@@ -119,6 +120,7 @@ class TrainStep:
 
     def step(self, camera: TorchCamera, gt_image: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's frame.  Returns the (device) loss scalar of the step."""
+        self.host_steps += 1
         self._load_inputs(camera, gt_image)
         if self.use_graph and self._graph is None and self._eager_steps >= 2:
             self._capture()
@@ -147,6 +149,14 @@ class TrainStep:
             for d, s in pairs:
                 d.copy_(s, non_blocking=True)
 
+    @property
+    def skipped_steps(self) -> int:
+        """Steps whose update the device skipped because a captured frame overflowed its binning capacity (the overflow word,
+        FusedAdam.set_skip_words): step() calls minus applied Adam updates.  The host-side schedules (learning-rate decay,
+        densify / prune / reset intervals) advance with step() calls; a caller that wants the lost iterations back re-runs this
+        many.  Reads device state: synchronises."""
+        return self.host_steps - self.adam.step_count
+
     def _poll_overflow(self):
         """The sort kernel of every frame writes its counts to pinned host memory; reading them costs nothing and
         needs no synchronisation (they belong to the most recent frame that has got that far).  A replayed frame that
@@ -157,10 +167,13 @@ class TrainStep:
         if rasterizer.check_async_overflow(self.dev.index or 0):
             self.overflows += 1
             self._graph, self._eager_steps = None, 0
-            import warnings   # (every occurrence: the replays since the overflow stepped Adam on a zero gradient)
+            # every occurrence warns.  The replays since the overflow SKIPPED their update on the device: the Adam step count
+            # (`self.adam.step_count`, device state) stays behind the host's iteration counters by the number of skipped steps —
+            # the `skipped_steps` property is that difference, for callers whose schedules should re-run the lost iterations
+            import warnings
             warnings.warn(f"{type(self).__name__}: the binning capacity overflowed inside the captured step (occurrence "
                           f"{self.overflows}); the affected replays back-propagated zeros and their optimizer launch skipped the "
-                          "step (overflow word), the step runs eagerly and is captured again")
+                          "step (overflow word; `skipped_steps` counts them), the step runs eagerly and is captured again")
 
     # -- Gaussian maintenance (reference: train/iteration.py:62-86 -> model/fateavatar.py:610-731), generic-3DGS flavour:
     #    the FateAvatar versions additionally carry the mesh binding (face index, barycentrics) of every row
@@ -196,10 +209,10 @@ class TrainStep:
         acc, _ = self.reduce_densification_stats()
         w = acc.reshape(-1)
         idx = torch.zeros(increase_num, dtype=torch.int64, device=self.dev)
+        if float(w.sum()) <= 0:       # (the summed statistics are identical on every rank: all of them raise, none is left
+            raise RuntimeError("no densification statistics accumulated yet")   # waiting in the broadcast below)
         if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
-            if float(w.sum()) <= 0:
-                raise RuntimeError("no densification statistics accumulated yet")
-            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)
+            idx = torch.multinomial(w, increase_num, replacement=True, generator=generator)   # (`generator`: rank 0's only)
         dp.broadcast_(idx)
         rows = [getattr(pc, name).detach()[idx].clone() for name, _ in pc.FIELDS]
         rows[3] = torch.log(torch.exp(rows[3]) * 0.75)   # _scaling
@@ -250,6 +263,7 @@ class TrainStep:
             self.adam.exp_avg_sq.copy_(opt["exp_avg_sq"])
             self.adam.state.zero_()
             self.adam.state[:4].copy_(opt["state"][:4])
+        self.host_steps = self.adam.step_count          # (skipped_steps counts from the restored state on)
         dens = sd.get("densification")
         if dens is not None:
             self.xyz_gradient_accum.copy_(dens["xyz_gradient_accum"])

@@ -102,7 +102,9 @@ typedef struct fr_aux {
     /* fr_backward out [1] (device float, or NULL): 1.0f if the frame this backward belongs to overflowed its binning capacity
      * — nothing was blended, every gradient of the call is zero —, else 0.0f.  A step replayed from a hipGraph cannot react on
      * the host before its optimizer kernel runs; fr_adam_config::skip points the update at these words instead (a step
-     * whose gradient is partly zeros for that reason is skipped, moments and step count included). */
+     * whose gradient is partly zeros for that reason is skipped, moments and step count included).  The word is OVERWRITTEN by
+     * every backward call: frames that feed one optimizer step need ONE WORD EACH (fr_adam_config::skip takes up to
+     * FR_ADAM_MAX_GRADS of them); the views of one fr_backward_batch call must not share a word. */
     float* overflow_out;
 } fr_aux;
 
