@@ -659,7 +659,7 @@ def _dp_reference_at_1(args):
     """`bench.py --exchange-at-1` as a child process (its own HIP context and one-rank RCCL group), after this process's timed
     region: the N > 1 steps at one rank.  A run that cannot produce it says why in `status`."""
     try:
-        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--opacity", str(args.opacity)] + _scene_args(args))
+        rec = _child_line(["--exchange-at-1", "--cpu-seconds", "0", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--no-config5", "--opacity", str(args.opacity)] + _scene_args(args))
         m = rec["dp"]["modes"]
         keys = ("value", "unit", "ms_per_step", "frames_per_step_per_gpu")
         return {"status": "ok",
@@ -677,7 +677,7 @@ def _coherent_layout(args):
     scene (its order is random) and never `value`."""
     try:
         os.environ["FR_BENCH_ORDER"] = "coherent"
-        rec = _child_line(["--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--opacity", str(args.opacity)] + _scene_args(args))
+        rec = _child_line(["--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--no-config5", "--opacity", str(args.opacity)] + _scene_args(args))
         return {"status": "ok", "value": rec["value"], "unit": rec["unit"], "one_frame_at_a_time": (rec.get("one_frame_at_a_time") or {}).get("value"),
                 "preprocess_fwd_us": (rec.get("stage_us") or {}).get("preprocess_fwd"),
                 "what": "the same Gaussians stored in grid-cell order (fateavatar_amd.scenes.spatial_order), same modes as `value`"}
@@ -693,7 +693,7 @@ def _runtime_defaults(args):
     saved = {k: os.environ.pop(k, None) for k in ("HIP_FORCE_DEV_KERNARG", "DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
     try:
         os.environ["FR_BENCH_RUNTIME_DEFAULTS"] = "1"
-        rec = _child_line(["--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults",
+        rec = _child_line(["--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--no-config5",
                            "--opacity", str(args.opacity)] + _scene_args(args)[:-2] + ["--rounds", "1"])
         return {"status": "ok", "one_frame_at_a_time": rec["value"], "unit": rec["unit"], "hip_env": rec["config"]["hip_env"],
                 "what": "the same frames, one at a time, in a process that sets neither runtime switch"}
@@ -710,12 +710,32 @@ def _opaque_scene(args):
     """The operating point training moves to (opacity 0.9; config/fateavatar.yaml:40-47 prunes below 0.005, the rest
     saturates): the same scene and run, one frame at a time, as a child process — frames/s and the blend backward's launch."""
     try:
-        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults"]
+        rec = _child_line(["--opacity", "0.9", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque", "--no-coherent", "--no-runtime-defaults", "--no-config5"]
                           + _scene_args(args)[:-2] + ["--rounds", "1"])
         r = rec.get("roofline") or {}
         return {"status": "ok", "opacity": 0.9, "value": rec["value"], "unit": rec["unit"], "frames_in_flight": 1,
                 "num_rendered": rec["config"]["num_rendered"], "blend_bwd_us": r.get("avg_launch_us"), "blend_bwd_frac": r.get("frac"),
                 "stage_us": rec.get("stage_us")}
+    except Exception as e:
+        return {"status": "failed: " + repr(e)[:300]}
+
+
+def _config5_scene(args):
+    """SURVEY.md §8d config 5 — 500 000 Gaussians at 1024 x 1024, the largest single-GPU configuration, where the launch ramp
+    distorts the graded kernel's fraction least — as a child process after the timed region: the blend backward's isolated
+    launch (dispatch-tied events, as `roofline`), its algorithmic bytes (76 R + 20 HW + 8 T) and fraction, every stage's
+    duration and fraction, one frame at a time."""
+    try:
+        rec = _child_line(["--P", "500000", "--res", "1024", "--in-flight", "1", "--cpu-seconds", "0", "--no-dp-reference", "--no-opaque",
+                           "--no-coherent", "--no-runtime-defaults", "--no-config5", "--steps", str(min(args.steps, 60)),
+                           "--warmup", str(min(args.warmup, 10)), "--sh-degree", str(args.sh_degree), "--rounds", "1"], timeout=600)
+        r = rec.get("roofline") or {}
+        return {"status": "ok", "workload": rec["config"]["workload"], "bound": "hbm", "kernel": r.get("kernel"),
+                "avg_launch_us": r.get("avg_launch_us"), "launches": r.get("launches"), "algorithmic_bytes": r.get("algorithmic_bytes"),
+                "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+                "num_rendered": rec["config"]["num_rendered"], "tile_instances_8x8": rec["config"]["tile_instances_8x8"],
+                "max_tile_list": rec["config"]["max_tile_list"],
+                "one_frame_at_a_time": rec["value"], "stage_us": rec.get("stage_us"), "stage_frac": rec.get("stage_frac")}
     except Exception as e:
         return {"status": "failed: " + repr(e)[:300]}
 
@@ -760,6 +780,9 @@ def main():
     ap.add_argument("--no-runtime-defaults", dest="runtime_defaults", action="store_false", default=True,
                     help="N = 1: do not add `runtime_defaults` (one frame at a time in a process that leaves the ROCm runtime's "
                          "switches alone, measured by a second run of this script after the timed region)")
+    ap.add_argument("--no-config5", dest="config5", action="store_false", default=True,
+                    help="N = 1: do not add `roofline_config5` (the blend backward's launch and every stage at 500 k Gaussians / "
+                         "1024 x 1024, measured by a second run of this script after the timed region)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="replay the frame as a HIP graph")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", default=True,
@@ -986,6 +1009,9 @@ def main():
         rt_defaults = None
         if not STUB and world == 1 and not exchanging and args.runtime_defaults and args.graph and stock_run(args):
             rt_defaults = _runtime_defaults(args)
+        config5 = None
+        if not STUB and world == 1 and not exchanging and args.config5 and args.graph and stock_run(args) and (args.P, args.res) == (100_000, 512):
+            config5 = _config5_scene(args)
         coherent = None
         if (not STUB and world == 1 and not exchanging and args.coherent and args.graph and args.scale is None
                 and os.environ.get("FR_BENCH_ORDER") is None):
@@ -1027,7 +1053,10 @@ def main():
                                         f"dp1 ({rounds} round(s) of {K_best} view(s) in flight per step, each view on its own stream)")),
                        "num_rendered": R, "tile_instances_8x8": counts["num_instances"],
                        "max_tile_list": counts["max_tile_list"]},
-            "roofline": roof, "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac,
+            "roofline": roof,
+            # the same kernel at SURVEY.md §8d config 5 (500 k Gaussians, 1024 x 1024: the largest single-GPU configuration)
+            "roofline_config5": config5,
+            "cpu_baseline": cpu, "stage_us": stages, "stage_frac": stage_frac,
             # (stage_frac bills SURVEY.md's formulas; stage_frac_required the bytes this layout has to move: stage_bytes_required)
             "stage_frac_required": stage_frac_required, "dp": dpinfo,
             "one_frame_at_a_time": single,

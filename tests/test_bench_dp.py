@@ -76,7 +76,7 @@ def test_bench_single_rank_stub_line_is_well_formed():
     assert j["n_gpus"] == 1 and j["dp"] is None and j["data"] == "stub"
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "config",
               "roofline", "cpu_baseline", "stage_us", "stage_frac", "stage_frac_required", "scaling_reference", "efficiency",
-              "opaque", "coherent_layout", "one_frame_at_a_time"):
+              "opaque", "roofline_config5", "coherent_layout", "one_frame_at_a_time"):
         assert k in j
 
 
