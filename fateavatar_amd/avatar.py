@@ -245,6 +245,7 @@ class AvatarStep(TrainStep):
         self.out = None
         self.use_graph = bool(use_graph)
         self._graph, self._eager_steps, self.overflows = None, 0, 0
+        self.host_steps = 0      # (TrainStep.skipped_steps)
 
     def adam_segments(self):
         """The optimizer groups (train/optim.py:15-21 with config/fateavatar.yaml:34-39) as runs of the flat buffer."""

@@ -19,7 +19,10 @@ constexpr int kSubWords = 8;      // per-tile sub-list table: start (within the 
 // reads, independent alpha evaluations in flight, no divergent walk).
 constexpr uint32_t kDensePairsFwd = 1000;  // local forward blend: all-pairs loop above this many mask bits per unit
 constexpr uint32_t kDensePairsBwd = 1000;  // backward: the same choice inside k_unit_blend_bwd_sparse
-constexpr int kPreWG = 128;   // threads per workgroup of k_preprocess_fwd
+#ifndef FR_PRE_WG
+#define FR_PRE_WG 128
+#endif
+constexpr int kPreWG = FR_PRE_WG;   // threads per workgroup of k_preprocess_fwd
 constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
 constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)

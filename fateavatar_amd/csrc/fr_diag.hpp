@@ -76,3 +76,5 @@ extern "C" int fr_debug_read_fwd_trace(void* dst, size_t bytes)
 #define FW_STAMP(K) do { } while (0)
 #define FW_STAMPV(K, V) do { } while (0)
 #endif
+
+// (fr_preprocess.hip has its own timing-experiment switch, -DFR_DIAG_PRE_ABLATE=mask, defined at its head)

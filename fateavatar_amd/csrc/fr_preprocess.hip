@@ -7,6 +7,40 @@
 // kernels are bandwidth-trivial; the missing FMAs cost nothing measurable.
 #include "fr_bind_math.hpp"
 
+// Development only, compiled out of the product build: -DFR_DIAG_PRE_ABLATE=mask — timing experiments on k_preprocess_fwd (results are WRONG): bit 0 no SH colour (no SH loads), bit 1
+//                     no counting pass, bit 2 the counting pass without its key stores, bit 3 without its global atomics, bit 4
+//                     without the early SH line touches, bit 5 without the geometry (everything culled right after the loads), bit 6 without the d colour / d direction stores, bit 7 without the
+//                     blend-record stores
+#ifdef FR_DIAG_PRE_ABLATE
+#define FR_PRE_ABLATE(k) (((FR_DIAG_PRE_ABLATE) >> (k)) & 1)
+#else
+#define FR_PRE_ABLATE(k) false
+#endif
+
+// -DFR_DIAG_PRE_TRACE: per-wave cycle stamps at the phase boundaries of k_preprocess_fwd (tools/diag/pre_phases.py reads them)
+#ifdef FR_DIAG_PRE_TRACE
+namespace fr {
+constexpr unsigned kPreTraceWaves = 16384, kPreTraceSlots = 12;
+__device__ unsigned long long g_pre_trace[kPreTraceWaves * kPreTraceSlots];
+}
+extern "C" int fr_diag_read_pre_trace(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fr::g_pre_trace), bytes < sizeof(fr::g_pre_trace) ? bytes : sizeof(fr::g_pre_trace));
+}
+#define PRE_TR_DECL unsigned long long ptr_acc[::fr::kPreTraceSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ptr_t = __builtin_readcyclecounter(), ptr_rt0 = __builtin_amdgcn_s_memrealtime()
+#define PRE_TR(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); ptr_acc[(k)] += n_ - ptr_t; ptr_t = n_; } while (0)
+#define PRE_TR_STORE() do { \
+        ptr_acc[11] = (ptr_rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); \
+        const unsigned w_ = (blockIdx.x * kPreWG + threadIdx.x) >> 6; \
+        if (lane == 0 && w_ < ::fr::kPreTraceWaves && blockIdx.y == 0) \
+            for (unsigned k_ = 0; k_ < ::fr::kPreTraceSlots; k_++) ::fr::g_pre_trace[(size_t)w_ * ::fr::kPreTraceSlots + k_] = ptr_acc[k_]; \
+    } while (0)
+#else
+#define PRE_TR_DECL do { } while (0)
+#define PRE_TR(k) do { } while (0)
+#define PRE_TR_STORE() do { } while (0)
+#endif
+
 namespace fr {
 
 __constant__ float kSH_C0 = 0.28209479177387814f;
@@ -140,7 +174,41 @@ __device__ __forceinline__ bool footprint_touches_tile(const float4 conic_tau2, 
 }
 
 constexpr int kCountUnroll = 4;                           // candidates per lane and pass of the counting loop
-constexpr int kCountLdsBytes = 2816 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below)
+constexpr int kCountLdsBytes = 2816 + 3 * kCountUnroll * 256;  // per-wave tables of the counting pass (see below): 5888 B
+
+// The SH rows of a wave's 64 Gaussians are one contiguous block of 64 x M3 floats.  It is copied into LDS by LDS-DMA
+// (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, no staging registers, fully coalesced 1-KB pieces), issued
+// when the kernel starts, and every thread reads its own row from there when it evaluates its colour.  (Each thread loading
+// its own 192-byte row from memory — twelve 16-byte loads at a 192-byte stride across the wave — asked the L1 for every
+// 128-byte line of the block eight times: 25 of config 5's 73 us, tools/diag/ab_pre.sh.)  The counting pass's tables reuse
+// the space once the rows have been read.
+// The copy is issued from inline assembly (FR_PRE_SH_DMA 2; 1 = the compiler's builtin): with the builtin the compiler knows
+// that an LDS-DMA is in flight somewhere and puts an s_waitcnt vmcnt(0) in front of EVERY later LDS access of the kernel —
+// each of the counting pass's phases then waited for all of the thread's outstanding stores.  The waits the copy needs are
+// written out where its rows are read; an instruction the compiler does not count only makes its own counted waits stricter.
+#ifndef FR_PRE_SH_DMA
+#define FR_PRE_SH_DMA 2
+#endif
+__device__ __forceinline__ void dma16_to_lds(const void* g, uint32_t lds_byte_address /* wave-uniform */)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_address), "v"(g) : "memory");   // (m0 is reserved: the compiler sets it itself before every use of its own)
+}
+// FR_PRE_ROWS_IN_REGS: at M = 16 every thread takes its row into registers BEFORE the counting tables are written, which then
+// reuse the block's space (12 KB per wave instead of 18: three waves per SIMD instead of two) at the price of 48 registers
+// held across the counting pass
+#ifndef FR_PRE_ROWS_IN_REGS
+#define FR_PRE_ROWS_IN_REGS 1
+#endif
+__host__ __device__ constexpr int pre_wave_lds_bytes(int M3)
+{
+    // the SH block (it has to be there BEFORE the counting atomics are issued and is read while they are in flight: loads
+    // and returning atomics come back in order, a block requested behind the atomics would arrive behind them), then the
+    // tables of the counting pass
+#if FR_PRE_ROWS_IN_REGS
+    if (M3 == 48) return 256 * M3;   // (the rows are in registers by the time the tables are written: same space)
+#endif
+    return 256 * M3 + kCountLdsBytes;
+}
 
 __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
 {
@@ -151,6 +219,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DeviceCounts) / 4) reinterpret_cast<uint32_t*>(a.counts)[threadIdx.x] = 0u;
     if ((int)(blockIdx.x * kPreWG) >= a.P) return;   // (a batched launch's grid is the largest view's; P > 0: block 0 stays)
     const int M3 = a.M * 3;
+    PRE_TR_DECL;
     // every input of this thread is requested up front (camera, mean, scale, rotation, opacity — and the SH block
     // below), so that the kernel pays one memory round trip for its inputs instead of one per use
     const CameraRegs cam = load_camera(a.view, a.proj, a.campos, lane);
@@ -180,31 +249,54 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
             in_rot[3] = a.rotations[4 * li + 3];
     }
     const float in_opacity = a.opacities[li];
-    float sh_touch = 0.f;
-    if (a.shs && !a.colors_precomp) {
-        // one load per 128-byte line of the wave's [64][M3] block of SH rows: they are in this XCD's L2 by the time the
-        // threads ask for their own rows (the sum is only consumed at the kernel's end: nothing waits for these loads)
-        const int wave_first = blockIdx.x * kPreWG + wave * 64;
-        if (wave_first < a.P) {
-            const char* blk = reinterpret_cast<const char*>(a.shs + (size_t)wave_first * M3);
-            const int bytes = min(64, a.P - wave_first) * M3 * 4;
-            for (int off = lane * 128; off < bytes; off += 64 * 128) sh_touch += *reinterpret_cast<const float*>(blk + off);
-        }
+    // (requested with the other inputs: a load issued behind the counting atomics would come back behind them)
+    float in_col[3] = {0.f, 0.f, 0.f};
+    if (a.colors_precomp) in_col[0] = a.colors_precomp[3 * li], in_col[1] = a.colors_precomp[3 * li + 1], in_col[2] = a.colors_precomp[3 * li + 2];
+    // one LDS region per wave: the SH rows of its Gaussians, then the tables of its counting pass —
+    // nothing in it is shared between waves, so the kernel needs no workgroup barrier for it
+    float* const wave_lds = s_sh + (size_t)wave * (pre_wave_lds_bytes(M3) / 4);   // (launch_forward sizes it the same way)
+    const int wave_first = blockIdx.x * kPreWG + wave * 64;
+    // The colour stage reads every thread's SH row from LDS.  Full waves get their block by LDS-DMA; the last wave of the
+    // launch (the copy moves whole 16-byte pieces and must not read past the array) has every thread copy its own row.
+    const bool rows_in_lds = a.shs && !a.colors_precomp && !FR_PRE_ABLATE(0);
+    const bool sh_in_lds = rows_in_lds && __builtin_amdgcn_readfirstlane((int)(FR_PRE_SH_DMA && wave_first + 64 <= a.P)) != 0;
+#if FR_PRE_SH_DMA
+    if (sh_in_lds) {
+        const char* blk = reinterpret_cast<const char*>(a.shs + (size_t)wave_first * M3);
+        const int bytes = 256 * M3;                                   // 64 rows x M3 floats
+#if FR_PRE_SH_DMA == 2
+        const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)wave_lds);
+#endif
+        for (int off = 0; off < bytes; off += 1024)                   // (wave-uniform trip count)
+            if (off + lane * 16 < bytes) {
+#if FR_PRE_SH_DMA == 2
+                dma16_to_lds(blk + off + lane * 16, lds0 + (uint32_t)off);
+#else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(wave_lds) + off), 16, 0, 0);
+#endif
+            }
     }
-    // one LDS region per wave: the tables of its counting pass — nothing in it is shared between waves, so the kernel needs
-    // no workgroup barrier for it
-    float* const wave_lds = s_sh + (size_t)wave * (kCountLdsBytes / 4);   // (launch_forward sizes it the same way)
+#endif
+    if (rows_in_lds && !sh_in_lds && live)
+        for (int k = 0; k < M3; k++) wave_lds[lane * M3 + k] = a.shs[(size_t)idx * M3 + k];
     uint32_t ref_tiles = 0;  // tiles_touched in reference semantics (16x16)
     uint2 rect = make_uint2(0u, 0u);
     float4 cull = make_float4(0.f, 0.f, 0.f, __builtin_inff());  // conic + footprint threshold (per-tile culling)
     float2 ctr = make_float2(0.f, 0.f);
-    float key_depth = 0.f;   // view-space z: the sort key of this Gaussian's instances
+    // what the geometry leaves for the colour stage of a Gaussian that passed it (`alive`)
+    bool alive = false;
+    int mr_out = 0;
+    float rec_ca = 0.f, rec_cb = 0.f, rec_cc = 0.f, rec_op = 0.f, rec_z = 0.f;
+    PRE_TR(0);   // loads issued
     if (idx < a.P) {
-        int radius_out = 0;
         do {
             // near cull only (auxiliary.h:154)
             const float3 p_view = xform4x3(p_orig, cam.view);
+            PRE_TR(1);   // inputs landed (first use)
             if (p_view.z <= 0.2f) break;
+            if (FR_PRE_ABLATE(5) && in_opacity > -1e30f) break;
 
             const float4 p_hom = xform4x4(p_orig, cam.proj);
             const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -274,67 +366,20 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
             if ((rx1 - rx0) * (ry1 - ry0) == 0) break;
             ref_tiles = (uint32_t)((rx1 - rx0) * (ry1 - ry0));
 
-            // ---- colour (forward.cu:20-71)
-            float col[3];
-            float raw_sum = 0.f;   // of the colour BEFORE the clamp at 0 (fmaxf would turn a NaN into 0)
-            uint8_t clamp_bits = 0;
-            if (a.colors_precomp) {
-                col[0] = a.colors_precomp[3 * idx], col[1] = a.colors_precomp[3 * idx + 1], col[2] = a.colors_precomp[3 * idx + 2];
-                raw_sum = (col[0] + col[1]) + col[2];
-            } else {
-                float dx = p_orig.x - cam.campos[0], dy = p_orig.y - cam.campos[1], dz = p_orig.z - cam.campos[2];
-                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = dx / len, dy = dy / len, dz = dz / len;
-                float dd[9];
-                // (one body for both sources of the coefficients; fully unrolled so that every index is a constant)
-                auto eval_colour = [&](const float* sh) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float v = sh_channel(sh, c, a.D, dx, dy, dz);
-                        if (v < 0) clamp_bits |= (uint8_t)(1u << c);
-                        col[c] = fmaxf(v, 0.0f);
-                        raw_sum += v;
-                        sh_dchannel_ddir(sh, c, a.D, dx, dy, dz, dd[c], dd[3 + c], dd[6 + c]);
-                    }
-                };
-                if (M3 == 48) {   // the thread's own row, twelve 16-byte loads (the lines are in L2: touched at the kernel's start)
-                    float shr[48];
-                    const float4* row = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
-#pragma unroll
-                    for (int k = 0; k < 12; k++) {
-                        const float4 q = row[k];
-                        shr[4 * k] = q.x, shr[4 * k + 1] = q.y, shr[4 * k + 2] = q.z, shr[4 * k + 3] = q.w;
-                    }
-                    eval_colour(shr);
-                } else {
-                    eval_colour(a.shs + (size_t)idx * M3);   // (other row lengths: straight from memory)
-                }
-                float* o = a.g.dcolor_ddir + (size_t)idx * 9;
-                for (int k = 0; k < 9; k++) o[k] = dd[k];
-            }
 
             const float opacity = a.raw ? act_sigmoid(in_opacity) : in_opacity;
             // Contract: a Gaussian whose projected state is not finite (NaN / inf position, scale,
-            // rotation, opacity or colour) is DROPPED like a culled one — radius 0, no instances, zero gradient rows —
-            // instead of spreading NaN over the image and every gradient as the reference's arithmetic would.
+            // rotation, opacity or colour) is DROPPED like a culled one — radius 0, no contribution to any pixel, zero gradient
+            // rows — instead of spreading NaN over the image and every gradient as the reference's arithmetic would.  The
+            // geometry is tested here, the colour when it has been evaluated (below).
             {
-                const float chk = (((pix_x + pix_y) + (conic_a + conic_b + conic_c)) + raw_sum) + (opacity + p_view.z);
+                const float chk = ((pix_x + pix_y) + (conic_a + conic_b + conic_c)) + (opacity + p_view.z);
                 if (!(fabsf(chk) < 3.0e38f)) break;
             }
-            radius_out = mr;
-            key_depth = p_view.z;
-            a.g.opacity_act[idx] = opacity;
-            {
-                // the blend record (GeomView::rec_tmpl): the conic as (-0.5 a, -b, -0.5 c) — exact scalings — so that the blend
-                // loops get the reference's power = a'dx^2 + c'dy^2 + b'dxdy (forward.cu:340) in three multiply-adds, and the
-                // blend backward the reference's conic itself
-                float4* t = a.g.rec_tmpl + (size_t)idx * 3;
-                t[0] = make_float4(pix_x, pix_y, conic_a * -0.5f, -conic_b);
-                t[1] = make_float4(conic_c * -0.5f, opacity, col[0], col[1]);
-                t[2] = make_float4(col[2], __uint_as_float((uint32_t)idx), p_view.z, 0.f);   // (.z: view-space depth, for diagnostics)
-            }
-            a.g.clamped[idx] = clamp_bits;
-
+            alive = true;
+            mr_out = mr;
+            rec_ca = conic_a, rec_cb = conic_b, rec_cc = conic_c, rec_op = opacity, rec_z = p_view.z;
+            ctr = make_float2(pix_x, pix_y);
             // ---- 8x8-tile rectangle of the alpha >= 1/255 footprint, clipped to the pixels the
             // reference rectangle covers.  A pixel outside it can never pass the blend kernels'
             // alpha test, so dropping those (tile, Gaussian) instances changes no pixel.
@@ -365,125 +410,259 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
                     cull = make_float4(conic_a, conic_b, conic_c, 2.0f * tau * (1.0f + 1e-6f));
                 }
             }
-            ctr = make_float2(pix_x, pix_y);
             if (px1 < px0 || py1 < py0) break;
             const int tx0 = px0 / kTile, tx1 = px1 / kTile + 1, ty0 = py0 / kTile, ty1 = py1 / kTile + 1;
             rect = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
         } while (false);
-        a.radii[idx] = radius_out;
-        if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
     }
+    PRE_TR(2);   // geometry, footprint rectangle (and the wave's reconvergence)
+
     // ---- count the (tile, Gaussian) instances AND write their keys.  The atomic that counts an instance hands out
     // its slot in the (tile, XCD) key bucket, and the key goes there at once: no second pass over the Gaussians (the
     // reference's duplicateWithKeys, rasterizer_impl.cu:70-111) and no scan in front of it.  The wave spreads its
     // instances over its lanes: one returning atomic round trip per 64 instances instead of one per tile of the
     // widest rectangle.
-    {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the SH rows have been read: reuse their space
-        __builtin_amdgcn_wave_barrier();
-        char* cl = reinterpret_cast<char*>(wave_lds);
-        float4* s_cull = reinterpret_cast<float4*>(cl);                                  // [64]   1024 B
-        uint2* s_rect = reinterpret_cast<uint2*>(cl + 1024);                              // [64]    512 B
-        float2* s_ctr = reinterpret_cast<float2*>(cl + 1536);                             // [64]    512 B
-        uint32_t* s_excl = reinterpret_cast<uint32_t*>(cl + 2048);                        // [64]    256 B
-        uint2* s_gk = reinterpret_cast<uint2*>(cl + 2304);                                // [64]    512 B  (id, depth bits)
-        // (the lanes of the wave talk through these two: plain LDS accesses, ordered by wave-level fences between the
-        // phases below — as `volatile` pointers they lost their address space and became FLAT loads and stores, whose
-        // s_waitcnt vmcnt(0) also waited for every global atomic in flight)
-        uint32_t* s_gkey = reinterpret_cast<uint32_t*>(cl + 2816);      // [4][64] 1024 B
-        uint32_t* s_gbase = reinterpret_cast<uint32_t*>(cl + 3840);     // [4][64] 1024 B
-        uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 4864);                        // [4][64] 1024 B  -> kCountLdsBytes
+    // The chip serves about 26 returning atomics per nanosecond whatever their addresses (tools/micro_atomics.hip): the
+    // instances of BASELINE config 2 are 10 us of that, config 5's 38 us — so the atomics of a wave's first 256 instances
+    // are ISSUED before its colours are evaluated and their keys are stored after: the SH evaluation, the record stores and
+    // the SH rows' own trip from memory run while the atomics queue.
+    const bool rows_in_regs = FR_PRE_ROWS_IN_REGS && M3 == 48;
+    char* cl = reinterpret_cast<char*>(wave_lds) + (rows_in_regs ? 0 : 256 * M3);
+    float4* s_cull = reinterpret_cast<float4*>(cl);                                  // [64]   1024 B
+    uint2* s_rect = reinterpret_cast<uint2*>(cl + 1024);                              // [64]    512 B
+    float2* s_ctr = reinterpret_cast<float2*>(cl + 1536);                             // [64]    512 B
+    uint32_t* s_excl = reinterpret_cast<uint32_t*>(cl + 2048);                        // [64]   256 B
+    uint2* s_gk = reinterpret_cast<uint2*>(cl + 2304);                                // [64]    512 B  (id, depth bits)
+    // (the lanes of the wave talk through these: plain LDS accesses, ordered by wave-level fences between the
+    // phases below — as `volatile` pointers they lost their address space and became FLAT loads and stores, whose
+    // s_waitcnt vmcnt(0) also waited for every global atomic in flight)
+    uint32_t* s_gkey = reinterpret_cast<uint32_t*>(cl + 2816);      // [4][64] 1024 B
+    uint32_t* s_gcnt = reinterpret_cast<uint32_t*>(cl + 3840);      // [4][64] 1024 B  -> 4864
+    uint32_t* s_gbase = reinterpret_cast<uint32_t*>(cl + 4864);     // [4][64] 1024 B  -> kCountLdsBytes
+    const int rw_ = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), rh_ = (int)(rect.y >> 16) - (int)(rect.x >> 16);
+    const uint32_t n = (rw_ > 0 && rh_ > 0) ? (uint32_t)(rw_ * rh_) : 0u;
+    uint32_t incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    auto stage_tables = [&]() {
         s_cull[lane] = cull;
         s_ctr[lane] = ctr;
-        const int w = (int)(rect.y & 0xffff) - (int)(rect.x & 0xffff), h = (int)(rect.y >> 16) - (int)(rect.x >> 16);
-        const uint32_t n = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
-        s_gk[lane] = make_uint2((uint32_t)idx, __float_as_uint(key_depth));
-        uint32_t incl = n;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        const uint32_t total = __shfl(incl, 63);
+        s_gk[lane] = make_uint2((uint32_t)idx, __float_as_uint(rec_z));
         s_excl[lane] = incl - n;
         s_rect[lane] = rect;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
-        // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several)
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
-        // Wave-level aggregation: lanes of one pass that count into the SAME counter (Gaussians stored in a spatially
-        // coherent order, e.g. the reference's UV-raster initialisation, hit a handful of tiles per wave) are grouped
-        // through a 64-slot table in LDS keyed by the counter index: the group's first lane issues ONE global atomic
-        // for the whole group.  Lanes whose slot is taken by another counter fall back to their own atomic, so with
-        // random orders (all counters distinct) nothing is lost but a few LDS operations.
-        for (uint32_t b0 = 0; b0 < total; b0 += 64 * kCountUnroll) {   // wave-uniform trip count
-            uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll], tile_id[kCountUnroll];
-            uint2 gk[kCountUnroll];
-            bool valid[kCountUnroll], grouped[kCountUnroll];
+    };
+    // the SH block has landed (it was requested with the inputs; LDS-DMA counts on vmcnt like any load, and the compiler does
+    // not see a dependence between the copy and the LDS reads of the colour stage): waited for HERE, in front of the atomics.
+    // (As the builtin, not inline assembly: the compiler's own wait insertion must KNOW that nothing is outstanding here —
+    // otherwise the first register it reuses that some never-taken path loaded into costs an s_waitcnt vmcnt(0) in the
+    // middle of the colour stage, i.e. a wait for the atomics.)   vmcnt(0), expcnt and lgkmcnt untouched: 0x0F70 on gfx9
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    float shr[48];
+#if FR_PRE_ROWS_IN_REGS
+    if (rows_in_regs && rows_in_lds) {
+        const float4* row = reinterpret_cast<const float4*>(wave_lds + lane * 48);
 #pragma unroll
-            for (int u = 0; u < kCountUnroll; u++) {
-                const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
-                valid[u] = false, grouped[u] = false;
-                rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, tile_id[u] = 0, gk[u] = make_uint2(0u, 0u);
-                s_gcnt[u * 64 + lane] = 0u;
-                if (k < total) {
-                    int lo = 0, hi = 63;
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_excl[mid] <= k) lo = mid; else hi = mid - 1;
-                    }
-                    const uint2 rr = s_rect[lo];
-                    const uint32_t j = k - s_excl[lo];
-                    const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
-                    const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
-                    // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
-                    // reaches both ends of its bounding box); only wider ones can miss a corner tile
-                    const uint32_t rh = (rr.y >> 16) - y0;
-                    if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[lo], s_ctr[lo], tx, ty)) {
-                        valid[u] = true;
-                        const uint32_t bx4 = (uint32_t)(a.tiles_x + 3) / 4;   // ImageView::counter_index
-                        key[u] = xcc * a.tpad + ((ty >> 2) * bx4 + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
-                        tile_id[u] = ty * (uint32_t)a.tiles_x + tx;
-                        gk[u] = s_gk[lo];
-                        slot[u] = (key[u] * 2654435761u) >> 26;
-                        s_gkey[u * 64 + slot[u]] = key[u];   // several lanes may write: one of them wins the slot
-                    }
+        for (int k = 0; k < 12; k++) {
+            const float4 q = row[k];
+            shr[4 * k] = q.x, shr[4 * k + 1] = q.y, shr[4 * k + 2] = q.z, shr[4 * k + 3] = q.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every lane has its row: the tables may take the space
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
+    stage_tables();
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & (uint32_t)(kXcds - 1);  // HW_REG_XCC_ID[3:0]
+    PRE_TR(5);   // counting tables set up (scan)
+    // kCountUnroll candidates per lane and pass: their returning atomics are all in flight before the first
+    // result is needed (a wave typically has 2-4 x 64 candidates: one round trip instead of several).
+    // Wave-level aggregation: lanes of one pass that count into the SAME counter (Gaussians stored in a spatially
+    // coherent order, e.g. the reference's UV-raster initialisation, hit a handful of tiles per wave) are grouped
+    // through a 64-slot table in LDS keyed by the counter index: the group's first lane issues ONE global atomic
+    // for the whole group.  Lanes whose slot is taken by another counter fall back to their own atomic, so with
+    // random orders (all counters distinct) nothing is lost but a few LDS operations.
+    uint32_t rank[kCountUnroll], key[kCountUnroll], slot[kCountUnroll], tile_id[kCountUnroll], got[kCountUnroll], owner[kCountUnroll];
+    uint2 gk[kCountUnroll];
+    bool valid[kCountUnroll], grouped[kCountUnroll];
+    static_assert(kCountUnroll == 4, "count_finish pins four positions");
+    auto count_issue = [&](uint32_t b0) {   // candidates b0 .. b0 + 255: tile, footprint test, grouping, atomics issued
+#pragma unroll
+        for (int u = 0; u < kCountUnroll; u++) {
+            const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
+            valid[u] = false, grouped[u] = false;
+            rank[u] = 0, key[u] = 0, slot[u] = (uint32_t)lane, tile_id[u] = 0, gk[u] = make_uint2(0u, 0u), owner[u] = 0, got[u] = 0;
+            s_gcnt[u * 64 + lane] = 0u;
+            if (k < total) {
+                // owner of candidate k: the last lane whose first candidate is <= k.  Six fixed steps, no branches: the
+                // four candidates of a lane search in lockstep (as a `while (lo < hi)` loop each, the four searches ran one
+                // behind the other: 24 dependent LDS round trips per pass instead of 6)
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) lo += (s_excl[lo + step] <= k) ? step : 0;
+                const uint2 rr = s_rect[lo];
+                const uint32_t j = k - s_excl[lo];
+                const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
+                const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
+                // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
+                // reaches both ends of its bounding box); only wider ones can miss a corner tile
+                const uint32_t rh = (rr.y >> 16) - y0;
+                if (!(rw > 1 && rh > 1) || footprint_touches_tile(s_cull[lo], s_ctr[lo], tx, ty)) {
+                    valid[u] = true;
+                    const uint32_t bx4 = (uint32_t)(a.tiles_x + 3) / 4;   // ImageView::counter_index
+                    key[u] = xcc * a.tpad + ((ty >> 2) * bx4 + (tx >> 2)) * 16u + ((ty & 3u) << 2 | (tx & 3u));
+                    tile_id[u] = ty * (uint32_t)a.tiles_x + tx;
+                    gk[u] = s_gk[lo];
+                    owner[u] = (uint32_t)lo;
+                    slot[u] = (key[u] * 2654435761u) >> 26;
+                    s_gkey[u * 64 + slot[u]] = key[u];   // several lanes may write: one of them wins the slot
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the slots' winners are in LDS
-            __builtin_amdgcn_wave_barrier();
+        }
+        PRE_TR(6);   // candidates: owner search, tile, footprint test, hash slot
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the slots' winners are in LDS
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < kCountUnroll; u++) {
-                grouped[u] = valid[u] && s_gkey[u * 64 + slot[u]] == key[u];
-                if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[u * 64 + slot[u]], 1u);
+        for (int u = 0; u < kCountUnroll; u++) {
+            grouped[u] = valid[u] && s_gkey[u * 64 + slot[u]] == key[u];
+            if (grouped[u]) rank[u] = atomicAdd(&s_gcnt[u * 64 + slot[u]], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' sizes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < kCountUnroll; u++) {
+            if (valid[u] && (!grouped[u] || rank[u] == 0)) {
+                const uint32_t n_add = grouped[u] ? s_gcnt[u * 64 + slot[u]] : 1u;
+                got[u] = FR_PRE_ABLATE(3) ? (uint32_t)lane : atomicAdd(&a.tile_count[key[u]], n_add);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' sizes
-            __builtin_amdgcn_wave_barrier();
-            uint32_t got[kCountUnroll];
+        }
+        PRE_TR(7);   // grouping, atomics issued
+    };
+    // `dead` (wave mask): Gaussians whose colour turned out not to be finite AFTER their instances had been counted — their
+    // keys get depth +inf: they sort behind every real entry of their tile (no unit boundary of the real entries moves, the
+    // image is what it is without them) and point at a record of opacity 0
+    auto count_finish = [&](unsigned long long dead) {   // the atomics' results -> positions -> the four key stores
 #pragma unroll
-            for (int u = 0; u < kCountUnroll; u++) {
-                got[u] = 0;
-                if (valid[u] && (!grouped[u] || rank[u] == 0)) {
-                    const uint32_t n_add = grouped[u] ? s_gcnt[u * 64 + slot[u]] : 1u;
-                    got[u] = atomicAdd(&a.tile_count[key[u]], n_add);
+        for (int u = 0; u < kCountUnroll; u++)
+            if (grouped[u] && rank[u] == 0) s_gbase[u * 64 + slot[u]] = got[u];
+        PRE_TR(8);   // atomics returned
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' bases
+        __builtin_amdgcn_wave_barrier();
+        // every position first, then the four key stores one behind the other.  (As one loop — position, test, store —
+        // the compiler put an s_waitcnt vmcnt(0) in front of every store: each waited for the one before it to complete,
+        // three store round trips per pass.)
+        uint32_t pos[kCountUnroll];
+#pragma unroll
+        for (int u = 0; u < kCountUnroll; u++) {
+            const uint32_t base = grouped[u] ? s_gbase[u * 64 + slot[u]] : got[u];
+            pos[u] = base + rank[u];
+        }
+        asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3]));
+#pragma unroll
+        for (int u = 0; u < kCountUnroll; u++) {
+            const uint32_t depth_bits = ((dead >> owner[u]) & 1ull) ? 0x7F800000u : gk[u].y;
+            // (a position beyond the bucket is dropped: k_tile_totals sees the count and flags the frame)
+            if (valid[u] && pos[u] < a.bucket_cap && !FR_PRE_ABLATE(2))
+                a.buckets[((size_t)tile_id[u] * kXcds + xcc) * a.bucket_cap + pos[u]] = ((uint64_t)depth_bits << 32) | gk[u].x;
+        }
+        PRE_TR(9);   // key stores issued
+    };
+    const bool counting = total > 0u && !FR_PRE_ABLATE(1);
+    if (counting) count_issue(0u);
+
+    // ---- colour (forward.cu:20-71), with the atomics above in flight
+    bool dead_colour = false;
+    if (idx < a.P) {
+        int radius_out = 0;
+        if (alive) {
+            float col[3];
+            float raw_sum = 0.f;   // of the colour BEFORE the clamp at 0 (fmaxf would turn a NaN into 0)
+            uint8_t clamp_bits = 0;
+            float dd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool from_sh = !FR_PRE_ABLATE(0) && !a.colors_precomp;
+            if (FR_PRE_ABLATE(0)) {
+                col[0] = col[1] = col[2] = 0.5f, raw_sum = 1.5f;
+            } else if (a.colors_precomp) {
+                col[0] = in_col[0], col[1] = in_col[1], col[2] = in_col[2];
+                raw_sum = (col[0] + col[1]) + col[2];
+            } else {
+                float dx = p_orig.x - cam.campos[0], dy = p_orig.y - cam.campos[1], dz = p_orig.z - cam.campos[2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len, dy = dy / len, dz = dz / len;
+                // (one body for both sources of the coefficients; fully unrolled so that every index is a constant)
+                auto eval_colour = [&](const float* sh) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float v = sh_channel(sh, c, a.D, dx, dy, dz);
+                        if (v < 0) clamp_bits |= (uint8_t)(1u << c);
+                        col[c] = fmaxf(v, 0.0f);
+                        raw_sum += v;
+                        sh_dchannel_ddir(sh, c, a.D, dx, dy, dz, dd[c], dd[3 + c], dd[6 + c]);
+                    }
+                };
+                const float* lrow = wave_lds + lane * M3;
+                if (M3 == 48) {   // twelve 16-byte LDS reads
+                    if (!rows_in_regs) {
+                        const float4* row = reinterpret_cast<const float4*>(lrow);
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            const float4 q = row[k];
+                            shr[4 * k] = q.x, shr[4 * k + 1] = q.y, shr[4 * k + 2] = q.z, shr[4 * k + 3] = q.w;
+                        }
+                    }
+                    eval_colour(shr);
+                } else {
+                    eval_colour(lrow);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < kCountUnroll; u++)
-                if (grouped[u] && rank[u] == 0) s_gbase[u * 64 + slot[u]] = got[u];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... the groups' bases
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < kCountUnroll; u++) {
-                if (!valid[u]) continue;
-                const uint32_t pos = (grouped[u] ? s_gbase[u * 64 + slot[u]] : got[u]) + rank[u];
-                // (a position beyond the bucket is dropped: k_tile_totals sees the count and flags the frame)
-                if (pos < a.bucket_cap)
-                    a.buckets[((size_t)tile_id[u] * kXcds + xcc) * a.bucket_cap + pos] = ((uint64_t)gk[u].y << 32) | gk[u].x;
+            PRE_TR(3);   // colour
+            dead_colour = !(fabsf(raw_sum) < 3.0e38f);
+            if (!dead_colour) {
+                radius_out = mr_out;
+                if (from_sh) {
+                    float* o = a.g.dcolor_ddir + (size_t)idx * 9;
+                    if (!FR_PRE_ABLATE(6))
+                        for (int k = 0; k < 9; k++) o[k] = dd[k];
+                    else asm volatile("" ::"v"(dd[0]), "v"(dd[1]), "v"(dd[2]), "v"(dd[3]), "v"(dd[4]), "v"(dd[5]), "v"(dd[6]), "v"(dd[7]), "v"(dd[8]));
+                }
+                a.g.opacity_act[idx] = rec_op;
+                a.g.clamped[idx] = clamp_bits;
+            }
+            {
+                // the blend record (GeomView::rec_tmpl): the conic as (-0.5 a, -b, -0.5 c) — exact scalings — so that the blend
+                // loops get the reference's power = a'dx^2 + c'dy^2 + b'dxdy (forward.cu:340) in three multiply-adds, and the
+                // blend backward the reference's conic itself.  A Gaussian whose colour is not finite leaves a record of
+                // opacity 0 and colour 0 behind its counted instances: no pixel passes its alpha test
+                float4* t = a.g.rec_tmpl + (size_t)idx * 3;
+                if (!FR_PRE_ABLATE(7)) {
+                    t[0] = make_float4(ctr.x, ctr.y, rec_ca * -0.5f, -rec_cb);
+                    t[1] = make_float4(rec_cc * -0.5f, dead_colour ? 0.f : rec_op, dead_colour ? 0.f : col[0], dead_colour ? 0.f : col[1]);
+                    t[2] = make_float4(dead_colour ? 0.f : col[2], __uint_as_float((uint32_t)idx), rec_z, 0.f);   // (.z: view-space depth, for diagnostics)
+                } else asm volatile("" ::"v"(col[0]), "v"(col[1]), "v"(col[2]));
+            }
+        }
+        a.radii[idx] = radius_out;
+        if (a.visible) a.visible[idx] = radius_out > 0 ? 1 : 0;
+    }
+    PRE_TR(4);   // record stores (and the wave's reconvergence)
+    const unsigned long long dead = __ballot(dead_colour);
+    if (counting) {
+        count_finish(dead);
+        if (total > 64u * kCountUnroll) {   // (rare: more than 256 instances in a wave) the remaining passes, one behind the other
+            for (uint32_t b0 = 64 * kCountUnroll; b0 < total; b0 += 64 * kCountUnroll) {   // wave-uniform trip count
+                count_issue(b0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                count_finish(dead);
             }
         }
     }
-    asm volatile("" ::"v"(sh_touch));   // (the early line touches: consumed here, so nothing above waited for them)
+    PRE_TR(10);
+    PRE_TR_STORE();
     // num_rendered in reference semantics: per-workgroup partial sums, added up by k_tile_totals (a single
     // counter would serialise one device-scope atomic per wave, ~11 ns each)
     __shared__ uint32_t s_ref[4];
@@ -747,7 +926,7 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
-    pre_lds = (kPreWG / 64) * (size_t)kCountLdsBytes;
+    pre_lds = (kPreWG / 64) * (size_t)pre_wave_lds_bytes(prm.M * 3);
     tot.v = v, tot.T = T, tot.capacity = c.cap, tot.block_ref_tiles = g.block_ref_tiles;
     tot.n_blocks = (uint32_t)((P + kPreWG - 1) / kPreWG);
     f.h = h, f.prm = c.prm, f.in = c.in, f.g = g, f.v = v, f.b = b, f.out_color = c.out_color;
