@@ -61,7 +61,8 @@ def test_no_kernel_uses_scratch_or_flat_accesses(tmp_path):
     for k, v in sorted(ours.items()):
         assert v.get("private_segment_fixed_size") == "0" and v.get("uses_dynamic_stack") == "false", (k, v)
         assert "bad" not in v, (k, v["bad"][:4])
-    # register budgets the occupancy of the per-Gaussian forward kernel depends on (five waves per SIMD)
+    # register budget the occupancy of the per-Gaussian forward kernel depends on: three waves per SIMD, which is what its
+    # LDS (the wave's 12 KB SH block) allows — the thread's SH row is held in 48 registers across the counting pass
     for k, v in ours.items():
         if "k_preprocess_fwd" in k:
-            assert int(v["vgpr_count"]) <= 96, (k, v["vgpr_count"])
+            assert int(v["vgpr_count"]) <= 168, (k, v["vgpr_count"])
