@@ -104,9 +104,12 @@ __device__ __forceinline__ float sh_channel(const float* sh, int c, int deg, flo
 
 // d(colour of channel c) / d(direction): the expressions of the reference's SH backward (backward.cu:44-133), evaluated
 // HERE, in the forward, where the coefficients are staged in LDS anyway (GeomView::dcolor_ddir).
+// (Not part of the forward state the tests hold bit-exact — it only feeds dL/dmeans3D in the backward, which is compared at
+// 1e-4 — so its multiply-adds may contract: 120 instructions per wave less than with the file's -ffp-contract=off.)
 __device__ __forceinline__ void sh_dchannel_ddir(const float* sh, int c, int deg, float x, float y, float z, float& ddx, float& ddy,
                                                  float& ddz)
 {
+#pragma clang fp contract(fast)
 #define SH(k) sh[(k) * 3 + c]
     ddx = ddy = ddz = 0.f;
     if (deg > 0) {
@@ -507,7 +510,13 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
                 const uint2 rr = s_rect[lo];
                 const uint32_t j = k - s_excl[lo];
                 const uint32_t x0 = rr.x & 0xffff, y0 = rr.x >> 16, rw = (rr.y & 0xffff) - x0;
-                const uint32_t ty = y0 + j / rw, tx = x0 + (j - (j / rw) * rw);
+                // j / rw and the remainder through a float reciprocal and one correction either way (j < 2^24: exact in
+                // float; the u32 division the compiler emits is thirty instructions per candidate)
+                int qd = (int)((float)j * __builtin_amdgcn_rcpf((float)rw));
+                int rd = (int)j - qd * (int)rw;
+                if (rd < 0) qd -= 1, rd += (int)rw;
+                if (rd >= (int)rw) qd += 1, rd -= (int)rw;
+                const uint32_t ty = y0 + (uint32_t)qd, tx = x0 + (uint32_t)rd;
                 // a one-tile-wide or one-tile-high rectangle is touched everywhere (the footprint is connected and
                 // reaches both ends of its bounding box); only wider ones can miss a corner tile
                 const uint32_t rh = (rr.y >> 16) - y0;

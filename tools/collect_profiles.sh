@@ -12,6 +12,7 @@ cp $O/${tag}_coherent_order.txt profiles/${name}_coherent_order.txt
 cp $O/${tag}_cpu_baseline.txt profiles/${name}_cpu_baseline.txt
 [ -f $O/${tag}_bwd_stats.txt ] && cp $O/${tag}_bwd_stats.txt profiles/${name}_bwd_stats.txt
 [ -f $O/${tag}_bwd_phases.txt ] && cp $O/${tag}_bwd_phases.txt profiles/${name}_bwd_phases.txt
+[ -f $O/${tag}_pre_phases.txt ] && cp $O/${tag}_pre_phases.txt profiles/${name}_pre_phases.txt
 cp $O/${tag}_eager/kernels.txt profiles/${name}_kernel_stats_bench_eager.txt
 cp $O/${tag}_graph/kernels.txt profiles/${name}_kernel_stats_bench_graph.txt
 cp $O/${tag}_graph3/kernels.txt profiles/${name}_kernel_stats_bench_graph_3_in_flight.txt

@@ -8,16 +8,18 @@ from tests.test_gpu_avatar import _setup, _targets
 from fateavatar_amd.avatar import AvatarStep
 from fateavatar_amd import rasterizer
 dev = torch.device("cuda:0")
-S = _setup(dev, 100_000, 512, 16)
 bg = torch.ones(3, device=dev)
-gts = _targets(S, dev, bg)
-st = AvatarStep(S["make"](), S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=False)
-for steps in (1, 3, 60):
-    for it in range(steps):
-        st.step(S["cams"][it % 16], S["posed"][it % 16], gts[it % 16])
-    torch.cuda.synchronize()
-    c = rasterizer.last_counts[0]
-    pc = st.pc
-    print(f"after {st.adam.step_count} steps: num_rendered {c.num_rendered} instances {c.num_instances} max_list {c.max_tile_list}; "
-          f"opacity mean {float(torch.sigmoid(pc._opacity).mean()):.3f} scale mean {float(torch.exp(pc._scaling).mean()):.2e} "
-          f"max {float(torch.exp(pc._scaling).max()):.2e}")
+for P, order in ((100_000, "random"), (100_000, "uv"), (256 * 256, "uv")):     # (uv: the reference's own initialisation)
+    S = _setup(dev, P, 512, 16, order=order)
+    gts = _targets(S, dev, bg)
+    st = AvatarStep(S["make"](), S["faces"], S["canon"], S["cams"][0].clone(), bg, use_graph=False)
+    print(f"== P {P} binding points: {order}; scale_init {np.exp(S['scale_init']):.3e}")
+    for steps in (1, 3, 60):
+        for it in range(steps):
+            st.step(S["cams"][it % 16], S["posed"][it % 16], gts[it % 16])
+        torch.cuda.synchronize()
+        c = rasterizer.last_counts[0]
+        pc = st.pc
+        print(f"after {st.adam.step_count} steps: num_rendered {c.num_rendered} instances {c.num_instances} max_list {c.max_tile_list}; "
+              f"opacity mean {float(torch.sigmoid(pc._opacity).mean()):.3f} scale mean {float(torch.exp(pc._scaling).mean()):.2e} "
+              f"max {float(torch.exp(pc._scaling).max()):.2e}")

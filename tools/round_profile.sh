@@ -35,4 +35,5 @@ python $R/tools/probe_coherent.py > $O/${tag}_coherent_order.txt 2>/dev/null
 python $R/tools/cpu_baseline.py > $O/${tag}_cpu_baseline.txt 2>/dev/null
 bash $R/tools/diag/bwd_stats.sh > $O/${tag}_bwd_stats.txt 2>/dev/null
 FR_HIP_LIB=$R/.ab/libfr_trace.so python $R/tools/diag/bwd_phases.py > $O/${tag}_bwd_phases.txt 2>/dev/null
+{ for a in "" "--P 500000 --res 1024"; do echo "== tools/diag/pre_phases.py $a"; FR_HIP_LIB=$R/.ab/libfr_pretrace.so python $R/tools/diag/pre_phases.py $a 2>/dev/null | tail -17; done; } > $O/${tag}_pre_phases.txt
 ls $O | grep $tag
