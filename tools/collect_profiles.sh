@@ -3,7 +3,7 @@
 #   gpurun_out/<tag>_* -> profiles/<name>_* (the committed evidence set) + profiles/blend_bwd_counters.json
 tag=$1; name=$2; O=gpurun_out
 for f in bench bench_2ranks_gloo_1gpu bench_config5 bench_dense bench_one_at_a_time bench_opaque bench_exchange_at_1 \
-         train_step train_step_fateavatar train_step_fateavatar_batch3 train_step_fateavatar_batch4 train_step_fateavatar_batch4_lanes \
+         train_step train_step_fateavatar train_step_fateavatar_tex256 train_step_fateavatar_tex256_batch4 train_step_fateavatar_batch3 train_step_fateavatar_batch4 train_step_fateavatar_batch4_lanes \
          train_step_fateavatar_binding_op train_step_fateavatar_batch4_binding_op \
          train_step_fateavatar_random_order train_step_fateavatar_batch4_random_order; do
   [ -f $O/${tag}_$f.json ] && grep '^{' $O/${tag}_$f.json | tail -1 > profiles/${name}_$f.json

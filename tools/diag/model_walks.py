@@ -135,3 +135,24 @@ for K, wide_cost in ((32, 1.0), (32, 1.5), (16, 1.5), (8, 1.5)):
                 cost += wide_cost
         total += cost
     print(f"(6) wide tail once <= {K} pixels are left, a wide step charged {wide_cost} trips: phase-A cost {total / now_total:.3f} of now")
+
+# (7) the SIMPLE wide tail (round 6): once few pixels are left, lane = record finishes ONE pixel's remaining records per step (every
+# lane evaluates its own record's alpha for that pixel, the T / accum recurrences as prefix products over the lanes): a step costs
+# `c` normal trips per pixel whatever it has left; taken when active * c < ceil(deepest / 2)
+for c in (0.6, 0.8, 1.0):
+    total, costs = 0.0, []
+    for u in range(U):
+        left = np.sort(per_pixel[u])[::-1].astype(np.int64).copy()
+        cost = 0.0
+        while left[0] > 0:
+            active = int((left > 0).sum())
+            if active * c < np.ceil(left[0] / 2.0):
+                cost += active * c
+                break
+            left = np.maximum(left - 2, 0)
+            cost += 1.0
+        total += cost
+        costs.append(cost)
+    costs = np.asarray(costs)
+    print(f"(7) record-wide finish at {c} trips per pixel: phase-A cost {total / now_total:.3f} of now; deepest unit {costs.max():.1f} trips "
+          f"(now {A_now.max():.1f}), p99 {np.percentile(costs, 99):.1f} ({np.percentile(A_now, 99):.1f}), p90 {np.percentile(costs, 90):.1f} ({np.percentile(A_now, 90):.1f})")

@@ -11,6 +11,9 @@ python $R/bench.py --scale 3e-3 --opacity 0.3 --steps 100 --no-dp-reference --cp
 python $R/tools/train_synthetic.py > $O/${tag}_train_step.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar > $O/${tag}_train_step_fateavatar.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 > $O/${tag}_train_step_fateavatar_batch4.json 2>> $O/${tag}_bench.err
+# the reference's own size: tex_size 256 -> 65 536 Gaussians (config/fateavatar.yaml:28)
+python $R/tools/train_synthetic.py --fateavatar --P 65536 > $O/${tag}_train_step_fateavatar_tex256.json 2>> $O/${tag}_bench.err
+python $R/tools/train_synthetic.py --fateavatar --P 65536 --views-per-step 4 > $O/${tag}_train_step_fateavatar_tex256_batch4.json 2>> $O/${tag}_bench.err
 python $R/tools/train_synthetic.py --fateavatar --views-per-step 4 --lanes > $O/${tag}_train_step_fateavatar_batch4_lanes.json 2>> $O/${tag}_bench.err
 # the same two steps with the binding as its own kernels (the A/B of fr_aux::binding), and the steps' timelines
 python $R/tools/train_synthetic.py --fateavatar --binding-op > $O/${tag}_train_step_fateavatar_binding_op.json 2>> $O/${tag}_bench.err
