@@ -481,7 +481,7 @@ def test_overflow_inside_the_captured_step_skips_the_update(gpu_device):
         "assert c.overflow and c.num_instances > cap_now, (c.overflow, c.num_instances, cap_now)\n"
         "assert float(pc.overflow_word) == 1.0\n"
         "assert torch.equal(pc.flat, flat0) and torch.equal(ts.adam.exp_avg, m0) and torch.equal(ts.adam.exp_avg_sq, v0)\n"
-        "assert ts.adam.step_count == 5\n"
+        "assert ts.adam.step_count == 5 and ts.host_steps == 6 and ts.skipped_steps == 1   # (the host-side schedules saw six steps)\n"
         "with warnings.catch_warnings(record=True) as w:\n"
         "    warnings.simplefilter('always')\n"
         "    ts.step(cam, gt)                          # the host sees the counts: eager, larger capacity, a normal step\n"
@@ -491,7 +491,7 @@ def test_overflow_inside_the_captured_step_skips_the_update(gpu_device):
         "for _ in range(4):\n"
         "    ts.step(cam, gt)\n"
         "torch.cuda.synchronize(); ts.check()\n"
-        "assert ts.adam.step_count == 10 and ts._graph is not None and ts.overflows == 1\n"
+        "assert ts.adam.step_count == 10 and ts._graph is not None and ts.overflows == 1 and ts.skipped_steps == 1\n"
         "print('gated-ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert "gated-ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])

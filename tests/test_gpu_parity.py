@@ -464,6 +464,40 @@ def test_fused_visibility_mask_and_densification_stats(gpu_device):
     assert torch.allclose(accum, ref_accum, rtol=1e-5, atol=0.0) and float(accum.max()) > 0
 
 
+def test_views_of_a_batch_must_not_share_an_overflow_word(gpu_device):
+    """fr_aux::overflow_out is overwritten (0 or 1) by every backward: two views of ONE batched launch that shared the word
+    would race, and a view that did not overflow could clear the flag of one that did.  The batched backward refuses a
+    shared word; a word per view (or none) is fine."""
+    import torch
+    from fateavatar_amd.model import FlatGaussians, TorchCamera
+    from fateavatar_amd.render import render_batch
+    P = 2000
+    s = [scenes.head_scene(P=P, res=96, sh_degree=1, seed=2, view=v, n_views=2) for v in range(2)]
+    cams = [TorchCamera(x.camera, gpu_device) for x in s]
+    bg = torch.from_numpy(s[0].bg).to(gpu_device)
+    w = torch.ones((3, 96, 96), device=gpu_device) / (3 * 96 * 96)
+
+    def holders(words):
+        out = []
+        for k in range(2):
+            pc = FlatGaussians(s[0].means3D, s[0].shs, s[0].opacities, s[0].scales, s[0].rotations, 1, gpu_device)
+            pc.fused_densification_stats = (torch.zeros((P, 1), device=gpu_device), torch.zeros((P, 1), device=gpu_device), words[k])
+            out.append(pc)
+        return out
+
+    shared = torch.zeros(1, device=gpu_device)
+    outs = render_batch(cams, holders([shared, shared]), bg)
+    with pytest.raises(RuntimeError, match="ONE overflow word EACH"):
+        torch.autograd.backward([o["render"] for o in outs], grad_tensors=[w, w])
+    own = [torch.zeros(1, device=gpu_device), torch.zeros(1, device=gpu_device)]
+    pcs = holders(own)
+    outs = render_batch(cams, pcs, bg)
+    torch.autograd.backward([o["render"] for o in outs], grad_tensors=[w, w])
+    torch.cuda.synchronize()
+    assert float(own[0]) == 0.0 and float(own[1]) == 0.0
+    assert all(float(pc.fused_densification_stats[1].max()) == 1.0 for pc in pcs)
+
+
 def test_fused_activations_match_torch_activations(gpu_device):
     """render() with raw parameters + in-kernel sigmoid/exp/normalize == render() with PyTorch activations
     (which the oracle tests pin), forward and every raw-parameter gradient."""
