@@ -596,7 +596,10 @@ __device__ __forceinline__ UnitInfo unit_info(const uint4 d, int W, int H, int l
     return i;
 }
 
-constexpr int kWavesPerWG = 4;   // the unit kernels run 4 independent waves per workgroup (workgroup dispatch rate, not work,
+#ifndef FR_UNIT_WAVES
+#define FR_UNIT_WAVES 4
+#endif
+constexpr int kWavesPerWG = FR_UNIT_WAVES;   // the unit kernels run 4 independent waves per workgroup (workgroup dispatch rate, not work,
                                  // bounded the one-wave-per-workgroup version)
 
 // ------------------------------------------------------------------ blend backward

@@ -708,9 +708,12 @@ struct TotalsArgs {
 };
 
 #ifndef FR_TOT_WAVES
-#define FR_TOT_WAVES 4
+#define FR_TOT_WAVES 1
 #endif
-constexpr int kTotWaves = FR_TOT_WAVES;   // waves per workgroup of k_tile_totals: 1 024 tiles per workgroup (16 waves = one workgroup for 512 x 512, no cursor atomics, was measured: 11.4 against 6.7 us — one workgroup is one CU)
+constexpr int kTotWaves = FR_TOT_WAVES;   // waves per workgroup of k_tile_totals: 256 tiles per wave.  Measured at 512 x 512 (4 096 tiles,
+                                          // rocprofv3, one box): 1 wave per workgroup 5.4 us, 2: 6.1, 4: 6.6, 8: 8.2, 16 (ONE workgroup, which
+                                          // then needs no cursor atomics): 11.4 — the pass is a chain of round trips per workgroup, and the
+                                          // more CUs share its loads the shorter each link
 __device__ __forceinline__ void tile_totals_body(const TotalsArgs& a)
 {
     const ImageView v = a.v;
