@@ -335,11 +335,11 @@ __device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t b
     return c->num_instances > c->capacity || c->max_bucket > bucket_cap;
 }
 
-// Grid: kMediumSorters workgroups that sort the medium lists (257..1024 keys, four waves per list, static
+// Grid: kMediumSorters workgroups that sort the medium lists (257..2048 keys, four waves per list, static
 // round-robin over the list k_tile_totals built), followed by Q = ceil(T/4) workgroups of 4 waves for the
 // short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
 // image region land in different workgroups) and sorts it in registers if it has <= 256 keys.  Lists longer
-// than 1024 are left to k_tile_sort_big.
+// than 2048 are left to k_tile_sort_big.
 #ifndef FR_MEDIUM_SORTERS
 #define FR_MEDIUM_SORTERS 1024
 #endif
@@ -375,7 +375,8 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
     uint32_t* unit_done = a.unit_done;
     float* empty_color = a.empty_color;
     const float* __restrict__ bg = a.bg;
-    __shared__ SortXchgT<4> sx;
+    __shared__ SortXchgT<8> sx8;   // (16 KB: the exchange buffer of the longest lists this kernel sorts, 2 048 keys)
+    SortXchgT<4>& sx = *reinterpret_cast<SortXchgT<4>*>(&sx8);
     const bool overflow = frame_overflow(v.counts, v.bucket_cap);
     if (blockIdx.x == 0 && threadIdx.x < 2 * kStripes) a.stripe_cursor[threadIdx.x * kStripeWords] = 0u;   // (BwdUnit list cursors)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -394,7 +395,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
     // longest jobs first in dispatch order: medium lists, then the short ones
     if (blockIdx.x < kMediumSorters) {
         if (overflow) return;
-        // medium lists (<= 1024): four waves each, static round-robin over the list built by k_tile_totals
+        // medium lists (<= 2048): four waves each, static round-robin over the list built by k_tile_totals
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t nm = v.counts->medium_tiles;
@@ -403,9 +404,10 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
             const uint32_t tile = v.medium_list[item];
             const uint32_t n = v.tile_total[tile];
             if (n <= 512u) sort_tile_group<2>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx2);
-            else sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
+            else if (n <= 1024u) sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
+            else sort_tile_group<8>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx8);   // (<= kSortGroupMax = 2 048)
         }
-        // Lists longer than 1024 normally go to k_tile_sort_big.  When the host has not launched it (the previous
+        // Lists longer than 2048 normally go to k_tile_sort_big.  When the host has not launched it (the previous
         // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
         // global-memory network — correct, just not fast; the next frame gets the big sorter back.
         if (take_long_lists) {
@@ -1713,7 +1715,7 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
     ChainArgs ca[kMaxBatch];
     uint32_t sort_blocks = 0, unit_wgs = 0, gather_blocks = 0;
     // The big sorter is only launched when the most recent frame whose counts have reached the host had a list
-    // longer than 1024 (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
+    // longer than kSortGroupMax (or none has been seen yet); otherwise k_tile_sort keeps a slow but correct path for them.
     // (A batch launches it if any of its views asks for it.)
     bool launch_big = false;
     for (int k = 0; k < n; k++) {

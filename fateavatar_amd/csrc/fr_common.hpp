@@ -25,7 +25,9 @@ constexpr uint32_t kDensePairsBwd = 1000;  // backward: the same choice inside k
 constexpr int kPreWG = FR_PRE_WG;   // threads per workgroup of k_preprocess_fwd
 constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
-constexpr int kSortGroupMax = 1024;  // longest list k_tile_sort handles (4 waves x 4 keys per lane)
+constexpr int kSortGroupMax = 2048;  // longest list k_tile_sort handles (4 waves x 8 keys per lane).  (1 024 until round 6: the reference's own
+                                     // initialisation at 100 k Gaussians has lists of 1 241 entries, and the big-list sorter on its side stream cost
+                                     // that step 20 us a frame)
 constexpr int kSortRegMax = 4096;    // longest list k_tile_sort_big sorts in registers (4 waves x 16 keys per lane);
                                      // longer ones take its global-memory fallback
 

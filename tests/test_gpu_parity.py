@@ -302,9 +302,10 @@ def test_binning_capacity_regrow(gpu_device):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("P,lo,hi", [(700, 256, 1024), (3000, 1024, 4096), (6000, 4096, 1 << 30)])
+@pytest.mark.parametrize("P,lo,hi", [(700, 256, 1024), (1400, 1024, 2048), (3000, 2048, 4096), (6000, 4096, 1 << 30)])
 def test_long_tile_lists_take_the_multi_wave_and_fallback_sorts(P, lo, hi, gpu_device):
-    """Many Gaussians on one 8x8 tile: the 4-wave register sorts (<= 1024, <= 4096 keys) and the global-memory
+    """Many Gaussians on one 8x8 tile: the 4-wave register sorts (<= 1024, <= 2048 in k_tile_sort, <= 4096 keys in the big-list
+    sorter) and the global-memory
     fallback (> 4096) must give the same blend order as the oracle (equal depths included: ties break by id)."""
     rng = np.random.default_rng(3)
     s = scenes.random_scene(P, 32, 32, sh_degree=0, seed=9, spread=0.004, scale_lo=0.002, scale_hi=0.004,
@@ -1201,7 +1202,7 @@ def test_forward_is_bit_reproducible_across_runs_and_in_flight(gpu_device, opaci
 
 
 def test_long_lists_without_the_big_sorter_launch(gpu_device):
-    """The big-list sorter is only launched when the previous frame had a list longer than 1024; a frame whose long
+    """The big-list sorter is only launched when the previous frame had a list longer than 2048; a frame whose long
     lists come as a surprise is sorted by the slow path inside k_tile_sort and must be just as correct.  Frame order:
     short lists -> long lists (slow path) -> long lists again (big sorter) -> short lists."""
     rng = np.random.default_rng(3)
@@ -1211,11 +1212,11 @@ def test_long_lists_without_the_big_sorter_launch(gpu_device):
     long_.means3D[:, 2] = 1.0 + rng.uniform(0, 0.5, long_.P).astype(np.float32)
     o_short, o_long = util.oracle_forward(short), util.oracle_forward(long_)
     h = util.HipFrame(short, gpu_device)
-    assert h.counts.max_tile_list <= 1024
+    assert h.counts.max_tile_list <= 2048
     _check_forward(o_short, h, "short-1")
     for tag in ("long-surprise", "long-again"):
         h = util.HipFrame(long_, gpu_device)
-        assert h.counts.max_tile_list > 1024
+        assert h.counts.max_tile_list > 2048
         _check_forward(o_long, h, tag)
         dpix = (rng.uniform(-1, 1, (3, 32, 32)) / (32 * 32)).astype(np.float32)
         _check_backward(o_long, h, dpix, tag)
