@@ -411,6 +411,15 @@ __device__ __forceinline__ void counters_sum(uint32_t cnt, uint32_t (&sub)[kXcds
     }
 }
 
+// a tile that does not fit: the frame's verdict for the kernels that read DeviceCounts, and bit 63 of EVERY region cursor for the
+// forward blend, whose waves read one cursor and nothing else in front of their first instruction
+constexpr unsigned long long kCursorOverflow = 1ull << 63;
+__device__ __forceinline__ void flag_overflow(const ImageView& v, int lane)
+{
+    if (lane == 0) v.counts->overflow = 1u;
+    if (lane < kRegions) __hip_atomic_fetch_or(&v.cell(lane)->cursor, kCursorOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // what every sorter does for its tile once the list has a place: the unit descriptors and the forward's hand-off words
 __device__ __forceinline__ void describe_units(const SortArgs& a, uint32_t tile, uint32_t tx, uint32_t ty, uint32_t n, uint32_t nu,
                                                uint32_t start, uint32_t u0, int lane)
@@ -470,7 +479,7 @@ __device__ __forceinline__ void sort_short_tile(const SortArgs& a, uint32_t tile
     SO_STAMP(4);   // the list's place known
     // the frame's verdict is the OR of the tiles': a key bucket that dropped keys, a region out of records or of units
     if (!(keys_ok && s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r)) {
-        if (lane == 0) v.counts->overflow = 1u;
+        flag_overflow(v, lane);
         return;
     }
     const uint32_t start = reg * a.cap_r + s_loc, u0 = reg * a.unit_cap_r + u_loc;
@@ -632,7 +641,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
                     const bool ok = s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r;
                     const uint32_t start = reg * a.cap_r + s_loc, u0 = reg * a.unit_cap_r + u_loc;
                     if (!ok) {
-                        if (ln == 0) c->overflow = 1u;
+                        flag_overflow(v, ln);
                     } else {
                         describe_units(a, tile, tx, ty, n, nu, start, u0, ln);
                         if (listed) {
@@ -676,7 +685,7 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
                 const uint32_t u_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
                 if (s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r)
                     describe_units(a, tile, tx, ty, n, nu, reg * a.cap_r + s_loc, reg * a.unit_cap_r + u_loc, ln);
-                else if (ln == 0) c->overflow = 1u;
+                else flag_overflow(v, ln);
             }
             SO_STAMPV(5, n);
             SO_STAMP(7);
@@ -1469,7 +1478,7 @@ __device__ __forceinline__ void frame_counts_final(const ChainArgs& a)
     uint32_t inst = 0, units = 0, fullest = 0, ml = 0, mb = 0;
     for (int x = 0; x < kRegions; x++) {
         const unsigned long long cur = a.v.cell(x)->cursor;
-        inst += (uint32_t)cur, units += (uint32_t)(cur >> 32);
+        inst += (uint32_t)cur, units += (uint32_t)(cur >> 32) & 0x7FFFFFFFu;
         fullest = max(fullest, (uint32_t)cur);
         ml = max(ml, a.v.cell_max(x)->max_list), mb = max(mb, a.v.cell_max(x)->max_bucket);
     }
@@ -1513,29 +1522,40 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         frame_counts_final(a);
         return;
     }
-    // unit SLOT u: slot l of region x = u / unit_cap_r is taken iff l < the units that region's cursor has handed out
-    const uint32_t u = (blockIdx.x - 1u) * kWavesPerWG + wave_in_wg;
+    // Workgroup w serves region w mod 8, slots 4 (w / 8) .. + 3 of it: slot l of a region is taken iff l < the units that region's
+    // cursor has handed out, so the workgroups with work are the FIRST ones of the launch in every region at once (region after
+    // region, the last region's units were dispatched behind two thousand empty workgroups: + 2.6 us at config 2, + 5.6 at
+    // config 5).  A unit still waits only for lower slots of its own region, i.e. for workgroups dispatched before its own.
+    const uint32_t w_blk = blockIdx.x - 1u;
+#ifndef FR_FWD_MAP
+#define FR_FWD_MAP 1
+#endif
+#if FR_FWD_MAP == 0
+    const uint32_t reg = w_blk & (uint32_t)(kRegions - 1);
+    const uint32_t u_loc = (w_blk >> kRegionsLog2) * kWavesPerWG + wave_in_wg;
+#elif FR_FWD_MAP == 1
+    // (rotated: the g-th workgroup of region r is workgroup 8 g + ((r - g) & 7), so that a region's workgroups — and a tile's
+    // units — go round the XCDs instead of all sitting on XCD r)
+    const uint32_t reg = (w_blk + (w_blk >> kRegionsLog2)) & (uint32_t)(kRegions - 1);
+    const uint32_t u_loc = (w_blk >> kRegionsLog2) * kWavesPerWG + wave_in_wg;
+#else
+    const uint32_t per_reg = (gridDim.x - 1u) / (uint32_t)kRegions;
+    const uint32_t reg = w_blk / per_reg;
+    const uint32_t u_loc = (w_blk - reg * per_reg) * kWavesPerWG + wave_in_wg;
+#endif
+    const uint32_t u = reg * a.unit_cap_r + min(u_loc, a.unit_cap_r - 1u);   // the unit's SLOT in the per-unit arrays
     // (the unit's descriptor is requested together with the cursors, not behind them: one dependent round trip less in
     // front of every wave's records; a.unit_cap descriptors exist whatever the frame holds)
-    const uint4 d_early = unit_tile[min(u, a.unit_cap - 1u)];
-    uint32_t taken[kRegions];
-#pragma unroll
-    for (int x = 0; x < kRegions; x++) taken[x] = (uint32_t)(a.v.cell(x)->cursor >> 32);
-    const uint32_t overflow = counts->overflow;
-    asm volatile("" ::"v"(d_early.x), "s"(taken[0]), "s"(taken[kRegions - 1]), "s"(overflow));
-    uint32_t reg = 0;
-#pragma unroll
-    for (int x = 1; x < kRegions; x++) reg += u >= (uint32_t)x * a.unit_cap_r ? 1u : 0u;
-    uint32_t nu_all = 0, before = 0, mine = 0;
-#pragma unroll
-    for (int x = 0; x < kRegions; x++) {
-        before += (uint32_t)x < reg ? taken[x] : 0u;
-        mine = (uint32_t)x == reg ? taken[x] : mine;
-        nu_all += taken[x];
-    }
-    const uint32_t u_loc = u - reg * a.unit_cap_r;
-    if (overflow || u >= a.unit_cap || u_loc >= mine) return;
-    const uint32_t ud = before + u_loc;   // the unit's DENSE index, 0 .. nu_all - 1 (the backward's work list is dense)
+    const uint4 d_early = unit_tile[u];
+    // ONE cursor in front of the wave's first instruction: the units its region has handed out, and the frame's verdict (bit 63)
+    const unsigned long long cur = a.v.cell((int)reg)->cursor;
+    // ... the other regions' counts (the unit's DENSE index, for the backward's work list) are not needed before the local walk is
+    // done: requested here by the first eight lanes, read there
+    uint32_t taken_l = 0;
+    if (lane < kRegions) taken_l = (uint32_t)(a.v.cell(lane)->cursor >> 32) & 0x7FFFFFFFu;
+    asm volatile("" ::"v"(d_early.x), "v"(taken_l), "s"(cur));
+    const uint32_t mine = (uint32_t)(cur >> 32) & 0x7FFFFFFFu;
+    if ((cur & kCursorOverflow) || u_loc >= mine) return;   // (mine <= unit_cap_r)
     FW_STAMP(0);
     FW_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     const TransposeConsts tc = transpose_consts(lane);
@@ -1573,6 +1593,13 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     if (ui.base + kUnit < ui.n)   // (nobody reads the last unit's product)
         __hip_atomic_store(g_tseg + (size_t)u * kUnit + lane, fmaxf(o.T, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the unit's place in the backward's work list (BwdUnit): long walks from the front of its stripe, the others from the back
+    uint32_t nu_all = 0, ud = u_loc;   // the unit's DENSE index, 0 .. nu_all - 1 (the backward's work list is dense)
+#pragma unroll
+    for (int x = 0; x < kRegions; x++) {
+        const uint32_t tx_ = (uint32_t)__builtin_amdgcn_readlane((int)taken_l, x);
+        ud += (uint32_t)x < reg ? tx_ : 0u;
+        nu_all += tx_;
+    }
     if (lane == 0) {
         const bool heavy = npairs >= a.heavy_pairs;
         // Which stripe?  Stripe j holds slots j, j + 64, ...: n_j = ceil((nu - j) / 64) of them, and the hardware runs
@@ -2036,7 +2063,7 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         const uint32_t small_blocks = (T + 3) / 4;
         sort_blocks = max(sort_blocks, small_blocks + kGroupSorters);
         // (one workgroup in front of the unit slots makes the frame's counts final: frame_counts_final)
-        unit_wgs = max(unit_wgs, (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG) + 1u);
+        unit_wgs = max(unit_wgs, (uint32_t)kRegions * (uint32_t)((b.unit_cap_r + kWavesPerWG - 1) / kWavesPerWG) + 1u);
         gather_blocks = max(gather_blocks, (T + kWavesPerWG - 1) / kWavesPerWG);
         SortArgs& a = sa[k];
         a.v = v, a.T = T, a.Q = small_blocks, a.keys = (u64*)b.keys, a.ids = b.ids, a.unit_tile = b.unit_tile;

@@ -111,7 +111,11 @@ struct GeomView {
 // to region (tx + 3 ty) & 7 (neighbouring tiles in different regions: a head-sized blob fills the regions to within 3 %), and a
 // cursor word packs (instances taken, units taken << 32).  No scan, no allocation launch: a tile needs nothing but its own
 // eight counters.  A single cursor would serialise one same-address atomic per non-empty tile (11 - 13 ns each).
-constexpr int kRegions = 8;
+#ifndef FR_REGIONS_LOG2
+#define FR_REGIONS_LOG2 3
+#endif
+constexpr int kRegionsLog2 = FR_REGIONS_LOG2;
+constexpr int kRegions = 1 << kRegionsLog2;
 struct RegionCell {
     unsigned long long cursor;   // (instances allocated) | (units allocated) << 32
 };

@@ -25,6 +25,8 @@ L.fr_debug_read_fwd_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert L.fr_debug_read_fwd_trace(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(16384, 16).astype(np.int64)
 work = t[:, 5] > 0
+# (units are traced by SLOT, and the slots a frame uses differ from frame to frame: keep the stamps of the last launch only)
+work &= t[:, 8] > t[work, 8].max() - 20000
 w = t[work]
 last = w[:, 7] > 0
 print(f"units {work.sum()}, of which last units of their tile (gatherers) {last.sum()}; instances {f2.counts.num_instances}")
@@ -48,3 +50,7 @@ for i in np.argsort(-ext)[:8]:
           f"pairs {w[i, 9]}, list {w[i, 10]}, segment {w[i, 11]}")
 nseg = (w[:, 10] + 63) // 64
 print("units by list length (units per tile): " + ", ".join(f"{k}: {int((nseg == k).sum())}" for k in sorted(set(nseg.tolist()))[:12]))
+idx = np.nonzero(work)[0]
+late = ent > 1.5
+print(f"late entries (> 1.5 us): {late.sum()}; slots {idx[late][:24].tolist()}; entry us {np.round(ent[late][:24], 2).tolist()}")
+print("entry time by slot decile:", [round(float(np.mean(ent[(idx >= np.percentile(idx, q)) & (idx <= np.percentile(idx, q + 10))])), 2) for q in range(0, 100, 10)])
