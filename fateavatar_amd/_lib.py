@@ -70,7 +70,7 @@ class fr_grads(C.Structure):
 
 class fr_counts(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("num_instances", C.c_uint32), ("max_tile_list", C.c_uint32),
-                ("overflow", C.c_uint32), ("capacity_required", C.c_uint32)]
+                ("overflow", C.c_uint32)]
 
 
 EXPORTS = ["fr_create", "fr_destroy", "fr_last_error", "fr_version", "fr_profile_enable", "fr_profile_read", "fr_geometry_bytes", "fr_image_bytes",

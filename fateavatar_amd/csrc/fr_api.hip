@@ -127,6 +127,9 @@ int fr_create(fr_handle** out)
     FR_HIP(hipEventCreateWithFlags(&h->counts_ready, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->frame_done, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&h->bwd_done, hipEventDisableTiming));
+    FR_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
     const char* bf = getenv("FR_BLEND_FWD");
     h->gather_in_chain = !(bf && strcmp(bf, "gather") == 0);
     const char* pf = getenv("FR_DENSE_PAIRS_FWD");
@@ -148,6 +151,9 @@ int fr_destroy(fr_handle* hh)
     (void)hipEventDestroy(h->counts_ready);
     if (h->frame_done) (void)hipEventDestroy(h->frame_done);
     if (h->bwd_done) (void)hipEventDestroy(h->bwd_done);
+    if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+    if (h->side_join) (void)hipEventDestroy(h->side_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     for (int st = 0; st < ST_COUNT; st++)
         for (size_t i = 0; i < h->ev[st].start.size(); i++) {
             (void)hipEventDestroy(h->ev[st].start[i]);
@@ -192,7 +198,7 @@ size_t fr_image_bytes(int32_t W, int32_t H) { return ImageView::bytes(W, H); }
 size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H)
 {
     ImageView v = ImageView::make(nullptr, W, H);
-    return BinningView::bytes((size_t)capacity, (size_t)v.tiles_x, (size_t)v.tiles_y);
+    return BinningView::bytes((size_t)capacity, (size_t)v.tiles_x * v.tiles_y);
 }
 
 int fr_forward(fr_handle* hh, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
@@ -241,7 +247,7 @@ int fr_read_counts(fr_handle* hh, fr_counts* counts)
     *counts = *h->host_counts;
     // (valid once the frame's stream has been synchronised: the caller's responsibility.)  A handle driven only with
     // FR_FLAG_NO_WAIT learns here that the pinned slot holds a completed frame's counts: the next eager frame sizes the
-    // key buckets from them (word kHostMaxBucket) and decides about the big-list sorter.
+    // key buckets from them (word 4) and decides about the big-list sorter.
     h->counts_seen = true;
     return FR_OK;
 }

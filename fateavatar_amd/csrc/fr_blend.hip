@@ -328,39 +328,22 @@ __device__ void sort_tile_global(const KeySrc& src, u64* keys, uint32_t* ids, ui
     }
 }
 
-// inclusive prefix sum over the 64 lanes with DPP only (no LDS round trips): shifts inside the 16-lane rows, then the
-// row totals broadcast into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+// The frame's verdict, from the cursors k_tile_totals left: too many instances for the record capacity, or a
+// (tile, XCD) list longer than its key bucket.
+__device__ __forceinline__ bool frame_overflow(const DeviceCounts* c, uint32_t bucket_cap)
 {
-#define FR_DPP_SHR_ADD(CTRL, ROWS) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (CTRL), (ROWS), 0xF, false)
-    FR_DPP_SHR_ADD(0x111, 0xF);  // row_shr:1
-    FR_DPP_SHR_ADD(0x112, 0xF);  // row_shr:2
-    FR_DPP_SHR_ADD(0x114, 0xF);  // row_shr:4
-    FR_DPP_SHR_ADD(0x118, 0xF);  // row_shr:8
-    FR_DPP_SHR_ADD(0x142, 0xA);  // row_bcast:15
-    FR_DPP_SHR_ADD(0x143, 0xC);  // row_bcast:31
-#undef FR_DPP_SHR_ADD
-    return x;
+    return c->num_instances > c->capacity || c->max_bucket > bucket_cap;
 }
 
-// ------------------------------------------------------------------ per-tile sort, self-allocating
-// No totals pass, no scan, no allocation launch: a tile's sorter adds up the tile's eight per-XCD counters itself (and leaves
-// them zeroed for the next frame), takes the tile's record and unit ranges from its region's cursor with ONE returning atomic
-// that is in flight while the keys are gathered and sorted in registers, and writes the sorted ids, the unit descriptors and
-// the hand-off words.  Nothing a tile's sorter needs depends on another tile (reference counterparts: InclusiveSum + the
-// blocking count read-back, rasterizer_impl.cu:277-281; SortPairs, identifyTileRanges :303-318).
-// Grid: kGroupSorters workgroups of four waves first (longest jobs first in dispatch order), then Q = ceil(T/4) workgroups
-// whose wave w OWNS tile w*Q + b (strided, so that the dense neighbouring tiles of one image region land in different
-// workgroups).  Who sorts a tile follows from its counters alone: a tile with a (tile, XCD) bucket beyond kHeavyBucket keys —
-// every list of more than 256 keys has one — belongs to the group sorters, which find these tiles in the bitmap the counting
-// pass left (ImageView::heavy_flags; static round-robin over the flagged tiles); every other tile to its owner wave, which sorts
-// its <= 256 keys alone.  Lists beyond kSortGroupMax are left to k_tile_sort_big (launched behind this kernel when the
-// previous frame had one) or, unannounced, sorted here by the global-memory network.
-#ifndef FR_GROUP_SORTERS
-#define FR_GROUP_SORTERS 1024
+// Grid: kMediumSorters workgroups that sort the medium lists (257..2048 keys, four waves per list, static
+// round-robin over the list k_tile_totals built), followed by Q = ceil(T/4) workgroups of 4 waves for the
+// short lists: wave w of workgroup b owns tile w*Q + b (strided, so that the dense neighbouring tiles of one
+// image region land in different workgroups) and sorts it in registers if it has <= 256 keys.  Lists longer
+// than 2048 are left to k_tile_sort_big.
+#ifndef FR_MEDIUM_SORTERS
+#define FR_MEDIUM_SORTERS 1024
 #endif
-constexpr uint32_t kGroupSorters = FR_GROUP_SORTERS;
-constexpr int kSortWaves = 4;
+constexpr uint32_t kMediumSorters = FR_MEDIUM_SORTERS;  // workgroups that sort the medium lists while the others sort the short ones
 
 struct SortArgs {
     ImageView v;
@@ -368,9 +351,10 @@ struct SortArgs {
     u64* keys;
     uint32_t* ids;
     uint4* unit_tile;
-    uint32_t cap_r, unit_cap_r, capacity;
+    uint32_t unit_cap;
     float* unit_tseg;
     int take_long_lists;
+    fr_counts* host_counts;
     uint32_t* unit_done;
     float* empty_color;
     const float* bg;
@@ -378,356 +362,105 @@ struct SortArgs {
     uint32_t* stripe_cursor;
 };
 
-struct SortJob {   // a group sorter's tile: wave 0 reads the counters and takes the ranges, four waves sort
-    uint32_t n, maxb, start, ok;
-    uint32_t sub[kXcds];
-};
-
-__device__ __forceinline__ KeySrc key_src_from(const ImageView& v, uint32_t tile, const uint32_t (&sub)[kXcds])
-{
-    KeySrc ks;
-    ks.base = reinterpret_cast<const u64*>(v.buckets) + (size_t)tile * kXcds * v.bucket_cap;
-    ks.cap = v.bucket_cap;
-#pragma unroll
-    for (int x = 0; x < kXcds; x++) ks.sub[x] = sub[x];
-    return ks;
-}
-
-// the tile's eight per-XCD counters: lane x reads copy x; sub[] = where each XCD's sub-list starts, n = the list's length,
-// maxb = its largest bucket.  `zero`: leave them zero for the next frame (the tile's sorter does, nobody else)
-__device__ __forceinline__ uint32_t* counter_ptr(const ImageView& v, uint32_t tx, uint32_t ty, int lane)
-{
-    return v.tile_count + (size_t)(lane & (kXcds - 1)) * v.tpad + v.counter_index(tx, ty);
-}
-__device__ __forceinline__ void counters_sum(uint32_t cnt, uint32_t (&sub)[kXcds], uint32_t& n, uint32_t& maxb)
-{
-    n = 0, maxb = 0;
-#pragma unroll
-    for (int x = 0; x < kXcds; x++) {
-        const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)cnt, x);
-        sub[x] = n;
-        n += cx;
-        maxb = max(maxb, cx);
-    }
-}
-
-// a tile that does not fit: the frame's verdict for the kernels that read DeviceCounts, and bit 63 of EVERY region cursor for the
-// forward blend, whose waves read one cursor and nothing else in front of their first instruction
-constexpr unsigned long long kCursorOverflow = 1ull << 63;
-__device__ __forceinline__ void flag_overflow(const ImageView& v, int lane)
-{
-    if (lane == 0) v.counts->overflow = 1u;
-    if (lane < kRegions) __hip_atomic_fetch_or(&v.cell(lane)->cursor, kCursorOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// what every sorter does for its tile once the list has a place: the unit descriptors and the forward's hand-off words
-__device__ __forceinline__ void describe_units(const SortArgs& a, uint32_t tile, uint32_t tx, uint32_t ty, uint32_t n, uint32_t nu,
-                                               uint32_t start, uint32_t u0, int lane)
-{
-    if (lane == 0) a.v.tile_offset[tile] = start, a.v.unit_offset[tile] = u0;
-    // descriptors of the tile's blend units (tile position, segment, list start, list length): one coalesced store
-    for (uint32_t k = (uint32_t)lane; k < nu; k += 64) a.unit_tile[u0 + k] = make_uint4(ty << 16 | tx, k, start, n);
-    // hand-off words of k_unit_blend_chained: a unit's per-pixel product is valid once it is non-zero
-    if (a.unit_tseg)
-        for (uint32_t k = 0; k + 1 < nu; k++) a.unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
-    if (a.unit_done)
-        for (uint32_t k = (uint32_t)lane; k < nu; k += 64) a.unit_done[u0 + k] = 0u;
-}
-
-// the longest list / largest bucket of the frame: nothing returns, nobody waits.  (Reading the cell first, to skip the atomic when
-// the value is beaten already, put a load from a line under atomic fire in front of every sorter's first instruction: + 2 us.)
-__device__ __forceinline__ void report_max(uint32_t* cell_word, uint32_t mine, int lane)
-{
-    if (lane == 0 && mine) atomicMax(cell_word, mine);
-}
-
-// <= 256 keys by one wave: keys requested, THEN the allocation atomic (loads and returning atomics come back in issue order:
-// the keys must not queue behind it), the sort while it is in flight, then the list's place, its units and the ids
-__device__ __forceinline__ void sort_short_tile(const SortArgs& a, uint32_t tile, uint32_t tx, uint32_t ty, uint32_t n,
-                                                const uint32_t (&sub)[kXcds], bool keys_ok, int lane, int wave = 0)
-{
-    const ImageView& v = a.v;
-    const uint32_t nu = (n + kUnit - 1) / kUnit, reg = region_of(tx, ty);
-    const KeySrc ks = key_src_from(v, tile, sub);
-    u64 kv[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-    if (keys_ok) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = (uint32_t)(r * 64 + lane);
-            if (i < n) kv[r] = ks.key(i);
-        }
-    }
-    asm volatile("" ::: "memory");
-    unsigned long long old = 0;
-    if (lane == 0)
-        old = __hip_atomic_fetch_add(&v.cell((int)reg)->cursor, (unsigned long long)n | ((unsigned long long)nu << 32), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::: "memory");
-#ifdef FR_DIAG_SORT_TRACE
-    asm volatile("" ::"v"(kv[0]), "v"(kv[1]), "v"(kv[2]), "v"(kv[3]));
-    SO_STAMP(2);   // keys here
-#endif
-    if (n <= 64) { u64 t[1] = {kv[0]}; wave_sort<1>(t, lane); kv[0] = t[0]; }
-    else if (n <= 128) { u64 t[2] = {kv[0], kv[1]}; wave_sort<2>(t, lane); kv[0] = t[0], kv[1] = t[1]; }
-    else wave_sort<4>(kv, lane);
-#ifdef FR_DIAG_SORT_TRACE
-    asm volatile("" ::"v"(kv[0]), "v"(kv[1]), "v"(kv[2]), "v"(kv[3]));
-    SO_STAMP(3);   // sorted
-#endif
-    const uint32_t s_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
-    const uint32_t u_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
-    SO_STAMP(4);   // the list's place known
-    // the frame's verdict is the OR of the tiles': a key bucket that dropped keys, a region out of records or of units
-    if (!(keys_ok && s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r)) {
-        flag_overflow(v, lane);
-        return;
-    }
-    const uint32_t start = reg * a.cap_r + s_loc, u0 = reg * a.unit_cap_r + u_loc;
-    describe_units(a, tile, tx, ty, n, nu, start, u0, lane);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t i = (uint32_t)(r * 64 + lane);
-        if (i < n) a.ids[start + i] = (uint32_t)kv[r];
-    }
-}
-
-// one list sorted by the four waves of a workgroup together (sort_tile_group, self-placing): every wave requests its share of
-// the keys, THEN wave 0 sends the allocation atomic (see sort_short_tile), which is in flight while the waves sort their
-// shares; wave 0 publishes the list's place in front of the network's first workgroup barrier.  Returns the atomic's result
-// (lane 0 of wave 0).
-template <int K>
-__device__ __forceinline__ unsigned long long coop_sort(const KeySrc& ks, uint32_t* ids, volatile SortJob* job, uint32_t n, int wave,
-                                                        int lane, SortXchgT<K>& sx, unsigned long long* cursor, unsigned long long amount,
-                                                        uint32_t region_start, uint32_t cap_r, uint32_t unit_cap_r)
-{
-    constexpr int KW = 64 * K;
-    u64 v[K];
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
-        v[r] = i < n ? ks.key(i) : ~0ull;
-    }
-    asm volatile("" ::: "memory");
-    unsigned long long old = 0;
-    if (wave == 0 && lane == 0) old = __hip_atomic_fetch_add(cursor, amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::: "memory");
-    wave_sort<K>(v, lane);
-    if (wave == 0 && lane == 0) {
-        const uint32_t s_loc = (uint32_t)old, u_loc = (uint32_t)(old >> 32);
-        job->start = region_start + s_loc;
-        job->ok = (s_loc + (uint32_t)amount <= cap_r && u_loc + (uint32_t)(amount >> 32) <= unit_cap_r) ? 1u : 0u;
-    }
-    cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaners_from<K, K / 2>(v);
-    lane_cleaners_from_32<K>(v, lane);
-    cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 3, (wave & 2) == 0);
-    cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaners_from<K, K / 2>(v);
-    lane_cleaners_from_32<K>(v, lane);
-    const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)job->start), ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)job->ok);
-    if (ok) write_ids<K>(ids, start, n, (uint32_t)(wave * KW), v, lane);
-    return old;
-}
-
-// the r-th flagged tile of chunk c of the heavy-tile flags (ImageView::heavy_flags; every wave of the workgroup finds the same
-// one), ~0u if the chunk has fewer: ONE 16-byte load per lane (a chunk is at most 1 024 bytes, each 0 or 1) and one wave scan
-__device__ __forceinline__ uint32_t nth_heavy_tile(const ImageView& v, uint32_t c, uint32_t r, int lane)
-{
-    const uint4* __restrict__ vec = reinterpret_cast<const uint4*>(v.heavy_flags + (size_t)c * v.flag_clen);
-    uint4 q = make_uint4(0u, 0u, 0u, 0u);
-    if ((uint32_t)lane * 16u < v.flag_clen) q = vec[lane];
-    const uint32_t pc = (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
-    const uint32_t incl = wave_incl_scan_u32(pc);
-    if (r >= (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)) return ~0u;
-    const int J = (int)__builtin_ctzll(__ballot(incl > r));   // the first lane whose running count passes r
-    uint32_t k = r - (uint32_t)__builtin_amdgcn_readlane((int)(incl - pc), J);
-    const uint32_t w[4] = {(uint32_t)__builtin_amdgcn_readlane((int)q.x, J), (uint32_t)__builtin_amdgcn_readlane((int)q.y, J),
-                           (uint32_t)__builtin_amdgcn_readlane((int)q.z, J), (uint32_t)__builtin_amdgcn_readlane((int)q.w, J)};
-    uint32_t byte = 0;
-    for (uint32_t bq = 0; bq < 16u; bq++) {
-        const uint32_t f = (w[bq >> 2] >> (8u * (bq & 3u))) & 1u;
-        if (f && k == 0u) { byte = bq; break; }
-        k -= f;
-    }
-    return (((uint32_t)J * 16u + byte) << v.flag_lg) | c;   // (position p of chunk c is tile p * 2^flag_lg + c)
-}
-
 __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
 {
     const ImageView v = a.v;
-    const uint32_t T = a.T, Q = a.Q;
-    DeviceCounts* c = v.counts;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockIdx.x < kGroupSorters) {
-        // ================= the tiles of the bitmap: four waves per list
-        __shared__ SortXchgT<8> sx8;   // (16 KB: the exchange buffer of the longest lists this kernel sorts, 2 048 keys)
-        __shared__ SortJob s_job;
-        SortXchgT<4>& sx = *reinterpret_cast<SortXchgT<4>*>(&sx8);
-        SortXchgT<2>& sx2 = *reinterpret_cast<SortXchgT<2>*>(&sx8);   // (lists up to 512: half the network)
-        if (blockIdx.x == 0 && threadIdx.x < 2 * kStripes) a.stripe_cursor[threadIdx.x * kStripeWords] = 0u;   // (BwdUnit list cursors)
-        if (blockIdx.x == 0 && threadIdx.x == 0) c->capacity = a.capacity;
-        // workgroup g serves chunk g mod 2^flag_lg of the flags: its flagged tiles number g / 2^flag_lg, + kGroupSorters / 2^flag_lg ...
-        // (static round-robin inside the chunk; the chunks interleave the image, so they hold about the same number of them)
-        const uint32_t n_chunks = 1u << v.flag_lg;
-        uint32_t chunk = blockIdx.x & (n_chunks - 1u), rank = blockIdx.x >> v.flag_lg;
-        const uint32_t rank_step = max(kGroupSorters >> v.flag_lg, 1u);
-        for (bool first = true;; first = false) {
-            // (the lane and the wave index are laundered once per item: otherwise every lane-dependent address and predicate of
-            // the three networks below is hoisted out of this loop and kept in registers for its whole life — thirty VGPRs and
-            // enough SGPR pairs to spill — for a loop that normally runs once)
-            int ln = lane, wv = wave;
-            asm volatile("" : "+v"(ln), "+s"(wv));
-            if (first) SO_STAMP(0);
-            uint32_t tile = nth_heavy_tile(v, chunk, rank, ln);
-            rank += rank_step;
-            if (first) SO_STAMP(1);   // flags searched
-            if (tile == ~0u) {   // (workgroup-uniform) this chunk is done; more chunks than group sorters: on to the next one of ours
-                chunk += kGroupSorters;
-                if (chunk >= n_chunks) return;
-                rank = 0;
-                continue;
-            }
-            if (tile >= T) continue;   // (cannot happen: no flag is ever stored beyond T)
-            const uint32_t tx = tile % (uint32_t)v.tiles_x, ty = tile / (uint32_t)v.tiles_x;
-            const uint32_t reg = region_of(tx, ty);
-            RegionCell* cell = v.cell((int)reg);
-            // wv 0 reads the counters (and zeroes them), everybody gets them through LDS
-            uint32_t n = 0, maxb = 0, sub[kXcds];
-            if (wv == 0) {
-                uint32_t cnt = 0;
-                uint32_t* p = counter_ptr(v, tx, ty, ln);
-                if (ln < kXcds) cnt = *p;
-                if (ln < kXcds && cnt) *p = 0u;
-                counters_sum(cnt, sub, n, maxb);
-                if (ln == 0) {
-                    volatile SortJob& j = s_job;
-                    j.n = n, j.maxb = maxb, j.start = 0u, j.ok = 0u;
-#pragma unroll
-                    for (int x = 0; x < kXcds; x++) j.sub[x] = sub[x];
-                }
-            }
-            __syncthreads();
-            {   // (wv-uniform values: back into scalar registers, or the key gather's sub-list search runs on vector ones)
-                volatile SortJob& j = s_job;
-                n = (uint32_t)__builtin_amdgcn_readfirstlane((int)j.n), maxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)j.maxb);
-#pragma unroll
-                for (int x = 0; x < kXcds; x++) sub[x] = (uint32_t)__builtin_amdgcn_readfirstlane((int)j.sub[x]);
-            }
-            const uint32_t nu = (n + kUnit - 1) / kUnit;
-            const bool keys_ok = maxb <= v.bucket_cap;   // (a bucket that overflowed dropped keys: the frame is invalid)
-            if (wv == 0) {
-                if (ln == 0 && v.tile_total) v.tile_total[tile] = n;
-                RegionMax* mx = v.cell_max((int)reg);
-                report_max(&mx->max_list, n, ln);
-                report_max(&mx->max_bucket, maxb, ln);
-            }
-            if (n <= (uint32_t)kSortWaveMax || !keys_ok) {
-                // (a heavy bucket in a list that one wv can still sort, or a frame that is invalid anyway)
-                if (wv == 0) sort_short_tile(a, tile, tx, ty, n, sub, keys_ok, ln, wv);
-                __syncthreads();   // (s_job is rewritten by the next item)
-                continue;
-            }
-            const KeySrc ks = key_src_from(v, tile, sub);
-            const bool listed = n > (uint32_t)kSortGroupMax && !a.take_long_lists;   // left to k_tile_sort_big, behind this kernel
-            if (n > (uint32_t)kSortGroupMax) {
-                unsigned long long old = 0;
-                if (wv == 0 && ln == 0)
-                    old = __hip_atomic_fetch_add(&cell->cursor, (unsigned long long)n | ((unsigned long long)nu << 32), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t s_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
-                const uint32_t u_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
-                if (wv == 0) {
-                    const bool ok = s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r;
-                    const uint32_t start = reg * a.cap_r + s_loc, u0 = reg * a.unit_cap_r + u_loc;
-                    if (!ok) {
-                        flag_overflow(v, ln);
-                    } else {
-                        describe_units(a, tile, tx, ty, n, nu, start, u0, ln);
-                        if (listed) {
-                            // the tile's sub-list table and a place in k_tile_sort_big's list
-                            if (ln < kXcds) {
-                                uint32_t mine = 0;
-#pragma unroll
-                                for (int x = 0; x < kXcds; x++) mine = ln == x ? sub[x] : mine;
-                                v.tile_sub[(size_t)tile * kSubWords + ln] = mine;
-                            }
-                            if (ln == 0) {
-                                if (n <= (uint32_t)kSortRegMax) v.big_list[atomicAdd(&c->big_tiles, 1u)] = tile;
-                                else v.large_list[atomicAdd(&c->large_tiles, 1u)] = tile;
-                            }
-                        }
-                    }
-                    if (ln == 0) {
-                        volatile SortJob& j = s_job;
-                        j.start = start, j.ok = ok && !listed ? 1u : 0u;
-                    }
-                }
-                __syncthreads();
-                // Lists longer than kSortGroupMax normally go to k_tile_sort_big.  When the host has not launched it (the
-                // previous frame had no such list: one launch less per frame) any that turn up are still sorted here, by
-                // the slow global-memory network — correct, just not fast; the next frame gets the big sorter back.
-                {
-                    volatile SortJob& j = s_job;
-                    if (j.ok) sort_tile_global(ks, a.keys, a.ids, j.start, n);
-                }
-                __syncthreads();
-                continue;
-            }
-            // 257 .. 2 048 keys: the register network over four waves
-            const unsigned long long amount = (unsigned long long)n | ((unsigned long long)nu << 32);
-            unsigned long long got;
-            if (n <= 512u) got = coop_sort<2>(ks, a.ids, &s_job, n, wv, ln, sx2, &cell->cursor, amount, reg * a.cap_r, a.cap_r, a.unit_cap_r);
-            else if (n <= 1024u) got = coop_sort<4>(ks, a.ids, &s_job, n, wv, ln, sx, &cell->cursor, amount, reg * a.cap_r, a.cap_r, a.unit_cap_r);
-            else got = coop_sort<8>(ks, a.ids, &s_job, n, wv, ln, sx8, &cell->cursor, amount, reg * a.cap_r, a.cap_r, a.unit_cap_r);
-            if (wv == 0) {
-                const uint32_t s_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
-                const uint32_t u_loc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
-                if (s_loc + n <= a.cap_r && u_loc + nu <= a.unit_cap_r)
-                    describe_units(a, tile, tx, ty, n, nu, reg * a.cap_r + s_loc, reg * a.unit_cap_r + u_loc, ln);
-                else flag_overflow(v, ln);
-            }
-            SO_STAMPV(5, n);
-            SO_STAMP(7);
-            __syncthreads();   // (s_job is rewritten by the next item)
-        }
+    const uint32_t T = a.T, Q = a.Q, unit_cap = a.unit_cap;
+    u64* keys = a.keys;
+    uint32_t* ids = a.ids;
+    uint4* unit_tile = a.unit_tile;
+    float* unit_tseg = a.unit_tseg;
+    const int take_long_lists = a.take_long_lists, W = a.W, H = a.H;
+    fr_counts* host_counts = a.host_counts;
+    uint32_t* unit_done = a.unit_done;
+    float* empty_color = a.empty_color;
+    const float* __restrict__ bg = a.bg;
+    __shared__ SortXchgT<8> sx8;   // (16 KB: the exchange buffer of the longest lists this kernel sorts, 2 048 keys)
+    SortXchgT<4>& sx = *reinterpret_cast<SortXchgT<4>*>(&sx8);
+    const bool overflow = frame_overflow(v.counts, v.bucket_cap);
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kStripes) a.stripe_cursor[threadIdx.x * kStripeWords] = 0u;   // (BwdUnit list cursors)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the frame's verdict for the later kernels, and the counts for the host (pinned memory; made visible by the
+        // end-of-kernel release; word 4 of the 64-byte slot = largest bucket need)
+        DeviceCounts* c = v.counts;
+        c->overflow = overflow ? 1u : 0u;
+        host_counts->num_rendered = c->num_rendered;
+        host_counts->num_instances = c->num_instances;
+        host_counts->max_tile_list = c->max_tile_list;
+        host_counts->overflow = overflow ? 1u : 0u;
+        reinterpret_cast<uint32_t*>(host_counts)[4] = c->max_bucket;
+        reinterpret_cast<uint32_t*>(host_counts)[5] = overflow ? 0u : c->num_units;   // (sizes the blend backward's grid)
+        if (overflow) c->num_units = 0u;   // nothing to blend
     }
-    // ================= every other tile: one wave, no workgroup barrier
-    const uint32_t b = blockIdx.x - kGroupSorters;
-    const uint32_t tile = (uint32_t)wave * Q + b;
-    if (!(b < Q && tile < T)) return;   // (a batched launch's grid is the largest view's)
-    SO_STAMP(0);
-    const uint32_t tx = tile % (uint32_t)v.tiles_x, ty = tile / (uint32_t)v.tiles_x;
-    uint32_t* p = counter_ptr(v, tx, ty, lane);
-    RegionMax* mcell = v.cell_max((int)(b & (uint32_t)(kRegions - 1)));
-    uint32_t cnt = 0;
-    if (lane < kXcds) cnt = *p;
-    // (whose tile this is comes from the flags, which do not change during this launch — the counters of a group
-    // sorter's tile may be zero already)
-    const uint32_t heavy_flag = v.heavy_flags[v.flag_index(tile)];
-    uint32_t n, maxb, sub[kXcds];
-    counters_sum(cnt, sub, n, maxb);
-    SO_STAMP(1);   // counters known
-    SO_STAMPV(5, n);
-    if (heavy_flag) return;   // a group sorter's tile (and its counters: not touched here)
-    if (lane < kXcds && cnt) *p = 0u;
-    if (lane == 0) v.tile_total[tile] = n;
-    if (n == 0) {
-        // a tile without instances has no blend unit to write its pixels (gather-in-chain mode): background here
-        if (a.empty_color) {
-            const int px = (int)tx * kTile + (lane & 7), py = (int)ty * kTile + (lane >> 3);
-            if (px < a.W && py < a.H) {
-                const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
-                v.final_T[pix] = 1.0f;
-                v.n_contrib[pix] = 0u;
-                a.empty_color[pix] = a.bg[0], a.empty_color[HW + pix] = a.bg[1], a.empty_color[2 * HW + pix] = a.bg[2];
+    // longest jobs first in dispatch order: medium lists, then the short ones
+    if (blockIdx.x < kMediumSorters) {
+        if (overflow) return;
+        // medium lists (<= 2048): four waves each, static round-robin over the list built by k_tile_totals
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t nm = v.counts->medium_tiles;
+        SortXchgT<2>& sx2 = *reinterpret_cast<SortXchgT<2>*>(&sx);   // (lists up to 512: half the network)
+        for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
+            const uint32_t tile = v.medium_list[item];
+            const uint32_t n = v.tile_total[tile];
+            if (n <= 512u) sort_tile_group<2>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx2);
+            else if (n <= 1024u) sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
+            else sort_tile_group<8>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx8);   // (<= kSortGroupMax = 2 048)
+        }
+        // Lists longer than 2048 normally go to k_tile_sort_big.  When the host has not launched it (the previous
+        // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
+        // global-memory network — correct, just not fast; the next frame gets the big sorter back.
+        if (take_long_lists) {
+            const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
+            for (uint32_t item = blockIdx.x; item < nb + nl; item += kMediumSorters) {
+                const uint32_t tile = item < nb ? v.big_list[item] : v.large_list[item - nb];
+                sort_tile_global(key_src(v, tile), keys, ids, v.tile_offset[tile], v.tile_total[tile]);
             }
         }
         return;
     }
-    report_max(&mcell->max_list, n, lane);
-    sort_short_tile(a, tile, tx, ty, n, sub, true, lane, wave);   // (n <= 8 x kHeavyBucket = kSortWaveMax, every bucket inside its capacity)
-    SO_STAMP(7);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const uint32_t tile = (uint32_t)wave * Q + (blockIdx.x - kMediumSorters);
+        if (blockIdx.x - kMediumSorters < Q && tile < T) {   // (a batched launch's grid is the largest view's)
+            // (everything the tile's wave reads before its keys — list start and length, first unit, sub-list table — in ONE
+            // round trip, together with the frame's counts: none of it sits behind a branch on another load)
+            const uint32_t start = v.tile_offset[tile];
+            const uint32_t n = v.tile_total[tile];
+            const uint32_t u0 = v.unit_offset[tile];
+            const KeySrc ks = key_src(v, tile);
+            asm volatile("" ::"s"(ks.sub[1]), "s"(ks.sub[7]), "s"(start), "s"(n), "s"(u0));
+            if (overflow) return;   // (k_tile_totals has already zeroed the counters for the next frame)
+            // descriptors of the tile's blend units (tile, segment, list start, list length): one coalesced store
+            const uint32_t nu = (n + kUnit - 1) / kUnit;
+            for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
+                if (u0 + k < unit_cap)   // (tile position, not tile index: the blend kernels need no division)
+                    unit_tile[u0 + k] = make_uint4((tile / (uint32_t)v.tiles_x) << 16 | (tile % (uint32_t)v.tiles_x), k, start, n);
+            // hand-off words of k_unit_blend_chained: a unit's per-pixel product is valid once it is non-zero
+            if (unit_tseg)
+                for (uint32_t k = 0; k + 1 < nu && u0 + k < unit_cap; k++) unit_tseg[(size_t)(u0 + k) * kUnit + lane] = 0.f;
+            if (unit_done)
+                for (uint32_t k = (uint32_t)lane; k < nu; k += 64)
+                    if (u0 + k < unit_cap) unit_done[u0 + k] = 0u;
+            // a tile without instances has no blend unit to write its pixels (gather-in-chain mode): background here
+            if (empty_color && n == 0) {
+                const int px = (int)(tile % (uint32_t)v.tiles_x) * kTile + (lane & 7);
+                const int py = (int)(tile / (uint32_t)v.tiles_x) * kTile + (lane >> 3);
+                if (px < W && py < H) {
+                    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+                    v.final_T[pix] = 1.0f;
+                    v.n_contrib[pix] = 0u;
+                    empty_color[pix] = bg[0], empty_color[HW + pix] = bg[1], empty_color[2 * HW + pix] = bg[2];
+                }
+            }
+            if (n > 0 && n <= (uint32_t)kSortWaveMax) {
+                if (n <= 64) sort_tile_regs<1>(ks, ids, start, n, lane);
+                else if (n <= 128) sort_tile_regs<2>(ks, ids, start, n, lane);
+                else sort_tile_regs<4>(ks, ids, start, n, lane);
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_tile_sort(SortArgs a) { tile_sort_body(a); }
@@ -751,6 +484,7 @@ __device__ __forceinline__ void tile_sort_big_body(const BigSortArgs& a)
     uint32_t* ids = a.ids;
     __shared__ SortXchgT<16> sx;
     SortXchgT<8>& sx8 = *reinterpret_cast<SortXchgT<8>*>(&sx);   // (lists up to 2048: half the network)
+    if (frame_overflow(v.counts, v.bucket_cap)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nb = v.counts->big_tiles, nl = v.counts->large_tiles;
@@ -1081,6 +815,21 @@ __device__ __forceinline__ uint2 transpose_bits64(uint2 row, int lane, const Tra
     FR_TR_LEVEL(4, 1)
 #undef FR_TR_LEVEL
     return make_uint2(lo, hi);
+}
+
+// inclusive prefix sum over the 64 lanes with DPP only (no LDS round trips): shifts inside the 16-lane rows, then the
+// row totals broadcast into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+#define FR_DPP_SHR_ADD(CTRL, ROWS) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (CTRL), (ROWS), 0xF, false)
+    FR_DPP_SHR_ADD(0x111, 0xF);  // row_shr:1
+    FR_DPP_SHR_ADD(0x112, 0xF);  // row_shr:2
+    FR_DPP_SHR_ADD(0x114, 0xF);  // row_shr:4
+    FR_DPP_SHR_ADD(0x118, 0xF);  // row_shr:8
+    FR_DPP_SHR_ADD(0x142, 0xA);  // row_bcast:15
+    FR_DPP_SHR_ADD(0x143, 0xC);  // row_bcast:31
+#undef FR_DPP_SHR_ADD
+    return x;
 }
 
 // ================================================================== sparse forward: one launch per frame
@@ -1440,10 +1189,7 @@ struct ChainArgs {
     BwdUnit* bwd_units;
     uint32_t* stripe_cursor;
     uint32_t heavy_pairs;
-    uint32_t unit_cap, unit_cap_r;
-    const uint32_t* block_ref_tiles;   // the frame's counts are made final (and host-visible) by this launch's last workgroup
-    uint32_t n_blocks;
-    fr_counts* host_counts;
+    uint32_t unit_cap;
     int W, H, tiles_x;
     float* g_tseg;
     float* g_out;
@@ -1456,44 +1202,6 @@ struct ChainArgs {
     float* out_color;
     uint32_t chain_spins;
 };
-
-// The frame's counts, final and host-visible: the FIRST workgroup of the forward blend's launch (in front of the unit slots) adds
-// up what the tiles' sorters left in the region cells and the preprocess workgroups' reference-semantics partial sums
-// (a single counter would serialise one same-address device atomic per contributor, ~11 ns each).
-__device__ __forceinline__ void frame_counts_final(const ChainArgs& a)
-{
-    __shared__ uint32_t s_ref[16];
-    DeviceCounts* c = a.counts;
-    // (the heavy-tile flags of this frame have been read by k_tile_sort: zero for the next frame, like the counters)
-    const uint32_t n_vec = a.v.flag_bytes() / 16u;
-    for (uint32_t k = threadIdx.x; k < n_vec; k += blockDim.x) reinterpret_cast<uint4*>(a.v.heavy_flags)[k] = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t ref = 0;
-    for (uint32_t k = threadIdx.x; k < a.n_blocks; k += blockDim.x) ref += a.block_ref_tiles[k];
-    for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
-    if ((threadIdx.x & 63) == 0) s_ref[threadIdx.x >> 6] = ref;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    uint32_t total_ref = 0;
-    for (uint32_t w = 0; w < blockDim.x / 64; w++) total_ref += s_ref[w];
-    uint32_t inst = 0, units = 0, fullest = 0, ml = 0, mb = 0;
-    for (int x = 0; x < kRegions; x++) {
-        const unsigned long long cur = a.v.cell(x)->cursor;
-        inst += (uint32_t)cur, units += (uint32_t)(cur >> 32) & 0x7FFFFFFFu;
-        fullest = max(fullest, (uint32_t)cur);
-        ml = max(ml, a.v.cell_max(x)->max_list), mb = max(mb, a.v.cell_max(x)->max_bucket);
-    }
-    const uint32_t overflow = c->overflow ? 1u : 0u;
-    const uint32_t required = min(fullest, 0x1FFFFFFFu) * (uint32_t)kRegions;
-    c->num_rendered = total_ref, c->num_instances = inst, c->max_tile_list = ml, c->max_bucket = mb;
-    c->capacity_required = required;
-    c->num_units = overflow ? 0u : units;   // (an overflowed frame has nothing to blend: the backward's work list is empty)
-    // (pinned memory; made visible by the end-of-kernel release)
-    fr_counts* hc = a.host_counts;
-    hc->num_rendered = total_ref, hc->num_instances = inst, hc->max_tile_list = ml, hc->overflow = overflow;
-    hc->capacity_required = required;
-    reinterpret_cast<uint32_t*>(hc)[kHostMaxBucket] = mb;
-    reinterpret_cast<uint32_t*>(hc)[kHostNumUnits] = overflow ? 0u : units;
-}
 
 __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
 {
@@ -1514,48 +1222,17 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4* rec = s_rec_all[wave_in_wg];
+    const uint32_t nu_all = counts->num_units;
     // (Giving XCD x a contiguous run of the units, as the backward's work list does, takes 4 MB off this kernel's L2
     // fills and 1 us off the isolated launch, but costs 2-3 % with frames in flight and at config 5: the heavy part of the
     // image then sits on one XCD.  Runs of 32 workgroups per XCD inside every 256: -2.6 MB, -0.3 us, still -1.5 % in
     // flight.  Measured, not kept.)
-    if (blockIdx.x == 0u) {   // one workgroup in front of the unit slots
-        frame_counts_final(a);
-        return;
-    }
-    // Workgroup w serves region w mod 8, slots 4 (w / 8) .. + 3 of it: slot l of a region is taken iff l < the units that region's
-    // cursor has handed out, so the workgroups with work are the FIRST ones of the launch in every region at once (region after
-    // region, the last region's units were dispatched behind two thousand empty workgroups: + 2.6 us at config 2, + 5.6 at
-    // config 5).  A unit still waits only for lower slots of its own region, i.e. for workgroups dispatched before its own.
-    const uint32_t w_blk = blockIdx.x - 1u;
-#ifndef FR_FWD_MAP
-#define FR_FWD_MAP 1
-#endif
-#if FR_FWD_MAP == 0
-    const uint32_t reg = w_blk & (uint32_t)(kRegions - 1);
-    const uint32_t u_loc = (w_blk >> kRegionsLog2) * kWavesPerWG + wave_in_wg;
-#elif FR_FWD_MAP == 1
-    // (rotated: the g-th workgroup of region r is workgroup 8 g + ((r - g) & 7), so that a region's workgroups — and a tile's
-    // units — go round the XCDs instead of all sitting on XCD r)
-    const uint32_t reg = (w_blk + (w_blk >> kRegionsLog2)) & (uint32_t)(kRegions - 1);
-    const uint32_t u_loc = (w_blk >> kRegionsLog2) * kWavesPerWG + wave_in_wg;
-#else
-    const uint32_t per_reg = (gridDim.x - 1u) / (uint32_t)kRegions;
-    const uint32_t reg = w_blk / per_reg;
-    const uint32_t u_loc = (w_blk - reg * per_reg) * kWavesPerWG + wave_in_wg;
-#endif
-    const uint32_t u = reg * a.unit_cap_r + min(u_loc, a.unit_cap_r - 1u);   // the unit's SLOT in the per-unit arrays
-    // (the unit's descriptor is requested together with the cursors, not behind them: one dependent round trip less in
+    const uint32_t u = blockIdx.x * kWavesPerWG + wave_in_wg;
+    // (the unit's descriptor is requested together with the unit count, not behind it: one dependent round trip less in
     // front of every wave's records; a.unit_cap descriptors exist whatever the frame holds)
-    const uint4 d_early = unit_tile[u];
-    // ONE cursor in front of the wave's first instruction: the units its region has handed out, and the frame's verdict (bit 63)
-    const unsigned long long cur = a.v.cell((int)reg)->cursor;
-    // ... the other regions' counts (the unit's DENSE index, for the backward's work list) are not needed before the local walk is
-    // done: requested here by the first eight lanes, read there
-    uint32_t taken_l = 0;
-    if (lane < kRegions) taken_l = (uint32_t)(a.v.cell(lane)->cursor >> 32) & 0x7FFFFFFFu;
-    asm volatile("" ::"v"(d_early.x), "v"(taken_l), "s"(cur));
-    const uint32_t mine = (uint32_t)(cur >> 32) & 0x7FFFFFFFu;
-    if ((cur & kCursorOverflow) || u_loc >= mine) return;   // (mine <= unit_cap_r)
+    const uint4 d_early = unit_tile[min(u, a.unit_cap - 1u)];
+    asm volatile("" ::"v"(d_early.x), "s"(nu_all));
+    if (u >= nu_all) return;
     FW_STAMP(0);
     FW_STAMPV(8, __builtin_amdgcn_s_memrealtime());
     const TransposeConsts tc = transpose_consts(lane);
@@ -1593,13 +1270,6 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
     if (ui.base + kUnit < ui.n)   // (nobody reads the last unit's product)
         __hip_atomic_store(g_tseg + (size_t)u * kUnit + lane, fmaxf(o.T, 1e-30f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the unit's place in the backward's work list (BwdUnit): long walks from the front of its stripe, the others from the back
-    uint32_t nu_all = 0, ud = u_loc;   // the unit's DENSE index, 0 .. nu_all - 1 (the backward's work list is dense)
-#pragma unroll
-    for (int x = 0; x < kRegions; x++) {
-        const uint32_t tx_ = (uint32_t)__builtin_amdgcn_readlane((int)taken_l, x);
-        ud += (uint32_t)x < reg ? tx_ : 0u;
-        nu_all += tx_;
-    }
     if (lane == 0) {
         const bool heavy = npairs >= a.heavy_pairs;
         // Which stripe?  Stripe j holds slots j, j + 64, ...: n_j = ceil((nu - j) / 64) of them, and the hardware runs
@@ -1613,10 +1283,10 @@ __device__ __forceinline__ void unit_blend_chained_body(const ChainArgs& a)
         for (; x < 7u; x++) {
             const uint32_t lo4 = 4u * x, hi4 = 32u + 4u * x;
             const uint32_t n_x = 8u * q + (rem > lo4 ? min(rem - lo4, 4u) : 0u) + (rem > hi4 ? min(rem - hi4, 4u) : 0u);
-            if (ud < first + n_x) break;
+            if (u < first + n_x) break;
             first += n_x;
         }
-        const uint32_t t = (ud - first) & 7u;
+        const uint32_t t = (u - first) & 7u;
         const uint32_t j = t < 4u ? 4u * x + t : 32u + 4u * x + (t - 4u);
         const uint32_t n_j = (nu_all - j + kStripes - 1u) / kStripes;   // the stripe's slot count
         const uint32_t k = atomicAdd(a.stripe_cursor + (j * 2u + (heavy ? 0u : 1u)) * kStripeWords, 1u);
@@ -1775,17 +1445,17 @@ __device__ __forceinline__ void unit_blend_bwd_sparse_body(const BlendBwdArgs& a
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // The first unit's descriptor is requested BEFORE the counts are known (one round trip less in front of every
     // wave's first loads): the descriptors sit at the head of the binning buffer whatever its capacity, and there are at
-    // more than T + 1 of them (BinningView::region_units), so index min(u, T) is always inside the buffer.
+    // least T + 1 of them (BinningView::units_for), so index min(u, T) is always inside the buffer.
     const uint32_t n_tiles = (uint32_t)v.tiles_x * (uint32_t)v.tiles_y;
     const uint32_t w_first = blockIdx.x * kWavesPerWG + wave_in_wg;   // slot of the work list (BwdUnit)
     const uint32_t nu = counts->num_units, capacity = counts->capacity;
-    const BwdUnit* __restrict__ work = BinningView::make(binning, 0, (size_t)v.tiles_x, (size_t)v.tiles_y).bwd_units;
+    const BwdUnit* __restrict__ work = BinningView::make(binning, 0, (size_t)n_tiles).bwd_units;
     const uint4 d_first = work[min(w_first, n_tiles)].d;
     const uint32_t u_of_first = work[min(w_first, n_tiles)].u;
     // (pinned together: the descriptor load is issued before anything waits for the counts — without this the compiler
     // parks it behind the loop's entry test, i.e. behind the counts' round trip)
     asm volatile("" ::"v"(d_first.x), "v"(u_of_first), "s"(nu), "s"(capacity));
-    const BinningView b = BinningView::make(binning, (size_t)capacity, (size_t)v.tiles_x, (size_t)v.tiles_y);
+    const BinningView b = BinningView::make(binning, (size_t)capacity, (size_t)n_tiles);
     SparseLds& S = s_all[wave_in_wg];
     const uint32_t wave_stride = gridDim.x * kWavesPerWG;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -2061,22 +1731,19 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         const BinningView& b = f[k].b;
         const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
         const uint32_t small_blocks = (T + 3) / 4;
-        sort_blocks = max(sort_blocks, small_blocks + kGroupSorters);
-        // (one workgroup in front of the unit slots makes the frame's counts final: frame_counts_final)
-        unit_wgs = max(unit_wgs, (uint32_t)kRegions * (uint32_t)((b.unit_cap_r + kWavesPerWG - 1) / kWavesPerWG) + 1u);
+        sort_blocks = max(sort_blocks, small_blocks + kMediumSorters);
+        unit_wgs = max(unit_wgs, (uint32_t)((b.unit_cap + kWavesPerWG - 1) / kWavesPerWG));
         gather_blocks = max(gather_blocks, (T + kWavesPerWG - 1) / kWavesPerWG);
         SortArgs& a = sa[k];
         a.v = v, a.T = T, a.Q = small_blocks, a.keys = (u64*)b.keys, a.ids = b.ids, a.unit_tile = b.unit_tile;
-        a.cap_r = (uint32_t)b.cap_r, a.unit_cap_r = (uint32_t)b.unit_cap_r, a.capacity = (uint32_t)b.cap;
-        a.unit_tseg = b.unit_tseg, a.take_long_lists = launch_big ? 0 : 1;
+        a.unit_cap = (uint32_t)b.unit_cap, a.unit_tseg = b.unit_tseg, a.take_long_lists = launch_big ? 0 : 1;
+        a.host_counts = h->host_counts_dev;
         a.unit_done = h->gather_in_chain ? b.unit_done : nullptr;
         a.empty_color = h->gather_in_chain ? f[k].out_color : nullptr;
         a.bg = f[k].in->background, a.W = prm.W, a.H = prm.H, a.stripe_cursor = b.stripe_cursor;
         ba[k].v = v, ba[k].keys = (u64*)b.keys, ba[k].ids = b.ids;
         ChainArgs& c = ca[k];
         c.counts = v.counts, c.unit_tile = b.unit_tile, c.masks = b.masks, c.walks = b.walks, c.bwd_units = b.bwd_units, c.stripe_cursor = b.stripe_cursor, c.heavy_pairs = h->heavy_pairs, c.unit_cap = (uint32_t)b.unit_cap;
-        c.unit_cap_r = (uint32_t)b.unit_cap_r, c.block_ref_tiles = f[k].g.block_ref_tiles;
-        c.n_blocks = prm.P > 0 ? (uint32_t)((prm.P + kPreWG - 1) / kPreWG) : 0u, c.host_counts = h->host_counts_dev;
         c.recs = RecSrc{b.ids, f[k].g.rec_tmpl};
         c.W = prm.W, c.H = prm.H, c.tiles_x = v.tiles_x, c.g_tseg = b.unit_tseg, c.g_out = b.unit_out;
         c.dense_pairs = h->dense_pairs_fwd, c.pair_hist = h->debug_pair_hist ? 1 : 0;
@@ -2086,9 +1753,19 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
     }
     {
         StageScope sc(h0, ST_SORT, s);
-        launch_views(k_tile_sort, k_tile_sort_batch, n, sa, sort_blocks, 64 * kSortWaves, 0, s);
-        // ... and BEHIND it (the lists it takes are named by k_tile_sort's owners): the few lists beyond kSortGroupMax
-        if (launch_big) launch_views(k_tile_sort_big, k_tile_sort_big_batch, n, ba, kBigSorters, 256, 0, s);
+        // ... and then NEXT TO k_tile_sort, on the (first view's) handle's side stream: its few long lists take as long as
+        // all the short ones together (config 5: 48 us against 65), the two kernels touch different tiles
+        if (launch_big) {
+            FR_HIP(hipEventRecord(h0->side_fork, s));
+            FR_HIP(hipStreamWaitEvent(h0->side_stream, h0->side_fork, 0));
+            launch_views(k_tile_sort_big, k_tile_sort_big_batch, n, ba, kBigSorters, 256, 0, h0->side_stream);
+            FR_HIP(hipEventRecord(h0->side_join, h0->side_stream));
+        }
+        launch_views(k_tile_sort, k_tile_sort_batch, n, sa, sort_blocks, 256, 0, s);
+        // the counts reach the pinned host slots with this kernel: the (waiting) forward blocks on them, not on the frame
+        for (int k = 0; k < n; k++)
+            if (!(f[k].prm->flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(f[k].h->counts_ready, s));
+        if (launch_big) FR_HIP(hipStreamWaitEvent(s, h0->side_join, 0));
     }
     FR_HIP(hipGetLastError());
     if ((rc = debug_sync(debug, s, "tile_sort"))) return rc;
@@ -2096,9 +1773,6 @@ int launch_sort_and_blend(int n, const FrameView* f, hipStream_t s, bool debug)
         StageScope sc(h0, ST_BLEND_FWD, s);
         // (one workgroup per four units, no grid-stride loop: see k_unit_blend_chained on forward progress)
         launch_views(k_unit_blend_chained, k_unit_blend_chained_batch, n, ca, unit_wgs, 64 * kWavesPerWG, 0, s);
-        // the counts reach the pinned host slots with this kernel: the (waiting) forward blocks on them
-        for (int k = 0; k < n; k++)
-            if (!(f[k].prm->flags & FR_FLAG_NO_WAIT)) FR_HIP(hipEventRecord(f[k].h->counts_ready, s));
         if (!h0->gather_in_chain)   // (n == 1, see above)
             hipLaunchKernelGGL(k_tile_gather, dim3(gather_blocks), dim3(64 * kWavesPerWG), 0, s, f[0].v.counts, f[0].v,
                                f[0].b.unit_out, f[0].b.unit_state, f[0].prm->W, f[0].prm->H, f[0].in->background, f[0].out_color);
@@ -2116,7 +1790,7 @@ int launch_blend_backward(int n, const BackwardCall* calls, const GeomView* g, c
     uint32_t unit_grid = 256;
     for (int k = 0; k < n; k++) {
         const fr_handle_impl* h = calls[k].h;
-        const uint32_t seen = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[kHostNumUnits] : ~0u;
+        const uint32_t seen = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[5] : ~0u;
         const uint32_t want = seen > 4u * kUnitGrid ? kUnitGrid : (seen + seen / 8 + kWavesPerWG - 1) / kWavesPerWG;
         unit_grid = min(kUnitGrid, max(unit_grid, want));
     }

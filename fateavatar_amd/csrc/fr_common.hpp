@@ -23,11 +23,6 @@ constexpr uint32_t kDensePairsBwd = 1000;  // backward: the same choice inside k
 #define FR_PRE_WG 128
 #endif
 constexpr int kPreWG = FR_PRE_WG;   // threads per workgroup of k_preprocess_fwd
-#ifndef FR_HEAVY_BUCKET
-#define FR_HEAVY_BUCKET 32
-#endif
-constexpr uint32_t kHeavyBucket = FR_HEAVY_BUCKET;    // a tile with a (tile, XCD) bucket beyond this many keys is sorted by a four-wave workgroup: every
-                                         // list of more than 8 x 32 = kSortWaveMax keys has one (kBucketCapInit must exceed it)
 constexpr uint32_t kBucketCapInit = 64;  // initial capacity of a (tile, XCD) key bucket; grows (power of two) on overflow
 constexpr int kSortWaveMax = 256;    // longest tile list one wave sorts alone in registers (4 keys per lane)
 constexpr int kSortGroupMax = 2048;  // longest list k_tile_sort handles (4 waves x 8 keys per lane).  (1 024 until round 6: the reference's own
@@ -106,97 +101,41 @@ struct GeomView {
     }
 };
 
-// Record and unit ranges are handed out by the tile's own sorter (k_tile_sort) with ONE returning atomic on the cursor of the
-// tile's REGION: the per-instance and per-unit arrays of the binning buffer are cut into kRegions equal parts, a tile belongs
-// to region (tx + 3 ty) & 7 (neighbouring tiles in different regions: a head-sized blob fills the regions to within 3 %), and a
-// cursor word packs (instances taken, units taken << 32).  No scan, no allocation launch: a tile needs nothing but its own
-// eight counters.  A single cursor would serialise one same-address atomic per non-empty tile (11 - 13 ns each).
-#ifndef FR_REGIONS_LOG2
-#define FR_REGIONS_LOG2 3
-#endif
-constexpr int kRegionsLog2 = FR_REGIONS_LOG2;
-constexpr int kRegions = 1 << kRegionsLog2;
-struct RegionCell {
-    unsigned long long cursor;   // (instances allocated) | (units allocated) << 32
-};
-struct RegionMax {             // on lines of their own (no returning atomic queues behind these)
-    uint32_t max_list;           // longest tile list / largest (tile, XCD) bucket seen by the sorters that report here
-    uint32_t max_bucket;
-};
-#ifndef FR_REGION_HASH
-#define FR_REGION_HASH 0
-#endif
-__host__ __device__ static inline uint32_t region_of(uint32_t tx, uint32_t ty)
-{
-#if FR_REGION_HASH == 0
-    return (tx + 3u * ty) & (uint32_t)(kRegions - 1);
-#elif FR_REGION_HASH == 1
-    return ((tx >> 2) + 3u * (ty >> 2)) & (uint32_t)(kRegions - 1);
-#elif FR_REGION_HASH == 2
-    return ((tx >> 3) + 3u * (ty >> 3)) & (uint32_t)(kRegions - 1);
-#else
-    return (ty >> 3) & (uint32_t)(kRegions - 1);
-#endif
-}
-
-struct DeviceCounts {  // lives at the head of the image buffer; zeroed by k_preprocess_fwd, final once k_unit_blend_chained has run
+struct DeviceCounts {  // lives at the head of the image buffer
     uint32_t num_rendered;   // reference semantics
     uint32_t num_instances;
     uint32_t max_tile_list;
-    uint32_t overflow;       // set by any tile's sorter that finds a key bucket or its region full
+    uint32_t overflow;
     uint32_t large_tiles;    // number of tiles whose list exceeds kSortRegMax
     uint32_t max_bucket;     // largest (tile, XCD) list: above ImageView::bucket_cap the key buckets overflowed
-    uint32_t capacity_required;   // 8 x the fullest region: the smallest binning capacity that holds this frame
+    uint32_t medium_tiles;   // number of tiles sorted cooperatively by a 4-wave workgroup
     uint32_t big_tiles;      // number of tiles with kSortGroupMax < entries <= kSortRegMax (4 waves x 16 keys per lane)
     uint32_t pad2;
     uint32_t pair_hist[5];   // FR_DEBUG_PAIR_HIST=1 only: units by pairs named (<= 500, <= 1000, <= 1500, <= 2500, more)
     uint32_t num_units;      // total number of blend units (64-record segments of tile lists)
     uint32_t capacity;       // binning capacity of this frame (the backward re-derives the binning layout from it)
 };
-static_assert(sizeof(DeviceCounts) == 64, "DeviceCounts layout");
-// distance between two region cursors (ImageView::cells): atomics on ONE 64-byte line queue at the memory side (the eight cursors in
-// one line: k_tile_sort 14.8 -> 25.1 us at config 2, 52 -> 75 at config 5), so every cursor has a line of its own, on another channel
-#ifndef FR_CELL_STRIDE
-#define FR_CELL_STRIDE 4352
-#endif
-constexpr size_t kCellStride = FR_CELL_STRIDE;
-constexpr size_t kMaxCellStride = 320;   // the regions' (max_list, max_bucket) words, behind the cursors
-constexpr size_t kCellBytes = kRegions * kCellStride + 256 + kRegions * kMaxCellStride;
 
 struct ImageView {
     DeviceCounts* counts;
-    char* cells;             // kRegions RegionCells, kCellStride bytes apart (zeroed by k_preprocess_fwd with the counts)
-    __host__ __device__ RegionCell* cell(int x) const { return reinterpret_cast<RegionCell*>(cells + (size_t)x * kCellStride); }
-    __host__ __device__ RegionMax* cell_max(int x) const { return reinterpret_cast<RegionMax*>(cells + kRegions * kCellStride + 256 + (size_t)x * kMaxCellStride); }
     // The per-tile counters do NOT live in the image buffer: they belong to the handle (fr_handle_impl::tile_counters),
-    // are zero between frames (the tile's sorter re-zeroes its eight counters after reading them) and so need no zeroing
-    // launch per frame.  launch_forward points tile_count / buckets at them.
+    // are zero between frames (k_tile_totals re-zeroes tile_count after reading it) and so need no zeroing launch per
+    // frame.  launch_forward points tile_count / buckets at them.
     // They are PRIVATE PER XCD: a counting atomic from XCD x goes to copy x, so a counter's cache line stays in one
     // XCD's L2 instead of bouncing between the eight (device-scope atomics from several XCDs on one line serialise
     // at the fabric); a tile's segment is the concatenation of its eight per-XCD sub-segments.
     uint32_t* tile_count;    // [kXcds][tpad] instances counted by XCD x (block-major, counter_index)
-    uint8_t* heavy_flags;    // a byte per tile, = 1: some (tile, XCD) bucket has more than kHeavyBucket keys — stored (plain byte stores:
-                             // a bitmap would take same-address atomics, ~12 ns each, at the tail of the counting pass) by the
-                             // instance that takes position kHeavyBucket, read by k_tile_sort, whose group sorters own exactly these
-                             // tiles, zeroed by the forward blend's first workgroup (handle-owned, behind the counters).
-                             // Tile t's flag sits at flag_index(t): 2^flag_lg CHUNKS of flag_clen <= 1024 bytes, chunk c holding the
-                             // tiles t = c (mod 2^flag_lg) — every chunk samples the whole image, so the chunks hold about the same
-                             // number of flagged tiles, and a group sorter finds "the r-th flagged tile of chunk c" with ONE
-                             // 16-byte load per lane and one wave scan
-    uint32_t flag_lg, flag_clen;
-    __host__ __device__ uint32_t flag_index(uint32_t t) const { return (t & ((1u << flag_lg) - 1u)) * flag_clen + (t >> flag_lg); }
-    __host__ __device__ uint32_t flag_bytes() const { return flag_clen << flag_lg; }
     uint64_t* buckets;       // [T][kXcds][bucket_cap] the keys of the instances, written by the counting pass itself:
                              // slot s of (tile, XCD x) is the s-th instance XCD x counted into the tile (handle-owned)
     uint32_t bucket_cap;
-    uint32_t* tile_sub;      // [T][kSubWords] start, within the tile's list, of each XCD's sub-list (written for the lists left to
-                             // k_tile_sort_big only: every other sorter has the counters themselves)
+    uint32_t* tile_sub;      // [T][kSubWords] start, within the tile's list, of each XCD's sub-list
     uint32_t tpad;           // row pitch of the two counter arrays
     uint32_t* tile_total;    // [T rounded up to 16] instances per tile (sum over the XCD copies)
-    uint32_t* tile_offset;   // [T+1] first record of the tile's list (taken from its region's cursor by the tile's sorter)
+    uint32_t* tile_offset;   // [T+1] first record of the tile's list (allocated by k_tile_totals, in no particular tile order)
     uint32_t* large_list;    // [T]   ids of tiles with more than kSortRegMax entries
+    uint32_t* medium_list;   // [T]   ids of tiles with kSortWaveMax < entries <= kSortGroupMax (sorted by 4 waves)
     uint32_t* big_list;      // [T]   ids of tiles with kSortGroupMax < entries <= kSortRegMax
-    uint32_t* unit_offset;   // [T+1] first blend unit of each tile (ceil(tile_total / 64) consecutive unit slots of its region)
+    uint32_t* unit_offset;   // [T+1] first blend unit of each tile (ceil(tile_total / 64) consecutive units, allocated likewise)
     float* final_T;          // [W*H]
     uint32_t* n_contrib;     // [W*H] index+1 (in the 8x8 tile list) of the last blended entry
     int tiles_x, tiles_y;
@@ -214,11 +153,7 @@ struct ImageView {
         v.tiles_y = (H + kTile - 1) / kTile;
         size_t T = (size_t)v.tiles_x * v.tiles_y;
         v.counts = carve<DeviceCounts>(p, 1);
-        v.cells = carve<char>(p, kCellBytes);
-        v.flag_lg = 0;
-        while ((T + 1023) / 1024 > ((size_t)1 << v.flag_lg)) v.flag_lg++;
-        v.flag_clen = (uint32_t)((((T + ((size_t)1 << v.flag_lg) - 1) >> v.flag_lg) + 15) & ~(size_t)15);
-        v.tile_count = nullptr, v.heavy_flags = nullptr, v.buckets = nullptr, v.bucket_cap = 0;
+        v.tile_count = nullptr, v.buckets = nullptr, v.bucket_cap = 0;
         // counters are stored in 4x4-tile blocks (one 64-byte line per block): lanes of one atomic instruction that
         // fall into the same line are merged into ONE request (27 requests/ns vs 250 lane-atomics/ns,
         // tools/micro_atomics.hip), and the tiles of one Gaussian's rectangle are 2-D neighbours
@@ -227,6 +162,7 @@ struct ImageView {
         v.tile_total = carve<uint32_t>(p, (T + 15) & ~(size_t)15);
         v.tile_offset = carve<uint32_t>(p, T + 1);
         v.large_list = carve<uint32_t>(p, T);
+        v.medium_list = carve<uint32_t>(p, T);
         v.big_list = carve<uint32_t>(p, T);
         v.unit_offset = carve<uint32_t>(p, T + 1);
         v.final_T = carve<float>(p, (size_t)W * H);
@@ -268,7 +204,6 @@ constexpr uint32_t kStripeWords = 16;   // words between two cursors
 
 struct BinningView {
     size_t cap, unit_cap;
-    size_t cap_r, unit_cap_r;   // per region: instances [x * cap_r, (x + 1) * cap_r), unit slots [x * unit_cap_r, (x + 1) * unit_cap_r)
     BwdUnit* bwd_units;   // [unit_cap]
     uint32_t* stripe_cursor;   // [kStripes * 2 * kStripeWords] (zeroed by k_tile_sort)
     uint64_t* keys;       // [cap] (depth_bits << 32 | gaussian id), grouped per tile, unsorted
@@ -282,20 +217,13 @@ struct BinningView {
     float* unit_tseg;     // [unit_cap*64]   product of (1-alpha) over the unit's blendable records, per pixel
     float* unit_out;      // [unit_cap*5*64] forward partials per pixel: Cr, Cg, Cb, T_out, (last | done<<31)
     float4* unit_state;   // [unit_cap*64]   backward entry state per pixel: colour behind the unit / T_out, T_out
-    // a region holds cap / 8 instances, i.e. at most cap / 512 full units plus one partial unit per tile of the region
-    // (every image row has at most ceil(tiles_x / 8) tiles of a region)
-    __host__ __device__ static size_t region_units(size_t cap, size_t tiles_x, size_t tiles_y)
-    {
-        return (cap / kRegions) / kUnit + tiles_y * ((tiles_x + kRegions - 1) / kRegions) + 1;
-    }
-    __host__ __device__ static BinningView make(void* buf, size_t cap, size_t tiles_x, size_t tiles_y)
+    __host__ __device__ static size_t units_for(size_t cap, size_t T) { return cap / kUnit + T + 1; }
+    __host__ __device__ static BinningView make(void* buf, size_t cap, size_t T)
     {
         char* p = static_cast<char*>(buf);
         BinningView b;
         b.cap = cap;
-        b.cap_r = cap / kRegions;
-        b.unit_cap_r = region_units(cap, tiles_x, tiles_y);
-        b.unit_cap = b.unit_cap_r * kRegions;
+        b.unit_cap = units_for(cap, T);
         // (the backward's work list comes FIRST: its address does not depend on the capacity, so the blend backward, which
         // learns the capacity from the device counts, can request a unit's descriptor together with the counts)
         b.bwd_units = carve<BwdUnit>(p, b.unit_cap);
@@ -311,9 +239,9 @@ struct BinningView {
         b.unit_state = carve<float4>(p, b.unit_cap * kUnit);
         return b;
     }
-    static size_t bytes(size_t cap, size_t tiles_x, size_t tiles_y)
+    static size_t bytes(size_t cap, size_t T)
     {
-        BinningView b = make(nullptr, cap, tiles_x, tiles_y);
+        BinningView b = make(nullptr, cap, T);
         return reinterpret_cast<size_t>(b.unit_state + b.unit_cap * kUnit) + 256;
     }
 };
@@ -334,11 +262,6 @@ struct StageEvents {
     std::vector<hipEvent_t> start, stop;
     size_t used = 0;
 };
-
-// words of the 64-byte pinned count slot behind the fr_counts fields
-constexpr int kHostMaxBucket = 5;   // largest (tile, XCD) bucket need of the frame: sizes the key buckets
-constexpr int kHostNumUnits = 6;    // blend units of the frame (0 if it overflowed): sizes the blend backward's grid
-static_assert(sizeof(fr_counts) == 20, "fr_counts: five words at the head of the pinned slot");
 
 struct fr_handle_impl {
     int device;
@@ -364,6 +287,10 @@ struct fr_handle_impl {
     // behind the last kernel that touches the counters of the previous frame (not while a stream is being captured:
     // a capture is ordered by its own stream, and replays of the graph are ordered by whoever launches them).
     hipEvent_t frame_done = nullptr;
+    // the big-list sorter (lists > 1024, only launched for frames that have had one) runs NEXT TO k_tile_sort on this
+    // stream: fork after the totals kernel, join before the blend (captured as a parallel branch in a HIP graph)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     // ... and their backward passes share the gradient accumulators: a backward enqueued on a different stream than the

@@ -77,20 +77,4 @@ extern "C" int fr_debug_read_fwd_trace(void* dst, size_t bytes)
 #define FW_STAMPV(K, V) do { } while (0)
 #endif
 
-//   -DFR_DIAG_SORT_TRACE   per-wave wall-clock stamps (s_memrealtime, 100 MHz) of k_tile_sort's phases (tools/diag/sort_trace.py)
-#ifdef FR_DIAG_SORT_TRACE
-namespace fr {
-__device__ unsigned long long g_sort_trace[16384 * 8];
-}
-extern "C" int fr_debug_read_sort_trace(void* dst, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fr::g_sort_trace), bytes < sizeof(fr::g_sort_trace) ? bytes : sizeof(fr::g_sort_trace));
-}
-#define SO_STAMP(K) do { if (lane == 0 && blockIdx.x * 4u + (unsigned)wave < 16384u) ::fr::g_sort_trace[(size_t)(blockIdx.x * 4u + (unsigned)wave) * 8 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define SO_STAMPV(K, V) do { if (lane == 0 && blockIdx.x * 4u + (unsigned)wave < 16384u) ::fr::g_sort_trace[(size_t)(blockIdx.x * 4u + (unsigned)wave) * 8 + (K)] = (unsigned long long)(V); } while (0)
-#else
-#define SO_STAMP(K) do { } while (0)
-#define SO_STAMPV(K, V) do { } while (0)
-#endif
-
 // (fr_preprocess.hip has its own timing-experiment switch, -DFR_DIAG_PRE_ABLATE=mask, defined at its head)

@@ -69,13 +69,10 @@ struct PreArgs {
     BindArgs bind;
     GeomView g;
     uint32_t* tile_count;
-    uint8_t* heavy_flags;   // ImageView::heavy_flags, flag_index()
-    uint32_t flag_lg, flag_clen;
     uint64_t* buckets;      // key buckets [tiles][8][bucket_cap]
     uint32_t bucket_cap;
     uint32_t tpad;          // row pitch of the per-XCD counter copies
     DeviceCounts* counts;
-    char* cells;   // ImageView::cells
     int tiles_x, tiles_y;   // 8x8 tiles
     int ref_gx, ref_gy;     // 16x16 tiles (reference grid)
 };
@@ -221,15 +218,8 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the frame's device counts (the region cursors of k_tile_sort) start from zero: the image buffer is caller-owned scratch
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < sizeof(DeviceCounts) / 4) reinterpret_cast<uint32_t*>(a.counts)[threadIdx.x] = 0u;
-        for (uint32_t k = threadIdx.x; k < kRegions * 4u; k += kPreWG) {   // (cursor; max_list, max_bucket of every region)
-            const ImageView iv = {nullptr, a.cells};
-            uint32_t* w = (k & 2u) ? reinterpret_cast<uint32_t*>(iv.cell_max((int)(k >> 2))) : reinterpret_cast<uint32_t*>(iv.cell((int)(k >> 2)));
-            w[k & 1u] = 0u;
-        }
-    }
+    // the frame's device counts (cursors of k_tile_totals) start from zero: the image buffer is caller-owned scratch
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DeviceCounts) / 4) reinterpret_cast<uint32_t*>(a.counts)[threadIdx.x] = 0u;
     if ((int)(blockIdx.x * kPreWG) >= a.P) return;   // (a batched launch's grid is the largest view's; P > 0: block 0 stays)
     const int M3 = a.M * 3;
     PRE_TR_DECL;
@@ -584,16 +574,10 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
 #pragma unroll
         for (int u = 0; u < kCountUnroll; u++) {
             const uint32_t depth_bits = ((dead >> owner[u]) & 1ull) ? 0x7F800000u : gk[u].y;
-            // (a position beyond the bucket is dropped: the tile's sorter sees the count and flags the frame)
+            // (a position beyond the bucket is dropped: k_tile_totals sees the count and flags the frame)
             if (valid[u] && pos[u] < a.bucket_cap && !FR_PRE_ABLATE(2))
                 a.buckets[((size_t)tile_id[u] * kXcds + xcc) * a.bucket_cap + pos[u]] = ((uint64_t)depth_bits << 32) | gk[u].x;
         }
-        // the instance that takes position kHeavyBucket of a bucket marks its tile for k_tile_sort's group sorters (at most
-        // eight of these per tile and frame; a plain byte store)
-#pragma unroll
-        for (int u = 0; u < kCountUnroll; u++)
-            if (valid[u] && pos[u] == kHeavyBucket)
-                a.heavy_flags[(tile_id[u] & ((1u << a.flag_lg) - 1u)) * a.flag_clen + (tile_id[u] >> a.flag_lg)] = (uint8_t)1;
         PRE_TR(9);   // key stores issued
     };
     const bool counting = total > 0u && !FR_PRE_ABLATE(1);
@@ -688,7 +672,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
     }
     PRE_TR(10);
     PRE_TR_STORE();
-    // num_rendered in reference semantics: per-workgroup partial sums, added up by the forward blend's last workgroup (a single
+    // num_rendered in reference semantics: per-workgroup partial sums, added up by k_tile_totals (a single
     // counter would serialise one device-scope atomic per wave, ~11 ns each)
     __shared__ uint32_t s_ref[4];
     uint32_t s = ref_tiles;
@@ -705,6 +689,146 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs& a)
 __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd(PreArgs a) { preprocess_fwd_body(a); }
 // batched frames: view blockIdx.y
 __global__ void __launch_bounds__(kPreWG) k_preprocess_fwd_batch(BatchOf<PreArgs> b) { preprocess_fwd_body(b.v[blockIdx.y]); }
+
+// Everything between the counting pass and the sort, in ONE wide launch (it used to be a totals kernel plus a
+// single-workgroup scan): per tile, add up the eight per-XCD counter copies, write the sub-list table and leave the
+// counters zeroed for the next frame; then ALLOCATE the tile's record range and blend-unit range.  Nothing needs the
+// tiles' lists in tile order, only each list contiguous, so a workgroup scans its own 1024 tiles in LDS and takes its
+// block of records / units / list entries with one returning atomic per cursor (4 workgroups at 512 x 512): no
+// grid-wide prefix, no second launch.  The frame counts (instances, units, longest list, largest bucket, the
+// reference-semantics num_rendered) are reduced with a few atomics per workgroup; k_tile_sort's first thread turns
+// them into the overflow verdict and the host-visible counts.
+// reference counterparts: InclusiveSum + the blocking count read-back (rasterizer_impl.cu:277-281), identifyTileRanges.
+struct TotalsArgs {
+    ImageView v;
+    uint32_t T;
+    uint64_t capacity;
+    const uint32_t* block_ref_tiles;
+    uint32_t n_blocks;
+};
+
+#ifndef FR_TOT_WAVES
+#define FR_TOT_WAVES 1
+#endif
+constexpr int kTotWaves = FR_TOT_WAVES;   // waves per workgroup of k_tile_totals: 256 tiles per wave.  Measured at 512 x 512 (4 096 tiles,
+                                          // rocprofv3, one box): 1 wave per workgroup 5.4 us, 2: 6.1, 4: 6.6, 8: 8.2, 16 (ONE workgroup, which
+                                          // then needs no cursor atomics): 11.4 — the pass is a chain of round trips per workgroup, and the
+                                          // more CUs share its loads the shorter each link
+__device__ __forceinline__ void tile_totals_body(const TotalsArgs& a)
+{
+    const ImageView v = a.v;
+    const uint32_t T = a.T, n_blocks = a.n_blocks;
+    const uint64_t capacity = a.capacity;
+    const uint32_t* __restrict__ block_ref_tiles = a.block_ref_tiles;
+    __shared__ uint32_t s_wave[2][kTotWaves];   // per-wave totals: instances, units
+    __shared__ uint32_t s_base[8];        // workgroup bases: instances, units, medium / big / large list heads
+    __shared__ uint32_t s_heads[3];       // workgroup-local list counters
+    if (threadIdx.x < 3) s_heads[threadIdx.x] = 0;
+    DeviceCounts* c = v.counts;
+    // every thread: four consecutive counters = one row of a 4x4-tile block
+    const uint32_t i = (blockIdx.x * (uint32_t)(64 * kTotWaves) + threadIdx.x) * 4u;
+    uint32_t sub[4][kSubWords];
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    uint32_t biggest = 0;
+    if (i < v.tpad) {
+#pragma unroll
+        for (int x = 0; x < kXcds; x++) {
+            uint4* p1 = reinterpret_cast<uint4*>(v.tile_count + (size_t)x * v.tpad + i);
+            const uint4 c1 = *p1;
+            *p1 = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t a1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sub[q][x] = acc[q];                  // start of XCD x's sub-list inside the tile's list
+                acc[q] += a1[q];
+                biggest = max(biggest, a1[q]);
+            }
+        }
+    }
+    const uint32_t bx = (uint32_t)(v.tiles_x + 3) / 4, blk = i >> 4, row = (i >> 2) & 3u;
+    const uint32_t ty = (blk / bx) * 4 + row, tx0 = (blk % bx) * 4;
+    const bool row_ok = i < v.tpad && ty < (uint32_t)v.tiles_y;   // (padding rows of the block grid are never counted into)
+    uint32_t n_sum = 0, u_sum = 0, longest = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!(row_ok && tx0 + q < (uint32_t)v.tiles_x)) acc[q] = 0;
+        n_sum += acc[q];
+        u_sum += (acc[q] + kUnit - 1) / kUnit;
+        longest = max(longest, acc[q]);
+    }
+    // ---- workgroup scan of (instances, units): wave scan by shuffles, wave totals through LDS
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t n_inc = n_sum, u_inc = u_sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tn = __shfl_up(n_inc, off), tu = __shfl_up(u_inc, off);
+        if (ln >= off) n_inc += tn, u_inc += tu;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        biggest = max(biggest, (uint32_t)__shfl_down(biggest, off));
+        longest = max(longest, (uint32_t)__shfl_down(longest, off));
+    }
+    // reference-semantics num_rendered: this workgroup adds up its slice of the preprocess workgroups' partial sums
+    uint32_t ref = 0;
+    for (uint32_t k = blockIdx.x * (uint32_t)(64 * kTotWaves) + threadIdx.x; k < n_blocks; k += gridDim.x * (uint32_t)(64 * kTotWaves)) ref += block_ref_tiles[k];
+    for (int off = 32; off > 0; off >>= 1) ref += __shfl_down(ref, off);
+    if (ln == 63) s_wave[0][wv] = n_inc, s_wave[1][wv] = u_inc;
+    if (ln == 0) {
+        if (biggest) atomicMax(&c->max_bucket, biggest);
+        if (longest) atomicMax(&c->max_tile_list, longest);
+        if (ref) atomicAdd(&c->num_rendered, ref);
+    }
+    // list membership of this thread's tiles (workgroup-local rank first, one global atomic per list and workgroup)
+    uint32_t cls[4], lrank[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t n = acc[q];
+        cls[q] = n > (uint32_t)kSortRegMax ? 2u : (n > (uint32_t)kSortGroupMax ? 1u : (n > (uint32_t)kSortWaveMax ? 0u : 3u));
+        lrank[q] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (cls[q] < 3u) lrank[q] = atomicAdd(&s_heads[cls[q]], 1u);
+    __syncthreads();
+    if (threadIdx.x < 5) {   // five returning atomics, one per lane: a single round trip, not five in a row
+        const uint32_t k = threadIdx.x;
+        uint32_t amount = 0;
+        if (k < 2) for (int w = 0; w < kTotWaves; w++) amount += s_wave[k][w];
+        else amount = s_heads[k - 2];
+        uint32_t* cursor = k == 0 ? &c->num_instances : k == 1 ? &c->num_units : k == 2 ? &c->medium_tiles
+                           : k == 3 ? &c->big_tiles : &c->large_tiles;
+        // (the launch's only workgroup — every image up to 4 096 tiles, 512 x 512 — owns the cursors: plain stores, no
+        // returning-atomic round trip in front of the tables)
+        if (gridDim.x == 1) *cursor = amount, s_base[k] = 0u;
+        else s_base[k] = amount ? atomicAdd(cursor, amount) : 0u;
+        if (blockIdx.x == 0 && k == 0) c->capacity = (uint32_t)capacity;
+    }
+    __syncthreads();
+    uint32_t n_run = s_base[0] + n_inc - n_sum, u_run = s_base[1] + u_inc - u_sum;
+    for (int w = 0; w < wv; w++) n_run += s_wave[0][w], u_run += s_wave[1][w];
+    if (!row_ok) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (tx0 + q >= (uint32_t)v.tiles_x) break;
+        const uint32_t tile = ty * (uint32_t)v.tiles_x + tx0 + q;
+        uint4* dst = reinterpret_cast<uint4*>(v.tile_sub + (size_t)tile * kSubWords);
+#pragma unroll
+        for (int w4 = 0; w4 < kSubWords / 4; w4++)
+            dst[w4] = make_uint4(sub[q][4 * w4], sub[q][4 * w4 + 1], sub[q][4 * w4 + 2], sub[q][4 * w4 + 3]);
+        v.tile_total[tile] = acc[q];
+        v.tile_offset[tile] = n_run;
+        v.unit_offset[tile] = u_run;
+        n_run += acc[q];
+        u_run += (acc[q] + kUnit - 1) / kUnit;
+        if (cls[q] == 0u) v.medium_list[s_base[2] + lrank[q]] = tile;
+        else if (cls[q] == 1u) v.big_list[s_base[3] + lrank[q]] = tile;
+        else if (cls[q] == 2u) v.large_list[s_base[4] + lrank[q]] = tile;
+    }
+    (void)T;
+}
+
+__global__ void __launch_bounds__(64 * kTotWaves) k_tile_totals(TotalsArgs a) { tile_totals_body(a); }
+__global__ void __launch_bounds__(64 * kTotWaves) k_tile_totals_batch(BatchOf<TotalsArgs> b) { tile_totals_body(b.v[blockIdx.y]); }
 
 // reference: checkFrustum, rasterizer_impl.cu:54-66
 __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* means3D, const float* view, uint8_t* present)
@@ -743,14 +867,15 @@ static bool capture_would_grow(const ForwardCall& c)
     const fr_handle_impl* h = c.h;
     const ImageView v = ImageView::make(nullptr, c.prm->W, c.prm->H);
     const size_t T = (size_t)v.tiles_x * v.tiles_y;
-    const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[kHostMaxBucket] : 0u;
+    const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
     return (size_t)c.prm->P > h->accum_rows || v.tpad > h->tile_counter_tiles || !h->key_buckets || T > h->bucket_tiles ||
            h->bucket_cap < need + need / 4;
 }
 
 // Everything one view's forward needs done on the host before its kernels can be enqueued: handle buffers sized, stream
 // ordered behind the handle's previous frame, views of the caller's buffers, the kernels' argument blocks.
-static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, FrameView& f, PreArgs& a, size_t& pre_lds)
+static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, FrameView& f, PreArgs& a, TotalsArgs& tot,
+                           size_t& pre_lds)
 {
     fr_handle_impl* h = c.h;
     const fr_params& prm = *c.prm;
@@ -759,7 +884,7 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     GeomView g = GeomView::make(c.geometry, (size_t)P);
     ImageView v = ImageView::make(c.image, W, H);
     const uint32_t T = (uint32_t)v.tiles_x * v.tiles_y;
-    BinningView b = BinningView::make(c.binning, (size_t)c.cap, (size_t)v.tiles_x, (size_t)v.tiles_y);
+    BinningView b = BinningView::make(c.binning, (size_t)c.cap, (size_t)T);
     int rc;
     // (launch_forward has already refused a capturing stream whose frame would need handle buffers grown: capture_would_grow)
     // the backward's gradient accumulators live in the handle (zero between backward passes): size them here, where an
@@ -771,11 +896,10 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     // enqueued on a different stream (fr_common.hpp, fr_handle_impl::frame_done)
     if (!capturing && h->have_last && h->last_stream != s) FR_HIP(hipStreamWaitEvent(s, h->frame_done, 0));
 
-    // per-tile counters: handle-owned, zero between frames (every tile's sorter restores the zeros), so a frame normally
+    // per-tile counters: handle-owned, zero between frames (k_tile_totals restores the zeros), so a frame normally
     // starts without any zeroing launch.  They are (re)allocated when the tile grid grows — not possible while the
     // stream is being captured into a graph: run one eager frame of the same size first.
-    const size_t counter_words = (size_t)kXcds * v.tpad + v.tpad / 4 + 4096 + 64;   // 8 XCD copies + the heavy-tile flags (a byte per tile,
-                                                                                    // chunks padded to 16: at most 16 x 1024 bytes more)
+    const size_t counter_words = (size_t)kXcds * v.tpad;   // 8 XCD copies
     if (v.tpad > h->tile_counter_tiles) {   // (tile_counter_tiles holds the largest pitch allocated so far)
         if ((rc = release_buffer(h, h->tile_counters, s))) return rc;
         h->tile_counters = nullptr, h->tile_counter_tiles = 0;
@@ -784,18 +908,17 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
         h->counters_clean = false;
     }
     if (!h->counters_clean)
-        if ((rc = launch_zero(h->tile_counters, ((size_t)kXcds * h->tile_counter_tiles + h->tile_counter_tiles / 4 + 4096 + 64) * sizeof(uint32_t), s)))
+        if ((rc = launch_zero(h->tile_counters, (size_t)kXcds * h->tile_counter_tiles * sizeof(uint32_t), s)))
             return rc;
     h->counters_clean = false;  // until every stage of this frame has been enqueued
     v.tile_count = h->tile_counters;
-    v.heavy_flags = reinterpret_cast<uint8_t*>(h->tile_counters + (size_t)kXcds * h->tile_counter_tiles);
 
     // key buckets: handle-owned, [tiles][8 XCDs][bucket_cap].  They grow when the tile grid grows, and their capacity
     // doubles when the last frame that reported back needed more (word 4 of the pinned count slot): that frame was
     // flagged as overflowed, and the caller is repeating it right now.
     {
         uint32_t want = h->bucket_cap ? h->bucket_cap : kBucketCapInit;
-        const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[kHostMaxBucket] : 0u;
+        const uint32_t need = h->counts_seen ? reinterpret_cast<const uint32_t*>(h->host_counts)[4] : 0u;
         while (want < need + need / 4) want <<= 1;
         if (want != h->bucket_cap || (size_t)T > h->bucket_tiles) {
             if ((rc = release_buffer(h, h->key_buckets, s))) return rc;
@@ -820,11 +943,13 @@ static int prepare_forward(const ForwardCall& c, hipStream_t s, bool capturing, 
     a.bound = (prm.aux && prm.aux->binding) ? 1 : 0;
     if (a.bound) a.bind = bind_args(*prm.aux->binding);
     else a.bind = BindArgs{};
-    a.radii = c.radii, a.g = g, a.tile_count = v.tile_count, a.heavy_flags = v.heavy_flags, a.flag_lg = v.flag_lg, a.flag_clen = v.flag_clen, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
-    a.tpad = v.tpad, a.counts = v.counts, a.cells = v.cells;
+    a.radii = c.radii, a.g = g, a.tile_count = v.tile_count, a.buckets = v.buckets, a.bucket_cap = v.bucket_cap;
+    a.tpad = v.tpad, a.counts = v.counts;
     a.tiles_x = v.tiles_x, a.tiles_y = v.tiles_y;
     a.ref_gx = (W + kRefTile - 1) / kRefTile, a.ref_gy = (H + kRefTile - 1) / kRefTile;
     pre_lds = (kPreWG / 64) * (size_t)pre_wave_lds_bytes(prm.M * 3);
+    tot.v = v, tot.T = T, tot.capacity = c.cap, tot.block_ref_tiles = g.block_ref_tiles;
+    tot.n_blocks = (uint32_t)((P + kPreWG - 1) / kPreWG);
     f.h = h, f.prm = c.prm, f.in = c.in, f.g = g, f.v = v, f.b = b, f.out_color = c.out_color;
     return FR_OK;
 }
@@ -833,6 +958,7 @@ int launch_forward(int n, const ForwardCall* calls, hipStream_t s)
 {
     FrameView f[kMaxBatch];
     PreArgs pre[kMaxBatch];
+    TotalsArgs tot[kMaxBatch];
     int rc;
     bool capturing = false;
     for (int k = 0; k < n; k++) capturing = note_capture(calls[k].h, s) || capturing;
@@ -843,13 +969,14 @@ int launch_forward(int n, const ForwardCall* calls, hipStream_t s)
                                 "this frame needs handle buffers (re)allocated, which cannot happen while the stream is "
                                 "being captured: run one eager frame of this size on this handle first");
     size_t pre_lds = 0;
-    uint32_t pre_blocks = 0;
+    uint32_t pre_blocks = 0, tot_blocks = 0;
     bool debug = false, no_wait = true;
     for (int k = 0; k < n; k++) {
         size_t lds;
-        if ((rc = prepare_forward(calls[k], s, capturing, f[k], pre[k], lds))) return rc;
+        if ((rc = prepare_forward(calls[k], s, capturing, f[k], pre[k], tot[k], lds))) return rc;
         pre_lds = lds > pre_lds ? lds : pre_lds;
         pre_blocks = max(pre_blocks, (uint32_t)((calls[k].prm->P + kPreWG - 1) / kPreWG));
+        tot_blocks = max(tot_blocks, (f[k].v.tpad + (uint32_t)(256 * kTotWaves) - 1u) / (uint32_t)(256 * kTotWaves));
         debug = debug || calls[k].prm->debug != 0;
         no_wait = no_wait && (calls[k].prm->flags & FR_FLAG_NO_WAIT) != 0;
     }
@@ -862,9 +989,15 @@ int launch_forward(int n, const ForwardCall* calls, hipStream_t s)
         FR_HIP(hipGetLastError());
         if ((rc = debug_sync(debug, s, "preprocess_fwd"))) return rc;
     }
-    for (int k = 0; k < n; k++)
-        if (calls[k].prm->P <= 0 || pre_blocks == 0)   // (k_preprocess_fwd, which zeroes the frame's device counts, did not run for it)
-            if ((rc = launch_zero(f[k].v.counts, (size_t)(f[k].v.cells - reinterpret_cast<char*>(f[k].v.counts)) + kCellBytes, s))) return rc;
+    {
+        StageScope sc(h0, ST_SCAN, s);
+        for (int k = 0; k < n; k++)
+            if (calls[k].prm->P <= 0 || pre_blocks == 0)   // (k_preprocess_fwd, which zeroes the frame's device counts, did not run for it)
+                if ((rc = launch_zero(f[k].v.counts, sizeof(DeviceCounts), s))) return rc;
+        launch_views(k_tile_totals, k_tile_totals_batch, n, tot, tot_blocks, 64 * kTotWaves, 0, s);
+    }
+    FR_HIP(hipGetLastError());
+    if ((rc = debug_sync(debug, s, "scan_tiles"))) return rc;
     if ((rc = launch_sort_and_blend(n, f, s, debug))) return rc;
     for (int k = 0; k < n; k++) {
         fr_handle_impl* h = calls[k].h;

@@ -87,13 +87,13 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
         const int rc = fr_forward(st.handle, &prm, &in, out_color.data_ptr<float>(), radii.data_ptr<int>(), geom.data_ptr(),
                                   img.data_ptr(), binning.data_ptr(), cap, &counts, stream);
         if (rc == FR_ERR_BINNING_CAPACITY) {
-            cap = (uint64_t)counts.capacity_required * 5 / 4 + 1024;
+            cap = (uint64_t)counts.num_instances * 5 / 4 + 1024;
             continue;
         }
         TORCH_CHECK(rc == FR_OK, "fr_forward failed (code ", rc, "): ", fr_last_error());
         break;
     }
-    st.capacity = std::max<uint64_t>(st.capacity, (uint64_t)counts.capacity_required * 5 / 4 + 1024);
+    st.capacity = std::max<uint64_t>(st.capacity, (uint64_t)counts.num_instances * 5 / 4 + 1024);
     return std::make_tuple((int)counts.num_rendered, out_color, radii, geom, binning, img);
 }
 

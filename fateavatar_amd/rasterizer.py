@@ -111,7 +111,7 @@ def check_async_overflow(device_index: int = 0) -> bool:
     c = read_counts(device_index)
     last_counts[device_index] = c
     if c.overflow:
-        _capacity_hint[device_index] = max(_capacity_hint.get(device_index, 0), int(max(c.capacity_required, c.num_instances) * 1.25) + 1024)
+        _capacity_hint[device_index] = max(_capacity_hint.get(device_index, 0), int(c.num_instances * 1.25) + 1024)
     return bool(c.overflow)
 
 
@@ -206,13 +206,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             rc = L.fr_forward(h, C.byref(prm), C.byref(inp), out_color.data_ptr(), radii.data_ptr(), geom.data_ptr(),
                               img.data_ptr(), binning.data_ptr(), cap, C.byref(counts), stream)
             if rc == _lib.FR_ERR_BINNING_CAPACITY:
-                cap = int(max(counts.capacity_required, counts.num_instances) * 1.25) + 1024
+                cap = int(counts.num_instances * 1.25) + 1024
                 continue
             _check(rc, "fr_forward")
             break
     if _no_wait:  # counts arrive later (read_counts / check_async_overflow)
         return 0, out_color, radii, geom, binning, img
-    _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(max(counts.capacity_required, counts.num_instances) * 1.25) + 1024)
+    _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(counts.num_instances * 1.25) + 1024)
     last_counts[dev] = counts
     return int(counts.num_rendered), out_color, radii, geom, binning, img
 
@@ -340,7 +340,7 @@ def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None, bindi
             if rc == _lib.FR_ERR_BINNING_CAPACITY:
                 for k, v in enumerate(st):
                     if counts[k].overflow:
-                        v["cap"] = int(max(counts[k].capacity_required, counts[k].num_instances) * 1.25) + 1024
+                        v["cap"] = int(counts[k].num_instances * 1.25) + 1024
                 continue
             _check(rc, "fr_forward_batch")
             break
@@ -349,9 +349,8 @@ def rasterize_gaussians_batch(views, slots=None, raw=False, visibles=None, bindi
         if _no_wait:
             out.append((0, v["out_color"], v["radii"], v["geom"], v["binning"], v["img"]))
             continue
-        c = _lib.fr_counts(counts[k].num_rendered, counts[k].num_instances, counts[k].max_tile_list, counts[k].overflow,
-                            counts[k].capacity_required)
-        _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(max(c.capacity_required, c.num_instances) * 1.25) + 1024)
+        c = _lib.fr_counts(counts[k].num_rendered, counts[k].num_instances, counts[k].max_tile_list, counts[k].overflow)
+        _capacity_hint[dev] = max(_capacity_hint.get(dev, 0), int(c.num_instances * 1.25) + 1024)
         last_counts[dev] = c
         out.append((int(c.num_rendered), v["out_color"], v["radii"], v["geom"], v["binning"], v["img"]))
     return out

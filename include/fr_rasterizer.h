@@ -179,11 +179,7 @@ typedef struct fr_counts {
     uint32_t num_rendered;   /* reference semantics: sum over Gaussians of 16x16 tiles touched */
     uint32_t num_instances;  /* (8x8 tile, Gaussian) instances this implementation bins and sorts */
     uint32_t max_tile_list;  /* longest per-tile list */
-    uint32_t overflow;       /* 1 if the frame did not fit the binning capacity (or a handle-owned key bucket): outputs invalid */
-    uint32_t capacity_required;  /* smallest binning_capacity that holds this frame: 8 x the fullest of the eight REGIONS the
-                                  * per-instance arrays are cut into (a tile's list lives in region (tx + 3 ty) & 7, so that
-                                  * lists are placed without a scan over the tiles): >= num_instances, within a few per
-                                  * cent of it for natural images, up to 8 x when every instance sits on tiles of one region */
+    uint32_t overflow;       /* 1 if num_instances exceeded the binning capacity */
 } fr_counts;
 
 int fr_create(fr_handle** out);
@@ -194,8 +190,8 @@ const char* fr_version(void);
 /* Stage timing.  While enabled, every kernel launch of fr_forward / fr_backward is bracketed by HIP
  * events on the stream it is launched on; fr_profile_read sums the elapsed time of one stage over all
  * launches since fr_profile_enable(h, 1) (the stream must have been synchronised by the caller).
- * stage: 0 preprocess_fwd (+ key binning), 1 scan (no launch any more: a tile's sorter adds up its own counters and takes
- * its ranges itself), 2 emit (no launch any more: the preprocess kernel writes the keys), 3 tile_sort, 4 blend_fwd, 5 blend_bwd, 6 preprocess_bwd. */
+ * stage: 0 preprocess_fwd (+ key binning), 1 scan (per-tile totals and range allocation), 2 emit (no launch any more:
+ * the preprocess kernel writes the keys), 3 tile_sort, 4 blend_fwd, 5 blend_bwd, 6 preprocess_bwd. */
 int fr_profile_enable(fr_handle* h, int32_t on);
 int fr_profile_read(fr_handle* h, int32_t stage, double* total_ms, uint32_t* launches);
 
@@ -206,7 +202,7 @@ size_t fr_image_bytes(int32_t W, int32_t H);
 size_t fr_binning_bytes(uint64_t capacity, int32_t W, int32_t H);
 
 /* out_color [3,H,W], radii [P] (reference semantics: ceil(3*sigma_max), 0 if culled).
- * Returns FR_OK, or FR_ERR_BINNING_CAPACITY with counts->capacity_required = capacity required
+ * Returns FR_OK, or FR_ERR_BINNING_CAPACITY with counts->num_instances = capacity required
  * (outputs are then undefined and the call must be repeated with a larger binning buffer). */
 int fr_forward(fr_handle* h, const fr_params* prm, const fr_inputs* in, float* out_color, int32_t* radii,
                void* geometry, void* image, void* binning, uint64_t binning_capacity, fr_counts* counts,
