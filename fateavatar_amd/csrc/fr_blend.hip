@@ -403,9 +403,14 @@ __device__ __forceinline__ void tile_sort_body(const SortArgs& a)
         for (uint32_t item = blockIdx.x; item < nm; item += kMediumSorters) {
             const uint32_t tile = v.medium_list[item];
             const uint32_t n = v.tile_total[tile];
-            if (n <= 512u) sort_tile_group<2>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx2);
-            else if (n <= 1024u) sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx);
-            else sort_tile_group<8>(key_src(v, tile), ids, v.tile_offset[tile], n, wave, lane, sx8);   // (<= kSortGroupMax = 2 048)
+            // (the lane and the wave index are laundered once per item: otherwise every lane-dependent address and predicate of
+            // the three networks below is hoisted out of this loop — which normally runs once — and held in registers for the
+            // kernel's whole life)
+            int ln = lane, wv = wave;
+            asm volatile("" : "+v"(ln), "+s"(wv));
+            if (n <= 512u) sort_tile_group<2>(key_src(v, tile), ids, v.tile_offset[tile], n, wv, ln, sx2);
+            else if (n <= 1024u) sort_tile_group<4>(key_src(v, tile), ids, v.tile_offset[tile], n, wv, ln, sx);
+            else sort_tile_group<8>(key_src(v, tile), ids, v.tile_offset[tile], n, wv, ln, sx8);   // (<= kSortGroupMax = 2 048)
         }
         // Lists longer than 2048 normally go to k_tile_sort_big.  When the host has not launched it (the previous
         // frame had no such list: one launch less per frame) any that turn up are still sorted here, by the slow
