@@ -89,34 +89,28 @@ __device__ __forceinline__ KeySrc key_src(const ImageView& v, uint32_t tile)
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
-// ---- bitonic network, "flip" formulation (every compare-exchange puts the smaller key at the
-// lower index), element index i = r*64 + lane (+ 256*wave in the 4-wave variant).
-template <int K, int MASK, int LOWBIT>
+// ---- bitonic network, "flip" formulation (every compare-exchange puts the smaller key at the lower index).
+// A wave holds 64 K keys, K per lane: ELEMENT e = lane * K + r (the 4-wave variants: + 64 K * wave).  The lane index carries the
+// high bits, so the short exchange distances — 1 .. K/2, which every merge level ends with — are exchanges between a lane's
+// own registers (a compare and four selects per pair, no cross-lane move), and only distances of K and more go through DPP /
+// ds_swizzle / v_permlane32_swap.  (Until round 6 the layout was e = r * 64 + lane: every distance below 64 was a cross-lane
+// exchange — 35 cross-lane stages and one register stage for 256 keys, against 21 and 15 now; one wave's 256 keys 4.1 -> 3 us.)
+// A stage exchanges e with e ^ M: lane ^ (M / K) and register ^ (M & (K - 1)).
+template <int K, int LM, int LOWBIT, int RM>
 __device__ __forceinline__ void lane_stage(u64 (&v)[K], int lane)
 {
-    // partner = lane ^ MASK in the same register; this lane is the lower index iff (lane & LOWBIT) == 0
+    // partner = (lane ^ LM, register ^ RM); this lane holds the lower index iff (lane & LOWBIT) == 0
     const bool lower = (lane & LOWBIT) == 0;
+    u64 b[K];
 #pragma unroll
-    for (int r = 0; r < K; r++) {
-        const u64 a = v[r];
-        const u64 b = lane_xor_u64<MASK>(a, lane);
-        // keep a iff it is the min (lower lane) / the max (upper lane): one 64-bit compare + one select
-        v[r] = ((a < b) == lower) ? a : b;
-    }
-}
-template <int K>
-__device__ __forceinline__ void lane_cleaners_from_32(u64 (&v)[K], int lane)
-{
-    lane_stage<K, 32, 32>(v, lane);
-    lane_stage<K, 16, 16>(v, lane);
-    lane_stage<K, 8, 8>(v, lane);
-    lane_stage<K, 4, 4>(v, lane);
-    lane_stage<K, 2, 2>(v, lane);
-    lane_stage<K, 1, 1>(v, lane);
+    for (int r = 0; r < K; r++) b[r] = lane_xor_u64<LM>(v[r ^ RM], lane);
+#pragma unroll
+    for (int r = 0; r < K; r++) v[r] = ((v[r] < b[r]) == lower) ? v[r] : b[r];   // keep the min (lower lane) / the max (upper lane)
 }
 template <int K, int JR>
-__device__ __forceinline__ void reg_cleaner(u64 (&v)[K])
+__device__ __forceinline__ void reg_stage(u64 (&v)[K])
 {
+    // pairs (r, r ^ JR) of a lane's own registers: the smaller key to the lower register
 #pragma unroll
     for (int r = 0; r < K; r++) {
         const int rp = r ^ JR;
@@ -127,54 +121,44 @@ __device__ __forceinline__ void reg_cleaner(u64 (&v)[K])
         }
     }
 }
-
-template <int K, int JR>
-__device__ __forceinline__ void reg_cleaners_from(u64 (&v)[K])
+// half-cleaners at element distances J, J/2, ..., 1
+template <int K, int J>
+__device__ __forceinline__ void cleaners_from(u64 (&v)[K], int lane)
 {
-    // half-cleaners at register distances JR, JR/2, ..., 1 (element distances 64*JR ... 64)
-    if constexpr (JR >= 1) {
-        reg_cleaner<K, JR>(v);
-        reg_cleaners_from<K, JR / 2>(v);
+    if constexpr (J >= 1) {
+        if constexpr (J >= K) lane_stage<K, J / K, J / K, 0>(v, lane);
+        else reg_stage<K, J>(v);
+        cleaners_from<K, J / 2>(v, lane);
     }
 }
-
+// one merge level: blocks of KK elements (flip with e ^ (KK - 1), then the half-cleaners KK/4 ... 1)
 template <int K, int KK>
-__device__ __forceinline__ void big_stage(u64 (&v)[K], int lane)
+__device__ __forceinline__ void merge_level(u64 (&v)[K], int lane)
 {
-    // merge step for blocks of KK in {128 ... 1024} elements held by one wave
-    constexpr int m = (KK >> 6) - 1;
-    // flip: partner index = i ^ (KK-1)  ->  register r ^ m, lane ^ 63
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const int rp = r ^ m;
-        if (rp > r) {
-            const u64 a = v[r], b = v[rp];
-            const u64 sa = lane_xor_u64<63>(a, lane), sb = lane_xor_u64<63>(b, lane);
-            v[r] = (a < sb) ? a : sb;
-            v[rp] = (b < sa) ? sa : b;
-        }
+    if constexpr (KK <= K) reg_stage<K, KK - 1>(v);
+    else lane_stage<K, KK / K - 1, KK / K / 2, K - 1>(v, lane);
+    cleaners_from<K, KK / 4>(v, lane);
+}
+template <int K, int KK>
+__device__ __forceinline__ void merge_levels_up_to(u64 (&v)[K], int lane)
+{
+    if constexpr (KK >= 2) {
+        merge_levels_up_to<K, KK / 2>(v, lane);
+        merge_level<K, KK>(v, lane);
     }
-    reg_cleaners_from<K, (KK >> 8)>(v);  // distances KK/4 ... 64
-    lane_cleaners_from_32<K>(v, lane);
+}
+// the cleaners behind a cross-wave stage: element distances 32 K ... 1 inside the wave
+template <int K>
+__device__ __forceinline__ void wave_cleaners(u64 (&v)[K], int lane)
+{
+    cleaners_from<K, 32 * K>(v, lane);
 }
 
-// one wave sorts 64*K keys (K <= 4)
+// one wave sorts 64*K keys (K = 1, 2, 4, 8, 16)
 template <int K>
 __device__ __forceinline__ void wave_sort(u64 (&v)[K], int lane)
 {
-    lane_stage<K, 1, 1>(v, lane);                                   // k = 2
-    lane_stage<K, 3, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);    // k = 4
-    lane_stage<K, 7, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);  // k = 8
-    lane_stage<K, 15, 8>(v, lane); lane_stage<K, 4, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);
-    lane_stage<K, 1, 1>(v, lane);                                   // k = 16
-    lane_stage<K, 31, 16>(v, lane); lane_stage<K, 8, 8>(v, lane); lane_stage<K, 4, 4>(v, lane);
-    lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);    // k = 32
-    lane_stage<K, 63, 32>(v, lane); lane_stage<K, 16, 16>(v, lane); lane_stage<K, 8, 8>(v, lane);
-    lane_stage<K, 4, 4>(v, lane);  lane_stage<K, 2, 2>(v, lane);  lane_stage<K, 1, 1>(v, lane);  // k = 64
-    if constexpr (K >= 2) big_stage<K, 128>(v, lane);
-    if constexpr (K >= 4) big_stage<K, 256>(v, lane);
-    if constexpr (K >= 8) big_stage<K, 512>(v, lane);
-    if constexpr (K >= 16) big_stage<K, 1024>(v, lane);
+    merge_levels_up_to<K, 64 * K>(v, lane);
 }
 
 // Which of the 64 pixels of tile (tile_x0, tile_y0) can pass the blend's alpha >= 1/255 test for this splat: a
@@ -226,7 +210,7 @@ __device__ __forceinline__ void write_ids(uint32_t* ids, uint32_t start, uint32_
 {
 #pragma unroll
     for (int r = 0; r < K; r++) {
-        const uint32_t i = base + (uint32_t)(r * 64 + lane);
+        const uint32_t i = base + (uint32_t)(lane * K + r);   // (K consecutive ids per lane)
         if (i < n) ids[start + i] = (uint32_t)v[r];
     }
 }
@@ -237,7 +221,7 @@ __device__ __forceinline__ void sort_tile_regs(const KeySrc& keys, uint32_t* ids
     u64 v[K];
 #pragma unroll
     for (int r = 0; r < K; r++) {
-        const uint32_t i = (uint32_t)(r * 64 + lane);
+        const uint32_t i = (uint32_t)(lane * K + r);
         v[r] = i < n ? keys.key(i) : ~0ull;
     }
     wave_sort<K>(v, lane);
@@ -275,19 +259,17 @@ __device__ void sort_tile_group(const KeySrc& keys, uint32_t* ids, uint32_t star
     u64 v[K];
 #pragma unroll
     for (int r = 0; r < K; r++) {
-        const uint32_t i = (uint32_t)(wave * KW + r * 64 + lane);
+        const uint32_t i = (uint32_t)(wave * KW + lane * K + r);
         v[r] = i < n ? keys.key(i) : ~0ull;
     }
     wave_sort<K>(v, lane);
-    // blocks of 2*KW: flip with wave ^ 1, then register / lane distances inside the wave
+    // blocks of 2*KW: flip with wave ^ 1 (element e ^ (KW - 1): lane ^ 63, register ^ (K - 1)), then the distances inside the wave
     cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaners_from<K, K / 2>(v);
-    lane_cleaners_from_32<K>(v, lane);
+    wave_cleaners<K>(v, lane);
     // blocks of 4*KW: flip with wave ^ 3, distance KW with wave ^ 1, then inside the wave
     cross_wave_stage<K, true>(v, sx, wave, lane, wave ^ 3, (wave & 2) == 0);
     cross_wave_stage<K, false>(v, sx, wave, lane, wave ^ 1, (wave & 1) == 0);
-    reg_cleaners_from<K, K / 2>(v);
-    lane_cleaners_from_32<K>(v, lane);
+    wave_cleaners<K>(v, lane);
     write_ids<K>(ids, start, n, (uint32_t)(wave * KW), v, lane);
 }
 
